@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference (kasvii/GATOR,
+mounted read-only at /root/reference) on CPU with import shims.  Dev-container only: the reference
+never travels to the GPU box; only the small data fixtures written here do.
+
+Usage:  python tools/gen_golden.py            (re-creates tests/golden/*.npz)
+
+Shims: timm DropPath/Mlp stubs, easydict stub, a pre-seeded core.config.cfg (the real
+one mkdirs under the read-only tree at import), funcs_utils stub (imports cv2/matplotlib), a 3-point
+affine solve standing in for cv2.getAffineTransform, identity .cuda(), Mesh default device -> cpu,
+chdir to a scratch dir holding seeded stand-ins for the licence-gated data/base_data files.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+
+from gator_amd import synthetic  # noqa: E402
+from oracle import graph_consts as gc  # noqa: E402  (Floyd-Warshall output = the path files fed to the reference)
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+
+class _EasyDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def install_shims(scratch, alpha):
+    # timm
+    timm = types.ModuleType('timm')
+    tm = types.ModuleType('timm.models')
+    tl = types.ModuleType('timm.models.layers')
+    tv = types.ModuleType('timm.models.vision_transformer')
+
+    class DropPath(nn.Module):
+        def __init__(self, p=0.):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    class Mlp(nn.Module):
+        def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+            super().__init__()
+            out_features = out_features or in_features
+            self.fc1 = nn.Linear(in_features, hidden_features)
+            self.act = act_layer()
+            self.fc2 = nn.Linear(hidden_features, out_features)
+            self.drop = nn.Dropout(drop)
+
+        def forward(self, x):
+            return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+    tl.DropPath = DropPath
+    tv.Mlp = Mlp
+    sys.modules.update({'timm': timm, 'timm.models': tm, 'timm.models.layers': tl,
+                        'timm.models.vision_transformer': tv})
+    ed = types.ModuleType('easydict')
+    ed.EasyDict = _EasyDict
+    sys.modules['easydict'] = ed
+    # core.config
+    cfg = _EasyDict()
+    cfg.DATASET = _EasyDict(BASE_DATA_DIR=os.path.join(scratch, 'data', 'base_data'))
+    cfg.MODEL = _EasyDict(alpha=alpha, posenet_pretrained=False, posenet_path='', input_shape=(384, 288))
+    core = types.ModuleType('core')
+    cc = types.ModuleType('core.config')
+    cc.cfg = cfg
+    core.config = cc
+    sys.modules.update({'core': core, 'core.config': cc})
+    fu = types.ModuleType('funcs_utils')
+    fu.load_checkpoint = lambda *a, **k: (_ for _ in ()).throw(ValueError('No checkpoint exists'))
+    sys.modules['funcs_utils'] = fu
+    # cv2: only getAffineTransform is reached (lib/aug_utils.py:164-167)
+    cv2 = types.ModuleType('cv2')
+
+    def get_affine_transform(src, dst):
+        a = np.concatenate([np.asarray(src, np.float64), np.ones((3, 1))], 1)
+        return np.linalg.solve(a, np.asarray(dst, np.float64)).T
+
+    cv2.getAffineTransform = get_affine_transform
+    sys.modules['cv2'] = cv2
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    for p in (os.path.join(REF, 'lib'),):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    return cfg
+
+
+def write_base_data(scratch, base, sp, path, tag):
+    d = os.path.join(scratch, 'data', 'base_data')
+    os.makedirs(d, exist_ok=True)
+    np.save(os.path.join(d, 'smpl_mean_vertices.npy'), base['smpl_mean_vertices'])
+    np.save(os.path.join(d, 'J_regressor_h36m.npy'), base['J_regressor_h36m'])
+    import scipy.sparse as sps
+    D = np.empty(2, dtype=object)
+    D[0], D[1] = base['D'][0].tocoo(), base['D'][1].tocoo()
+    U = np.empty(2, dtype=object)
+    U[0], U[1] = base['D'][0].T.tocoo(), base['D'][1].T.tocoo()
+    A = np.empty(3, dtype=object)
+    A[0], A[1], A[2] = sps.identity(6890).tocoo(), sps.identity(1723).tocoo(), sps.identity(431).tocoo()
+    np.savez(os.path.join(d, 'mesh_downsampling.npz'), A=A, U=U, D=D)
+    np.save(os.path.join(d, 'shortest_path_%s.npy' % tag), sp)
+    np.save(os.path.join(d, 'path_%s.npy' % tag), path)
+
+
+def dump_jregressors():
+    z = {}
+    for name, f in (('h36m', 'data/Human36M/J_regressor_h36m_correct.npy'), ('coco', 'data/COCO/J_regressor_coco.npy')):
+        m = np.load(os.path.join(REF, f))
+        r, c = np.nonzero(m)
+        z[name + '_row'], z[name + '_col'], z[name + '_val'] = r.astype(np.int32), c.astype(np.int32), m[r, c]
+    np.savez(os.path.join(OUT, 'j_regressors.npz'), **z)
+
+
+def run_variant(name, J, alpha, seed, B=4):
+    import scipy.sparse as sps
+    scratch = tempfile.mkdtemp(prefix='gator_golden_')
+    for m in [k for k in sys.modules if k.split('.')[0] in ('models', 'graph_utils', 'coarsening', 'core', 'funcs_utils')]:
+        del sys.modules[m]
+    install_shims(scratch, alpha)
+    base = synthetic.make_base_data(seed)
+    rs = base['rs']
+    skeleton, flips = gc.joint_setting(J)
+    adj0 = gc.build_adj(J, skeleton, flips)
+    sp, path = gc.floyd_warshall(gc.delete_symmetric_edges(adj0))
+    tag = '3dpw' if J == 19 else 'h36m'
+    write_base_data(scratch, base, sp, path, tag)
+    os.chdir(scratch)
+    import models  # noqa  (reference lib/models)
+    from models.backbones import mesh as ref_mesh
+    ref_mesh.Mesh.__init__.__defaults__ = ('data/base_data/mesh_downsampling.npz', 1, 1, torch.device('cpu'))
+    import graph_utils
+    ref_adj = graph_utils.build_adj(J, skeleton, flips)            # the reference's own adjacency builder
+    assert np.array_equal(ref_adj, adj0)
+    graph_adj = [None, sps.csr_matrix(ref_adj)]
+    jreg = synthetic.model_j_regressor(J)
+    model = models.GATOR.get_model(J, 128, 6, graph_adj, 1, torch.Tensor(jreg))
+    model.eval()
+    sd = model.state_dict()
+    new = synthetic.seeded_state_dict(synthetic.shapes_of(sd), rs)
+    sd.update({k: torch.from_numpy(v) for k, v in new.items()})
+    model.load_state_dict(sd)
+    pose2d = synthetic.synthetic_pose2d(B, J, seed + 1)
+    x = torch.from_numpy(pose2d)
+
+    taps = {}
+    hooks = []
+
+    def tap(mod, key, sel=lambda o: o):
+        hooks.append(mod.register_forward_hook(lambda m, i, o: taps.__setitem__(key, sel(o).detach().clone())))
+
+    tap(model.pose_lifter.get_hop_path_encoding, 'hop_path_bias')
+    tap(model.pose_lifter, 'feat', lambda o: o[1])
+    for i, blk in enumerate(model.pose_lifter.blocks):
+        tap(blk, 'gat_block%d' % i, lambda o: o[0])
+    tap(model.pose2mesh.selfatt, 'mdr_attn0')
+    tap(model.pose2mesh.norm_2, 'mdr_norm2')
+    tap(model.pose2mesh.upsample_conv, 'vert431_in')
+    up_in = {}
+    hooks.append(model.pose2mesh.upsample_conv.register_forward_hook(
+        lambda m, i, o: up_in.__setitem__('vert431', i[0].detach().clone())))
+    # verts tokens after the 3rd LBF layer = input of motion_linear
+    hooks.append(model.pose2mesh.motion_linear.register_forward_hook(
+        lambda m, i, o: taps.__setitem__('mdr_lbf2', i[0].detach().clone())))
+    with torch.no_grad():
+        verts, pose3d = model(x)
+    for h in hooks:
+        h.remove()
+    # fp64 re-evaluation of the same weights (tolerance anchor): cast plain-attribute tensors by hand
+    m64 = model.double()
+    for blk in m64.pose_lifter.blocks:
+        blk.adj = blk.adj.double()
+        blk.gcn.adj = blk.gcn.adj.double()
+    hp = m64.pose_lifter.get_hop_path_encoding
+    hp.edg_adj = hp.edg_adj.double()
+    hp.spatial = hp.spatial.double()
+    with torch.no_grad():
+        verts64, pose3d64 = m64(x.double())
+    gat = model.pose_lifter
+    out = dict(
+        seed=np.int64(seed), alpha=np.bool_(alpha), num_joint=np.int64(J),
+        pose2d=pose2d, verts=verts.float().numpy(), pose3d=pose3d.float().numpy(),
+        verts_f64=verts64.numpy(), pose3d_f64=pose3d64.numpy(),
+        hop_path_bias=taps['hop_path_bias'].float().numpy(), feat=taps['feat'].float().numpy(),
+        gat_block0=taps['gat_block0'].float().numpy(), gat_block5=taps['gat_block5'].float().numpy(),
+        mdr_lbf2=taps['mdr_lbf2'].float().numpy(), vert431=up_in['vert431'].float().numpy(),
+        graph_adj=gat.graph_adj.float().numpy(), shortest_path=sp, path=path,
+        edge_input=hp.edg_adj.float().numpy(),
+        vj_relation=np.asarray(model.pose2mesh.vj_relation, np.int64),
+        init_vertices_431=sd['pose2mesh.init_vertices'].float().numpy(),
+        state_dict_keys=np.array(sorted(sd.keys())),
+        state_dict_shapes=np.array([str(tuple(sd[k].shape)) for k in sorted(sd.keys())]),
+        # spot checks of the seeded weights so a recipe drift is caught without storing 46 MB
+        w_probe_lifter=sd['pose_lifter.lifter.weight'].float().numpy()[:2, :8],
+        w_probe_upconv=sd['pose2mesh.upsample_conv.weight'].float().numpy()[:2, :3],
+    )
+    err = np.abs(out['verts'].astype(np.float64) - out['verts_f64']).max() * 1000
+    print('%s: J=%d alpha=%s  |verts| max %.3f m  fp32-vs-fp64 max %.2e mm' % (name, J, alpha, np.abs(out['verts']).max(), err))
+    np.savez(os.path.join(OUT, name + '.npz'), **out)
+    os.chdir(REPO)
+
+
+def demo_preprocess_golden():
+    """Config 1 plumbing (demo/run.py:193-198,124-133): raw COCO-17 joints -> [1,19,2] normalised input."""
+    scratch = tempfile.mkdtemp(prefix='gator_golden_')
+    install_shims(scratch, True)
+    for m in [k for k in sys.modules if k in ('coord_utils', 'aug_utils')]:
+        del sys.modules[m]
+    import aug_utils
+    import coord_utils
+    raw = np.load(os.path.join(REF, 'demo', 'coco_joint_input.npy'))
+    names = ('Nose', 'L_Eye', 'R_Eye', 'L_Ear', 'R_Ear', 'L_Shoulder', 'R_Shoulder', 'L_Elbow', 'R_Elbow', 'L_Wrist',
+             'R_Wrist', 'L_Hip', 'R_Hip', 'L_Knee', 'R_Knee', 'L_Ankle', 'R_Ankle', 'Pelvis', 'Neck')
+    j = raw.copy()
+
+    def add(jc, a, b):
+        n = (jc[names.index(a)] + jc[names.index(b)]) * 0.5
+        n[2] = jc[names.index(a), 2] * jc[names.index(b), 2]
+        return np.concatenate((jc, n.reshape(1, 3)))
+
+    j = add(j, 'L_Hip', 'R_Hip')
+    j = add(j, 'L_Shoulder', 'R_Shoulder')
+    j = j[:, :2]
+    bbox = coord_utils.get_bbox(j)
+    bbox2 = coord_utils.process_bbox(bbox.copy())
+    ji, _ = aug_utils.j2d_processing(j.copy(), (288, 384), bbox2, 0, 0, None)
+    ji = ji[:, :2]
+    ji /= np.array([[288, 384]])
+    mean, std = np.mean(ji, axis=0), np.std(ji, axis=0)
+    ji = (ji.copy() - mean) / std
+    np.savez(os.path.join(OUT, 'demo_preprocess.npz'), raw_coco17=raw, pose2d=ji[None].astype(np.float32))
+    print('demo: normalised rows 0-3', ji[:4].round(4).tolist(), 'min %.4f max %.4f' % (ji.min(), ji.max()))
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    dump_jregressors()
+    run_variant('h36m17_bn', 17, False, seed=0)
+    run_variant('coco19_alpha', 19, True, seed=100)
+    demo_preprocess_golden()
