@@ -1,0 +1,61 @@
+"""ctypes binding of libgator_hip.so (C ABI: include/gator_hip.h).  No fallback: if the library is missing or
+does not load, importing the HIP path raises -- the product never routes through a CPU implementation."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libgator_hip.so')
+
+GATOR_F32, GATOR_I64, GATOR_I32 = 0, 1, 2
+IMPL_FUSED, IMPL_BASIC = 0, 1
+PART_GAT, PART_MDR = 1, 2
+
+
+class GatorTensor(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char_p), ('data', ctypes.c_void_p), ('dtype', ctypes.c_int32), ('ndim', ctypes.c_int32),
+                ('shape', ctypes.c_int64 * 4), ('is_host', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+class GatorConfig(ctypes.Structure):
+    _fields_ = [('num_joint', ctypes.c_int32), ('alpha', ctypes.c_int32), ('impl', ctypes.c_int32),
+                ('max_batch', ctypes.c_int32), ('parts', ctypes.c_int32)]
+
+
+# every symbol include/gator_hip.h declares: name -> (restype, argtypes)
+_P, _I, _L = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+SIGNATURES = {
+    'gator_create': (_I, [ctypes.POINTER(GatorTensor), _I, ctypes.POINTER(GatorConfig), ctypes.POINTER(_P)]),
+    'gator_destroy': (_I, [_P]),
+    'gator_forward_f32': (_I, [_P, _P, _I, _P, _P, _P]),
+    'gator_gat_forward_f32': (_I, [_P, _P, _I, _P, _P, _P]),
+    'gator_mdr_forward_f32': (_I, [_P, _P, _I, _P, _P]),
+    'gator_upsample_f32': (_I, [_P, _P, _I, _P, _P]),
+    'gator_get_tap': (_I, [_P, ctypes.c_char_p, _P, _L, ctypes.POINTER(_L), _P]),
+    'gator_regress_joints_f32': (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P]),
+    'gator_floyd_warshall': (_I, [_P, _I, _P, _P]),
+    'gator_gen_edge_input': (_I, [_P, _P, _I, _I, _P]),
+    'gator_verts_joints_relation': (_I, [_P, _I, _P, _I, _P]),
+    'gator_last_error': (ctypes.c_char_p, []),
+    'gator_version': (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libgator_hip.so not built (%s); run `python -m gator_amd.build` -- there is no CPU fallback'
+                               % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, load().gator_last_error().decode()))

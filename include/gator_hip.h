@@ -1,0 +1,109 @@
+/*
+ * gator_hip.h -- C ABI of libgator_hip.so: the MI355X (gfx950) implementation of the GATOR inference
+ * forward pass (GAT graph-aware transformer encoder -> MDR regression head -> 6890 SMPL vertices).
+ *
+ * The reference (kasvii/GATOR) has no FFI of its own: its boundary for this path is the Python
+ * nn.Module API of lib/models (GATOR.py:16-27, GAT.py:133-156, MDR.py:124-174).  These entry points are
+ * what a binding for that boundary calls; the modules under gator_amd/models/ are such a binding (ctypes) and
+ * INTEGRATION.md shows the stub a reference maintainer would add.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative gator_status otherwise; gator_last_error() then
+ *     returns a thread-local human-readable message (reference convention: Python exceptions,
+ *     lib/funcs_utils.py:121-127 -> the Python wrapper raises RuntimeError).
+ *   - "device pointer" = hipMalloc'd memory on the ctx's device (a torch tensor's data_ptr()).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is enqueued on it
+ *     and nothing synchronises the host.  A ctx is not thread-safe: one ctx per device per thread.
+ */
+#ifndef GATOR_HIP_H
+#define GATOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gator_ctx gator_ctx;
+
+typedef enum { GATOR_OK = 0, GATOR_EINVAL = -1, GATOR_EMISSING = -2, GATOR_ESHAPE = -3, GATOR_EHIP = -4,
+               GATOR_ENOMEM = -5, GATOR_EUNSUPPORTED = -6 } gator_status;
+
+typedef enum { GATOR_F32 = 0, GATOR_I64 = 1, GATOR_I32 = 2 } gator_dtype;
+
+/* One named tensor.  Names are the reference checkpoint's state_dict keys (SURVEY.md Appendix B:
+ * "pose_lifter.blocks.0.attn.qkv.weight", "pose2mesh.upsample_conv.weight", ...) -- the checkpoint layout IS
+ * the weight contract (lib/core/base.py:70, demo/run.py:98) -- plus the derived constants the reference keeps as
+ * plain module attributes:
+ *     "const.shortest_path" i64 [J,J]   (data/base_data/shortest_path_*.npy, lib/models/GAT.py:89-93)
+ *     "const.edge_input"    f32 [J,J,D] (gen_edg_input, lib/models/backbones/modules.py:13-29)
+ *     "const.vj_relation"   i32 [431]   (build_verts_joints_relation, lib/graph_utils.py:71-89)
+ * `data` may be a device or a host pointer (is_host says which); the ctx copies what it needs. */
+typedef struct {
+    const char* name;
+    const void* data;
+    int32_t dtype;      /* gator_dtype */
+    int32_t ndim;       /* <= 4 */
+    int64_t shape[4];
+    int32_t is_host;
+    int32_t reserved;
+} gator_tensor;
+
+typedef enum { GATOR_IMPL_FUSED = 0,   /* MFMA / register-resident fused kernels (default) */
+               GATOR_IMPL_BASIC = 1    /* bring-up kernels: one simple HIP kernel per reference op; used as an
+                                          on-device cross-check of the fused path */
+} gator_impl;
+
+typedef enum { GATOR_PART_GAT = 1,    /* pose_lifter.*  (models.GAT.get_model used stand-alone, lib/core/base.py:59) */
+               GATOR_PART_MDR = 2     /* pose2mesh.*    (models.MDR.get_model, lib/models/MDR.py:172-174) */
+} gator_parts;
+
+typedef struct {
+    int32_t num_joint;   /* 17 (Human3.6M) or 19 (COCO + pelvis + neck); lib/models/GAT.py:79-93 */
+    int32_t alpha;       /* cfg.MODEL.alpha: LayerNorm(3)+scale head instead of BatchNorm1d(431); MDR.py:115-119,162 */
+    int32_t impl;        /* gator_impl */
+    int32_t max_batch;   /* workspace is sized for this many samples up front (0 = grow on demand) */
+    int32_t parts;       /* gator_parts bitmask: which sub-modules' weights are present (0 = both) */
+} gator_config;
+
+/* Replaces: models.GATOR.get_model(...) + load_state_dict + .cuda()  (lib/models/GATOR.py:24-27,
+ * lib/core/base.py:57,70,197).  Copies/packs the weights, folds the input-independent constants
+ * (hop/path attention bias modules.py:98-107, MGCN adjacency :247-249, hop masks :163-170, BatchNorm affine). */
+int gator_create(const gator_tensor* tensors, int32_t n_tensors, const gator_config* cfg, gator_ctx** out);
+int gator_destroy(gator_ctx* ctx);
+
+/* Replaces: GATOR.forward (lib/models/GATOR.py:16-22).
+ *   pose2d [B,J,2] f32 device, contiguous  ->  verts [B,6890,3] f32 (metres), pose3d [B,J,3] f32 (mm). */
+int gator_forward_f32(gator_ctx* ctx, const float* pose2d, int32_t batch, float* verts, float* pose3d, void* stream);
+
+/* Stage entry points (parity tests; same semantics as the reference sub-modules):
+ *   GAT.forward   lib/models/GAT.py:133-152 : pose2d [B,J,2] -> x_out [B,3J] (mm), feat [B,J,128]
+ *   MDR.forward   lib/models/MDR.py:124-170 : pose_combine [B,J,133] -> verts [B,6890,3]
+ *   upsample_conv + template add  MDR.py:167-168 : vert431 [B,431,3] -> verts [B,6890,3]              */
+int gator_gat_forward_f32(gator_ctx* ctx, const float* pose2d, int32_t batch, float* x_out, float* feat, void* stream);
+int gator_mdr_forward_f32(gator_ctx* ctx, const float* pose_combine, int32_t batch, float* verts, void* stream);
+int gator_upsample_f32(gator_ctx* ctx, const float* vert431, int32_t batch, float* verts, void* stream);
+
+/* Debug taps of the LAST forward on this ctx, converted to the reference's layout:
+ *   "hop_path_bias" [8,J,J]   "feat" [B,J,128]   "mdr_lbf2" [B,431,64]   "vert431" [B,431,3]
+ * dst is a device pointer with room for `capacity` floats; *count receives the element count. */
+int gator_get_tap(gator_ctx* ctx, const char* name, float* dst, int64_t capacity, int64_t* count, void* stream);
+
+/* "Next" row 8(f)-1: J_regressor @ verts (lib/core/base.py:221, demo/run.py:142) as a sparse product.
+ *   coo_{row,col,val}: nnz entries of a [n_joint,6890] regressor (device); joints [B,n_joint,3]. */
+int gator_regress_joints_f32(const float* verts, int32_t batch, const int32_t* coo_row, const int32_t* coo_col,
+                             const float* coo_val, int32_t nnz, int32_t n_joint, float* joints, void* stream);
+
+/* Host-side graph constants (no GPU needed).  Replace the absent Cython algos.pyx
+ * (lib/models/backbones/setup.py:1-6) and lib/models/backbones/modules.py:6-29, lib/graph_utils.py:71-89. */
+int gator_floyd_warshall(const float* adj, int32_t n, int64_t* dist, int64_t* path);
+int gator_gen_edge_input(const int64_t* path, const float* edge_len, int32_t n, int32_t max_dist, float* out);
+int gator_verts_joints_relation(const float* joints, int32_t n_joint, const float* verts, int32_t n_vert, int32_t* rel);
+
+const char* gator_last_error(void);
+const char* gator_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GATOR_HIP_H */
