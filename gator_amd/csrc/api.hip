@@ -18,6 +18,18 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+StageTimer::StageTimer(gator_ctx* c_, const char* name, void* stream_) : c(c_), stream(stream_), idx(-1) {
+    if (!c->profiling) return;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    (void)hipEventRecord(a, (hipStream_t)stream);
+    idx = (int)c->prof.size();
+    c->prof.push_back({name, a, b});
+}
+StageTimer::~StageTimer() {
+    if (idx >= 0) (void)hipEventRecord((hipEvent_t)c->prof[idx].stop, (hipStream_t)stream);
+}
+
 namespace {
 
 struct Resolver {
@@ -168,9 +180,12 @@ using namespace gator;
 extern "C" const char* gator_last_error(void) { return g_err; }
 extern "C" const char* gator_version(void) { return "gator-amd 0.1 (gfx950)"; }
 
+static void prof_clear(gator_ctx* c);
+
 extern "C" int gator_destroy(gator_ctx* c) {
     if (!c) return GATOR_OK;
     fused_destroy(c);
+    prof_clear(c);
     if (c->ws) (void)hipFree(c->ws);
     if (c->arena) (void)hipFree(c->arena);
     delete c;
@@ -287,12 +302,55 @@ extern "C" int gator_forward_f32(gator_ctx* c, const float* pose2d, int32_t B, f
     if (c->impl != GATOR_IMPL_BASIC) return fused_forward(c, pose2d, B, verts, pose3d, stream);
     const BasicLayout L = basic_layout(c->J, c->cap_batch);
     float *feat = c->ws + L.feat, *xout = c->ws + L.xout, *pc = c->ws + L.pc;
-    rc = basic_gat_forward(c, pose2d, B, xout, feat, stream);
+    { StageTimer t(c, "gat", stream); rc = basic_gat_forward(c, pose2d, B, xout, feat, stream); }
     if (rc) return rc;
     c->taps["feat"] = {feat, (int64_t)B * c->J * kC};
     rc = basic_build_pc(c, pose2d, xout, feat, B, pc, pose3d, stream);
     if (rc) return rc;
+    StageTimer t(c, "mdr+upsample", stream);
     return basic_mdr_forward(c, pc, B, verts, stream);
+}
+
+static void prof_clear(gator_ctx* c) {
+    for (auto& r : c->prof) { (void)hipEventDestroy((hipEvent_t)r.start); (void)hipEventDestroy((hipEvent_t)r.stop); }
+    c->prof.clear();
+}
+
+extern "C" int gator_profile_enable(gator_ctx* c, int32_t on) {
+    if (!c) return fail(GATOR_EINVAL, "gator_profile_enable: null ctx");
+    prof_clear(c);
+    c->profiling = on != 0;
+    return GATOR_OK;
+}
+
+extern "C" int gator_profile_read(gator_ctx* c, char* names, int64_t cap, float* total_ms, int32_t* calls, int32_t max_entries,
+                                  int32_t* n_entries) {
+    if (!c || !names || !total_ms || !calls || !n_entries || cap <= 0) return fail(GATOR_EINVAL, "gator_profile_read: null argument");
+    std::vector<std::string> order;
+    std::map<std::string, std::pair<double, int>> acc;
+    for (auto& r : c->prof) {
+        GATOR_HIP_CHECK(hipEventSynchronize((hipEvent_t)r.stop));
+        float ms = 0.f;
+        GATOR_HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)r.start, (hipEvent_t)r.stop));
+        if (!acc.count(r.name)) order.push_back(r.name);
+        acc[r.name].first += ms;
+        acc[r.name].second += 1;
+    }
+    prof_clear(c);
+    std::string joined;
+    int n = 0;
+    for (auto& k : order) {
+        if (n >= max_entries) break;
+        if (n) joined += "\n";
+        joined += k;
+        total_ms[n] = (float)acc[k].first;
+        calls[n] = acc[k].second;
+        ++n;
+    }
+    if ((int64_t)joined.size() + 1 > cap) return fail(GATOR_ESHAPE, "gator_profile_read: names buffer too small");
+    memcpy(names, joined.c_str(), joined.size() + 1);
+    *n_entries = n;
+    return GATOR_OK;
 }
 
 extern "C" int gator_get_tap(gator_ctx* c, const char* name, float* dst, int64_t capacity, int64_t* count, void* stream) {

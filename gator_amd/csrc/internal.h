@@ -55,6 +55,7 @@ struct Weights {
 };
 
 struct FusedState;   // packed weights + workspace of the fused path (fused_*.hip)
+struct ProfRec { const char* name; void* start; void* stop; };
 
 }  // namespace gator
 
@@ -79,6 +80,9 @@ struct gator_ctx {
     int last_batch = 0;
     std::map<std::string, std::pair<const float*, int64_t>> taps;   // name -> (device ptr, numel) of the last forward
     gator::FusedState* fused = nullptr;
+    // measurement hook (gator_profile_*): (stage name, start event, stop event) per launch
+    bool profiling = false;
+    std::vector<gator::ProfRec> prof;
 };
 
 namespace gator {
@@ -98,6 +102,15 @@ int fused_gat_forward(gator_ctx* c, const float* pose2d, int B, float* x_out, fl
 int fused_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* stream);
 int fused_upsample(gator_ctx* c, const float* vert431, int B, float* verts, void* stream);
 int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream);
+}  // namespace gator
+
+namespace gator {
+// RAII stage bracket: records hipEvents around a stage when ctx->profiling (defined in api.hip)
+struct StageTimer {
+    gator_ctx* c; void* stream; int idx;
+    StageTimer(gator_ctx* c, const char* name, void* stream);
+    ~StageTimer();
+};
 }  // namespace gator
 
 #define GATOR_HIP_CHECK(expr)                                                                         \

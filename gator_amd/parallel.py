@@ -1,0 +1,79 @@
+"""Multi-GPU execution of the path: samples are independent, so the batch is sharded contiguously across
+ranks (one process per GPU, weights replicated) and the ONLY collective is an all-gather of the predicted vertices
+[B/N, 6890, 3] (+ pose3d [B/N, J, 3]) over xGMI -- RCCL via torch.distributed's "nccl" backend.  The reference has no
+multi-GPU counterpart (no torch.distributed anywhere); correctness criterion: the gathered tensor equals the
+single-GPU output of the concatenated batch bit for bit (same kernels, per-sample arithmetic independent of B).
+
+The gather of micro-batch k runs on a side stream while micro-batch k+1 computes: xGMI is point-to-point (7 links x ~153
+GB/s per GPU), a ring all-gather of 21 MB/rank per 256 samples costs ~1 ms at 8 GPUs, comparable to the compute."""
+import torch
+
+
+class ShardedForward:
+    def __init__(self, model, world_size=1, rank=0, dist=None, micro_batch=None):
+        self.model, self.world, self.rank, self.dist = model, world_size, rank, dist
+        self.micro = micro_batch
+        self._bufs = {}
+        self._comm_stream = None
+
+    def _buffers(self, B, J, device):
+        key = (B, J, str(device))
+        if key not in self._bufs:
+            self._bufs[key] = (torch.empty((self.world * B, 6890, 3), device=device, dtype=torch.float32),
+                               torch.empty((self.world * B, J, 3), device=device, dtype=torch.float32))
+        return self._bufs[key]
+
+    def step(self, pose2d_shard):
+        """pose2d_shard [B_local, J, 2] on this rank's GPU -> (verts [world*B_local,6890,3], pose3d [world*B_local,J,3])
+        replicated on every rank (rank r's samples at rows r*B_local ...)."""
+        if self.world == 1 or self.dist is None:
+            return self.model(pose2d_shard)
+        B, J = pose2d_shard.shape[0], pose2d_shard.shape[1]
+        dev = pose2d_shard.device
+        gv, gp = self._buffers(B, J, dev)
+        mb = self.micro or B
+        if dev.type != 'cuda':            # host tensors (gloo): same sharding / gather logic, no streams
+            return self._step_host(pose2d_shard, gv, gp, mb)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        # all_gather_into_tensor concatenates rank-major; to keep rank r's rows contiguous with micro-batching, each
+        # micro-batch gathers into a [world, mb, ...] staging view that aliases the right rows of the output.
+        gv_v = gv.view(self.world, B, 6890, 3)
+        gp_v = gp.view(self.world, B, J, 3)
+        for s in range(0, B, mb):
+            e = min(B, s + mb)
+            verts, pose3d = self.model(pose2d_shard[s:e])
+            if mb == B:
+                self._comm_stream.wait_stream(cur)
+                with torch.cuda.stream(self._comm_stream):
+                    self.dist.all_gather_into_tensor(gv, verts)
+                    self.dist.all_gather_into_tensor(gp, pose3d)
+                verts.record_stream(self._comm_stream)
+                pose3d.record_stream(self._comm_stream)
+            else:
+                self._comm_stream.wait_stream(cur)
+                with torch.cuda.stream(self._comm_stream):
+                    outs_v = [gv_v[r, s:e] for r in range(self.world)]
+                    outs_p = [gp_v[r, s:e] for r in range(self.world)]
+                    self.dist.all_gather(outs_v, verts)
+                    self.dist.all_gather(outs_p, pose3d)
+                verts.record_stream(self._comm_stream)
+                pose3d.record_stream(self._comm_stream)
+        cur.wait_stream(self._comm_stream)
+        return gv, gp
+
+    def _step_host(self, x, gv, gp, mb):
+        B, J = x.shape[0], x.shape[1]
+        gv_v, gp_v = gv.view(self.world, B, 6890, 3), gp.view(self.world, B, J, 3)
+        for s in range(0, B, mb):
+            e = min(B, s + mb)
+            verts, pose3d = self.model(x[s:e])
+            ov = [torch.empty_like(verts) for _ in range(self.world)]
+            op = [torch.empty_like(pose3d) for _ in range(self.world)]
+            self.dist.all_gather(ov, verts.contiguous())
+            self.dist.all_gather(op, pose3d.contiguous())
+            for r in range(self.world):
+                gv_v[r, s:e] = ov[r]
+                gp_v[r, s:e] = op[r]
+        return gv, gp

@@ -89,6 +89,13 @@ int gator_upsample_f32(gator_ctx* ctx, const float* vert431, int32_t batch, floa
  * dst is a device pointer with room for `capacity` floats; *count receives the element count. */
 int gator_get_tap(gator_ctx* ctx, const char* name, float* dst, int64_t capacity, int64_t* count, void* stream);
 
+/* Measurement hook (bench.py `roofline`): when enabled, every stage launch of a forward is bracketed by a hipEvent pair
+ * recorded on the launch stream.  gator_profile_read synchronises those events and returns, per stage name
+ * ('\n'-separated in `names`), the summed duration in ms and the number of launches since the last enable/read. */
+int gator_profile_enable(gator_ctx* ctx, int32_t on);
+int gator_profile_read(gator_ctx* ctx, char* names, int64_t names_capacity, float* total_ms, int32_t* calls,
+                       int32_t max_entries, int32_t* n_entries);
+
 /* "Next" row 8(f)-1: J_regressor @ verts (lib/core/base.py:221, demo/run.py:142) as a sparse product.
  *   coo_{row,col,val}: nnz entries of a [n_joint,6890] regressor (device); joints [B,n_joint,3]. */
 int gator_regress_joints_f32(const float* verts, int32_t batch, const int32_t* coo_row, const int32_t* coo_col,
