@@ -1,0 +1,108 @@
+// Device building blocks of the fused path (gfx950, wave64, fp32-input MFMA 32x32x2).
+//
+// Register-resident activation tiles.  A wave owns a tile of 32 tokens; one "block" = 32 tokens x 32 channels held as
+// an f32x16 per lane in exactly the MFMA 32x32 accumulator layout:
+//     T-layout (token on lane):   lane l -> token l&31, half h = l>>5;  v[r] <-> channel kap(r) + 4h
+//     C-layout (channel on lane): lane l -> channel l&31;               v[r] <-> token   kap(r) + 4h
+//     kap(r) = (r&3) + 8*(r>>2)                                   (C/D map of v_mfma_f32_32x32x2_f32)
+// Because a 32x32x2 MFMA takes ONE f32 per lane for A (A[i=l&31][k=l>>5]) and for B (B[k=l>>5][j=l&31]), register r of
+// such a block is directly the operand of the MFMA step that contracts over index kap(r)+4h -- as A (rows = lane index)
+// or as B (cols = lane index).  So a chain of linears, LayerNorms, softmaxes and attention products runs with no LDS
+// round trip and no cross-lane traffic except one lane<->lane^32 exchange per row reduction.
+//
+// Packed linear weight (nn.Linear W[N][K]):  Wp[nb][kb][g][lane][j] = W[32nb + (lane&31)][32kb + 8g + 4(lane>>5) + j]
+// i.e. one coalesced 1 KiB float4 wave-load feeds 4 MFMA steps, as A operand (T-layout output) or B operand (C-layout).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gator {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GATOR_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int kap(int r) { return (r & 3) + 8 * (r >> 2); }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }   // lane <-> lane^32
+
+// one packed (nb,kb) weight tile = 4 float4 per lane
+struct WTile { f32x4 g[4]; };
+
+__device__ __forceinline__ WTile load_wtile(const float* __restrict__ Wp, int tile, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(Wp) + ((size_t)tile * 4) * 64 + lane;
+    WTile t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) t.g[g] = p[g * 64];
+    return t;
+}
+
+// acc(T-layout)[n][token] += sum_k W[n][k] x[token][k] over one 32-wide k block:  A = weights, B = activations
+__device__ __forceinline__ f32x16 mma_T(const WTile& w, const f32x16& x, f32x16 acc) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = GATOR_MFMA(w.g[g][j], x[4 * g + j], acc);
+    return acc;
+}
+// acc(C-layout)[token][n] : A = activations, B = weights
+__device__ __forceinline__ f32x16 mma_C(const WTile& w, const f32x16& x, f32x16 acc) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = GATOR_MFMA(x[4 * g + j], w.g[g][j], acc);
+    return acc;
+}
+
+// per-channel vector (bias / norm weight) in T-layout: v[r] = vec[base + kap(r) + 4h]
+__device__ __forceinline__ f32x16 load_chanvec_T(const float* __restrict__ vec, int base, int h) {
+    f32x16 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(vec + base + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * g + j] = t[j];
+    }
+    return v;
+}
+
+// a block stored as 4 float4 per lane ([g][lane][4]); same form for T- and C-layout blocks
+__device__ __forceinline__ f32x16 load_block(const float* __restrict__ p, int lane) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(p) + lane;
+    f32x16 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = q[g * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * g + j] = t[j];
+    }
+    return v;
+}
+__device__ __forceinline__ void store_block(float* __restrict__ p, int lane, const f32x16& v) {
+    f32x4* q = reinterpret_cast<f32x4*>(p) + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = v[4 * g + j];
+        q[g * 64] = t;
+    }
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// XCD-aware bijective remap of a 1-D grid: blocks that share an XCD (equal blockIdx % 8) get CONTIGUOUS logical ids,
+// so the workgroups of one sample hit one L2.  Speed only -- never correctness (cdna_hip_programming.md T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+}  // namespace gator

@@ -1,0 +1,49 @@
+// State of the fused path: packed (MFMA-operand-order) weights and the per-batch workspace.
+#pragma once
+#include "internal.h"
+
+namespace gator {
+
+constexpr int kVT = 14;                 // 32-token tiles per sample (431 -> 448)
+constexpr int kOB = 216;                // 32-vertex output blocks of the upsample GEMM (6890 -> 6912)
+constexpr int kCB = 14;                 // 32-wide k blocks over the 431 coarse vertices
+constexpr int kTile = 32 * 32;          // floats in one packed 32x32 tile ([4 g][64 lanes][4])
+
+struct MdrLayerP {                      // packed weights of one LBF layer (device pointers into FusedState::wbuf)
+    const float *wq, *proj, *fc1, *fc2, *sa[4];
+};
+
+struct FusedState {
+    float* wbuf = nullptr;              // all packed weights
+    size_t wbuf_floats = 0;
+    // upsample: Wp[tap][ob][cb][4][64][4]
+    const float* up_w = nullptr;
+    // MDR
+    MdrLayerP lay[3];
+    const float* head_w = nullptr;      // [1 nb][2 kb] combined motion/bias/scale linear
+    const float* head_b = nullptr;      // [32]
+    const float* tok_base = nullptr;    // [14][2][4][64][4]  v431 part of get_verts_feature + bias + pos_v  (T-layout tiles)
+    const float* tok_w3 = nullptr;      // [3][64]            pose3d part of get_verts_feature (columns 3..5), row-major [i][ch]
+    // workspace (per cap batch)
+    float* ws = nullptr;
+    size_t ws_floats = 0;
+    int cap = 0;
+    float *vcp = nullptr;               // [MT][3][kCB][4][64][4]  packed vert431 (A operand of the upsample GEMM)
+    float *vc = nullptr;                // [B][431][3]
+    float *vf = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;   // [B][14][2][kTile] each
+    float *jkv = nullptr;               // [B][3 layers][2 (k,v)][2 heads][kTile]
+    float *hf = nullptr;                // [B][431][32] head features
+    float *lbf = nullptr;               // [B][431][64] tap: verts tokens after LBF3 (reference layout)
+    float *feat = nullptr, *xout = nullptr, *pc = nullptr;
+};
+
+// fused_pack.hip
+int fused_pack_linear(const float* W, int64_t wsn, int64_t wsk, int N, int K, float* dst, void* stream);   // -> [NB][KB] tiles
+inline int nblk32(int n) { return (n + 31) / 32; }
+// upsample_fused.hip
+int launch_pack_vc(const float* vc, int B, float* vcp, void* stream);
+int launch_upsample(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream);
+// mdr_fused.hip
+int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream);
+
+}  // namespace gator

@@ -1,0 +1,442 @@
+// MDR head (lib/models/MDR.py:124-170) as register-resident fp32-MFMA kernels.
+//
+// One wave owns one 32-token tile of one sample's 431 coarse-vertex tokens (14 tiles/sample) and keeps its 64-channel
+// token state in registers in the MFMA accumulator layout (fused_common.h).  Everything that is row-wise in the
+// reference -- LayerNorms, the cross-attention over the J joint tokens (MDR.py:34-46), the Mlp 64->256->64 (timm Mlp,
+// MDR.py:61,68), the Annotated-Transformer LayerNorm (vanilla_transformer_encoder.py:31-34), the q/k/v in-projections and
+// the out-projection + residual of the 431x431 self-attention (vanilla_transformer_encoder.py:82-94) -- chains through
+// MFMAs without touching LDS.  The only cross-token dependency is the self-attention's K/V of the whole sample, so the
+// three LBF layers become four launches:
+//     L0: tokenise -> tokenwise(0)              (writes vf, Q, K, V of layer 0, all in operand-packed tiles)
+//     L1: attention(0)+out-proj+res -> tokenwise(1)
+//     L2: attention(1)+out-proj+res -> tokenwise(2)
+//     L3: attention(2)+out-proj+res -> head features (motion_linear | bias_linear | scale_linear, MDR.py:156-162)
+// Attention is flash-style: S^T = K Q^T per 32-key tile with the key on the accumulator row, online softmax in registers
+// (one lane<->lane^32 max exchange per tile), and the probability registers are fed straight back as the B operand of
+// O^T += V^T P^T.  K and V tiles are stored by the producer in exactly the operand order the consumer loads (1 KiB
+// coalesced float4 wave loads from L2), so no LDS staging or barrier is needed.
+#include "fused_common.h"
+#include "fused_state.h"
+
+namespace gator {
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct LayerW {   // packed tiles (MdrLayerP) + reference-layout vectors of one LBF layer
+    const float *wq, *proj, *fc1, *fc2, *sa0, *sa1, *sa2, *sa3;
+    const float *n1w, *n1b, *proj_b, *n2w, *n2b, *fc1_b, *fc2_b, *a2, *b2, *sa0_b, *sa1_b, *sa2_b, *sa3_b;
+};
+
+struct MdrArgs {
+    int B, J, layer;
+    const float *vf_in, *q_in, *k_in, *v_in;
+    float *vf_out, *q_out, *k_out, *v_out;
+    const float* jkv;        // [B][3][2][2][kTile]
+    const float* pc;         // [B][J][133]
+    const int32_t* vj;       // [431]
+    const float *tok_base, *tok_w3;
+    const float *head_w, *head_b;
+    float *hf, *lbf;
+    LayerW prev, cur;        // prev: layer whose attention/out-proj runs first; cur: layer whose tokenwise part runs
+};
+
+// ---- row-wise helpers over the 64 channels (2 blocks) of a token (lane pair l, l^32) -------------------------------
+__device__ __forceinline__ float row_sum64(const f32x16& a, const f32x16& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += a[r] + b[r];
+    return s + xhalf(s);
+}
+
+// nn.LayerNorm(64), eps inside the sqrt
+__device__ __forceinline__ void layernorm64(const f32x16 (&x)[2], const float* __restrict__ w, const float* __restrict__ b,
+                                            int h, f32x16 (&y)[2]) {
+    const float mean = row_sum64(x[0], x[1]) * (1.0f / 64.0f);
+    f32x16 d0 = x[0] - mean, d1 = x[1] - mean;
+    const float var = row_sum64(d0 * d0, d1 * d1) * (1.0f / 64.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    y[0] = d0 * rstd * load_chanvec_T(w, 0, h) + load_chanvec_T(b, 0, h);
+    y[1] = d1 * rstd * load_chanvec_T(w, 32, h) + load_chanvec_T(b, 32, h);
+}
+
+// Annotated-Transformer LayerNorm: a_2 * (x - mean) / (std_unbiased + 1e-6) + b_2
+__device__ __forceinline__ void custom_ln64(f32x16 (&x)[2], const float* __restrict__ a2, const float* __restrict__ b2, int h) {
+    const float mean = row_sum64(x[0], x[1]) * (1.0f / 64.0f);
+    f32x16 d0 = x[0] - mean, d1 = x[1] - mean;
+    const float std = sqrtf(row_sum64(d0 * d0, d1 * d1) * (1.0f / 63.0f));
+    const float inv = 1.0f / (std + 1e-6f);
+    x[0] = load_chanvec_T(a2, 0, h) * d0 * inv + load_chanvec_T(b2, 0, h);
+    x[1] = load_chanvec_T(a2, 32, h) * d1 * inv + load_chanvec_T(b2, 32, h);
+}
+
+// y(T-layout, 64 ch) = W[64][64] x (+bias)
+__device__ __forceinline__ void linear64_T(const float* __restrict__ Wp, const float* __restrict__ bias, const f32x16 (&x)[2],
+                                           int lane, f32x16 (&y)[2]) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        f32x16 acc = bias ? load_chanvec_T(bias, 32 * nb, h) : zero16();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) acc = mma_T(load_wtile(Wp, nb * 2 + kb, lane), x[kb], acc);
+        y[nb] = acc;
+    }
+}
+
+// ---- flash attention of one 32-query tile against the 431 keys of its sample, one head --------------------------------
+__device__ __forceinline__ f32x16 self_attention_head(const float* __restrict__ qt, const float* __restrict__ kbase,
+                                                      const float* __restrict__ vbase, int lane) {
+    const int h = lane >> 5;
+    const f32x16 qv = load_block(qt, lane);
+    f32x16 O = zero16();
+    float m = -1e30f, l = 0.f;
+    const float c = kLog2e * 0.17677669529663688110f;      // log2(e) / sqrt(d_k): scores kept in the exp2 domain
+    for (int kt = 0; kt < kVT; ++kt) {
+        const f32x16 kb = load_block(kbase + (size_t)kt * 2 * kTile, lane);
+        const f32x16 vb = load_block(vbase + (size_t)kt * 2 * kTile, lane);
+        f32x16 S = zero16();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S = GATOR_MFMA(kb[r], qv[r], S);      // S^T[key][query]
+        float bm = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = S[r] * c;
+            if (kt == kVT - 1 && kap(r) + 4 * h >= kV - 32 * (kVT - 1)) s = -1e30f;   // keys 431..447 do not exist
+            S[r] = s;
+            bm = fmaxf(bm, s);
+        }
+        bm = fmaxf(bm, xhalf(bm));
+        if (!__all(bm <= m + 8.0f)) {            // lazy rescale (wave-uniform): P stays <= 2^8, exact in fp32
+            const float mn = fmaxf(m, bm);
+            const float al = __builtin_amdgcn_exp2f(m - mn);
+            O = O * al;
+            l *= al;
+            m = mn;
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(S[r] - m);
+            S[r] = p;
+            ps += p;
+        }
+        l += ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O = GATOR_MFMA(vb[r], S[r], O);       // O^T[d][query] += V^T[d][key] P^T[key][query]
+    }
+    l += xhalf(l);
+    return O * (1.0f / l);
+}
+
+// ---- cross-attention over the J joint tokens (keys/values precomputed per sample by k_mdr_joint) -------------------------
+__device__ __forceinline__ f32x16 cross_attention_head(const float* __restrict__ kj, const float* __restrict__ vjp,
+                                                       const f32x16& qh, int J, int lane) {
+    const int h = lane >> 5;
+    const f32x16 kb = load_block(kj, lane);
+    f32x16 S = zero16();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S = GATOR_MFMA(kb[r], qh[r], S);          // S^T[joint][token]
+    const float c = kLog2e * 0.17677669529663688110f;                      // head_dim ** -0.5 (MDR.py:25), exp2 domain
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float s = (kap(r) + 4 * h < J) ? S[r] * c : -1e30f;
+        S[r] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = fmaxf(mx, xhalf(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(S[r] - mx);
+        S[r] = p;
+        sum += p;
+    }
+    sum += xhalf(sum);
+    const float inv = 1.0f / sum;
+    const f32x16 vb = load_block(vjp, lane);
+    f32x16 O = zero16();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O = GATOR_MFMA(vb[r], S[r] * inv, O);
+    return O;
+}
+
+template <int MODE>   // 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
+__global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int id = xcd_remap(blockIdx.x, nwg) * 4 + wave;
+    if (id >= a.B * kVT) return;
+    const int b = id / kVT, t = id % kVT;
+    const size_t tile = ((size_t)b * kVT + t) * 2;          // index of this wave's first block in vf/q/k/v
+    const int token = 32 * t + (lane & 31);
+    f32x16 vf[2];
+    if (MODE == 0) {
+        // verts tokens = Linear(6->64)([v431, pose3d[vj]/1000]) + pos_v   (MDR.py:126-137); the v431/bias/pos part is folded
+        const int tk = token < kV ? token : kV - 1;
+        const float* p3 = a.pc + ((size_t)b * a.J + a.vj[tk]) * 133 + 2;
+        const float x0 = p3[0], x1 = p3[1], x2 = p3[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            f32x16 v = load_block(a.tok_base + ((size_t)t * 2 + nb) * kTile, lane);
+            v += load_chanvec_T(a.tok_w3, 32 * nb, h) * x0;
+            v += load_chanvec_T(a.tok_w3 + 64, 32 * nb, h) * x1;
+            v += load_chanvec_T(a.tok_w3 + 128, 32 * nb, h) * x2;
+            vf[nb] = v;
+        }
+    } else {
+        f32x16 att[2];
+#pragma unroll
+        for (int hd = 0; hd < 2; ++hd)
+            att[hd] = self_attention_head(a.q_in + (tile + hd) * kTile, a.k_in + ((size_t)b * kVT * 2 + hd) * kTile,
+                                          a.v_in + ((size_t)b * kVT * 2 + hd) * kTile, lane);
+        f32x16 y[2];
+        linear64_T(a.prev.sa3, a.prev.sa3_b, att, lane, y);                 // linears[-1], vanilla_transformer_encoder.py:94
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) vf[nb] = load_block(a.vf_in + (tile + nb) * kTile, lane) + y[nb];   // MDR.py:143
+    }
+    if (MODE == 2) {
+        if (token < kV) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = vf[nb][4 * g + j];
+                    *reinterpret_cast<f32x4*>(a.lbf + ((size_t)b * kV + token) * kE + 32 * nb + 8 * g + 4 * h) = v4;
+                }
+        }
+        f32x16 acc = load_chanvec_T(a.head_b, 0, h);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) acc = mma_T(load_wtile(a.head_w, kb, lane), vf[kb], acc);
+        if (token < kV) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v4[j] = acc[4 * g + j];
+                *reinterpret_cast<f32x4*>(a.hf + ((size_t)b * kV + token) * 32 + 8 * g + 4 * h) = v4;
+            }
+        }
+        return;
+    }
+    const LayerW& w = a.cur;
+    // ---- CrossAttentionBlock (MDR.py:64-69) ----
+    {
+        f32x16 fz[2], q[2], o[2];
+        layernorm64(vf, w.n1w, w.n1b, h, fz);
+        linear64_T(w.wq, nullptr, fz, lane, q);
+        const float* jb = a.jkv + (((size_t)b * 3 + a.layer) * 4) * kTile;       // [k/v][head] tiles
+#pragma unroll
+        for (int hd = 0; hd < 2; ++hd) o[hd] = cross_attention_head(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], a.J, lane);
+        f32x16 y[2];
+        linear64_T(w.proj, w.proj_b, o, lane, y);
+        vf[0] += y[0];
+        vf[1] += y[1];
+    }
+    {
+        f32x16 y2[2], acc2[2];
+        layernorm64(vf, w.n2w, w.n2b, h, y2);
+        acc2[0] = load_chanvec_T(w.fc2_b, 0, h);
+        acc2[1] = load_chanvec_T(w.fc2_b, 32, h);
+#pragma unroll 2
+        for (int c = 0; c < 8; ++c) {           // 256 hidden units in 8 chunks of 32: fc1 -> GELU -> fc2 partial
+            f32x16 hdn = load_chanvec_T(w.fc1_b, 32 * c, h);
+            hdn = mma_T(load_wtile(w.fc1, c * 2 + 0, lane), y2[0], hdn);
+            hdn = mma_T(load_wtile(w.fc1, c * 2 + 1, lane), y2[1], hdn);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hdn[r] = gelu_f(hdn[r]);
+            acc2[0] = mma_T(load_wtile(w.fc2, 0 * 8 + c, lane), hdn, acc2[0]);
+            acc2[1] = mma_T(load_wtile(w.fc2, 1 * 8 + c, lane), hdn, acc2[1]);
+        }
+        vf[0] += acc2[0];
+        vf[1] += acc2[1];
+    }
+    custom_ln64(vf, w.a2, w.b2, h);                                           // MDR.py:142 self.norm
+    store_block(a.vf_out + (tile + 0) * kTile, lane, vf[0]);
+    store_block(a.vf_out + (tile + 1) * kTile, lane, vf[1]);
+    // ---- in-projections of the self-attention (vanilla_transformer_encoder.py:87-89) in the consumer's operand order ----
+    {
+        f32x16 y[2];
+        linear64_T(w.sa0, w.sa0_b, vf, lane, y);
+        store_block(a.q_out + (tile + 0) * kTile, lane, y[0]);
+        store_block(a.q_out + (tile + 1) * kTile, lane, y[1]);
+        linear64_T(w.sa1, w.sa1_b, vf, lane, y);
+        if (token >= kV) { y[0] = zero16(); y[1] = zero16(); }               // pad keys: finite (they are masked anyway)
+        store_block(a.k_out + (tile + 0) * kTile, lane, y[0]);
+        store_block(a.k_out + (tile + 1) * kTile, lane, y[1]);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {                                       // V in C-layout: channel on the lane
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) acc = mma_C(load_wtile(w.sa2, nb * 2 + kb, lane), vf[kb], acc);
+            const float bv = w.sa2_b[32 * nb + (lane & 31)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = (32 * t + kap(r) + 4 * h < kV) ? acc[r] + bv : 0.f;
+            store_block(a.v_out + (tile + nb) * kTile, lane, acc);
+        }
+    }
+}
+
+// Joint tokens: jf = Linear(133->64)(pose_combine) + pos_j (MDR.py:130-134); per layer k = wk(LN1(jf)), v = wv(LN1(jf))
+// (MDR.py:37-38 with norm1 applied to the concatenated tokens, :65).  jf does not change across the three layers.
+// Output in MFMA operand order: K tile [hd][g][lane=(joint,h)][j] = k[joint][32hd+8g+4h+j];
+//                               V tile [hd][g][lane=(d,h)][j]     = v[joint=8g+4h+j][32hd+d].
+struct JointArgs {
+    const float *pc, *jw, *jb, *pos_j;
+    const float *n1w[3], *n1b[3], *wk[3], *wv[3];
+    float* jkv;
+    int J;
+};
+__global__ __launch_bounds__(256) void k_mdr_joint(const JointArgs a) {
+    __shared__ float pcs[kMaxJ][136];
+    __shared__ float jf[kMaxJ][kE], fz[kMaxJ][kE], kk[kMaxJ][kE], vv[kMaxJ][kE];
+    const int b = blockIdx.x, t = threadIdx.x, J = a.J;
+    for (int e = t; e < J * 133; e += 256) pcs[e / 133][e % 133] = a.pc[(size_t)b * J * 133 + e];
+    __syncthreads();
+    const int ch = t & 63;
+    for (int j = t >> 6; j < J; j += 4) {
+        double s = (double)a.jb[ch];
+        for (int k = 0; k < 133; ++k) s += (double)a.jw[ch * 133 + k] * (double)pcs[j][k];
+        jf[j][ch] = (float)(s + (double)a.pos_j[(j + 1) * kE + ch]);
+    }
+    __syncthreads();
+    for (int li = 0; li < 3; ++li) {
+        for (int j = t >> 6; j < J; j += 4) {        // one wave per joint: LayerNorm over 64 channels
+            double x = (double)jf[j][ch], s = x;
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const double mean = s / 64.0;
+            double q = (x - mean) * (x - mean);
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            fz[j][ch] = (float)((x - mean) / sqrt(q / 64.0 + 1e-5) * (double)a.n1w[li][ch] + (double)a.n1b[li][ch]);
+        }
+        __syncthreads();
+        for (int j = t >> 6; j < kMaxJ; j += 4) {
+            double sk = 0.0, sv = 0.0;
+            if (j < J)
+                for (int k = 0; k < kE; ++k) {
+                    sk += (double)a.wk[li][ch * kE + k] * (double)fz[j][k];
+                    sv += (double)a.wv[li][ch * kE + k] * (double)fz[j][k];
+                }
+            kk[j][ch] = (float)sk;      // rows >= J are zero: masked in the softmax / contribute nothing to PV
+            vv[j][ch] = (float)sv;
+        }
+        __syncthreads();
+        float* out = a.jkv + (((size_t)b * 3 + li) * 4) * kTile;
+        for (int e = t; e < 2 * kTile; e += 256) {
+            const int j4 = e & 3, lane = (e >> 2) & 63, g = (e >> 8) & 3, hd = e >> 10;
+            out[e] = kk[lane & 31][32 * hd + 8 * g + 4 * (lane >> 5) + j4];
+            out[2 * kTile + e] = vv[8 * g + 4 * (lane >> 5) + j4][32 * hd + (lane & 31)];
+        }
+        __syncthreads();
+    }
+}
+
+// MDR head (MDR.py:156-166) from the per-token head features hf[b][v][32]:
+//   ch 0..19 = mat_A, 24..26 = bias_linear out, 27 = scale_linear out, 28..30 = mat_C   (our own packing order)
+struct HeadArgs {
+    const float *hf, *bn_w, *bn_b, *bn_mean, *bn_var, *bconv_w, *bconv_b;
+    float* vc;
+    int alpha;
+};
+__global__ __launch_bounds__(256) void k_mdr_head(const HeadArgs a) {
+    __shared__ float bn[kV + 1][3];
+    __shared__ double part[4][60];
+    __shared__ float bc[20][3];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* hf = a.hf + (size_t)b * kV * 32;
+    for (int v = t; v < kV; v += 256) {
+        double x[3] = {(double)hf[v * 32 + 24], (double)hf[v * 32 + 25], (double)hf[v * 32 + 26]};
+        if (a.alpha) {      // LayerNorm(3)
+            const double m = (x[0] + x[1] + x[2]) / 3.0;
+            const double q = ((x[0] - m) * (x[0] - m) + (x[1] - m) * (x[1] - m) + (x[2] - m) * (x[2] - m)) / 3.0;
+            const double rs = 1.0 / sqrt(q + 1e-5);
+            for (int c = 0; c < 3; ++c) x[c] = (x[c] - m) * rs * (double)a.bn_w[c] + (double)a.bn_b[c];
+        } else {            // BatchNorm1d(431) eval: channel = vertex
+            const double rs = 1.0 / sqrt((double)a.bn_var[v] + 1e-5);
+            for (int c = 0; c < 3; ++c) x[c] = (x[c] - (double)a.bn_mean[v]) * rs * (double)a.bn_w[v] + (double)a.bn_b[v];
+        }
+        for (int c = 0; c < 3; ++c) bn[v][c] = (float)(0.5 * x[c] * (1.0 + erf(x[c] * 0.70710678118654752440)));
+    }
+    __syncthreads();
+    if (t < 240) {          // Conv1d(431->20,k3,p1): 60 outputs x 4 slices of the 431 input channels
+        const int o = t % 60, sl = t / 60, m = o / 3, l = o % 3;
+        double s = 0.0;
+        for (int c = sl; c < kV; c += 4)
+            for (int k = 0; k < 3; ++k) {
+                const int ll = l + k - 1;
+                if (ll >= 0 && ll < 3) s += (double)a.bconv_w[(m * kV + c) * 3 + k] * (double)bn[c][ll];
+            }
+        part[sl][o] = s;
+    }
+    __syncthreads();
+    if (t < 60) bc[t / 3][t % 3] = (float)(part[0][t] + part[1][t] + part[2][t] + part[3][t] + (double)a.bconv_b[t / 3]);
+    __syncthreads();
+    for (int v = t; v < kV; v += 256) {
+        const float* r = hf + v * 32;
+        double mx = -1e300, p[20], l = 0.0;
+        for (int m = 0; m < 20; ++m) mx = fmax(mx, (double)r[m]);
+        for (int m = 0; m < 20; ++m) {
+            p[m] = exp((double)r[m] - mx);
+            l += p[m];
+        }
+        const double sc = a.alpha ? pow(1.1, (double)r[27]) : 1.0;
+        for (int c = 0; c < 3; ++c) {
+            double o = 0.0;
+            for (int m = 0; m < 20; ++m) o += (p[m] / l) * (double)bc[m][c];
+            a.vc[((size_t)b * kV + v) * 3 + c] = (float)(sc * o + (double)r[28 + c]);
+        }
+    }
+}
+
+LayerW make_layer(const FusedState* f, const gator_ctx* c, int li) {
+    const MdrLayerP& p = f->lay[li];
+    const MdrLayerW& r = c->w.lay[li];
+    LayerW w;
+    w.wq = p.wq; w.proj = p.proj; w.fc1 = p.fc1; w.fc2 = p.fc2;
+    w.sa0 = p.sa[0]; w.sa1 = p.sa[1]; w.sa2 = p.sa[2]; w.sa3 = p.sa[3];
+    w.n1w = r.n1w; w.n1b = r.n1b; w.proj_b = r.proj_b; w.n2w = r.n2w; w.n2b = r.n2b; w.fc1_b = r.fc1_b; w.fc2_b = r.fc2_b;
+    w.a2 = r.a2; w.b2 = r.b2; w.sa0_b = r.sa_b[0]; w.sa1_b = r.sa_b[1]; w.sa2_b = r.sa_b[2]; w.sa3_b = r.sa_b[3];
+    return w;
+}
+
+}  // namespace
+
+// pc [B,J,133] (reference layout) -> f->vc [B,431,3] (vert431) ; taps: f->lbf
+int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const Weights& w = c->w;
+    JointArgs ja;
+    ja.pc = pc; ja.jw = w.jfeat_w; ja.jb = w.jfeat_b; ja.pos_j = w.pos_j; ja.jkv = f->jkv; ja.J = c->J;
+    for (int i = 0; i < 3; ++i) { ja.n1w[i] = w.lay[i].n1w; ja.n1b[i] = w.lay[i].n1b; ja.wk[i] = w.lay[i].wk; ja.wv[i] = w.lay[i].wv; }
+    { StageTimer tm(c, "mdr_joint", stream); k_mdr_joint<<<B, 256, 0, st>>>(ja); }
+    const size_t per = (size_t)f->cap * kVT * 2 * kTile;      // one [B][14][2] tile set
+    float* set[2][4] = {{f->vf, f->q, f->k, f->v}, {f->vf + per, f->q + per, f->k + per, f->v + per}};
+    MdrArgs a{};
+    a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
+    a.head_w = f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = f->lbf;
+    const int nwg = (B * kVT + 3) / 4;
+    for (int li = 0; li <= 3; ++li) {
+        float** in = set[(li + 1) & 1];
+        float** out = set[li & 1];
+        a.layer = li;
+        a.vf_in = in[0]; a.q_in = in[1]; a.k_in = in[2]; a.v_in = in[3];
+        a.vf_out = out[0]; a.q_out = out[1]; a.k_out = out[2]; a.v_out = out[3];
+        if (li > 0) a.prev = make_layer(f, c, li - 1);
+        if (li < 3) a.cur = make_layer(f, c, li);
+        StageTimer tm(c, li == 0 ? "mdr_tok" : "mdr_layer", stream);
+        if (li == 0) k_mdr_layer<0><<<nwg, 256, 0, st>>>(a, nwg);
+        else if (li < 3) k_mdr_layer<1><<<nwg, 256, 0, st>>>(a, nwg);
+        else k_mdr_layer<2><<<nwg, 256, 0, st>>>(a, nwg);
+    }
+    HeadArgs ha;
+    ha.hf = f->hf; ha.bn_w = w.bn_w; ha.bn_b = w.bn_b; ha.bn_mean = w.bn_mean; ha.bn_var = w.bn_var;
+    ha.bconv_w = w.bconv_w; ha.bconv_b = w.bconv_b; ha.vc = f->vc; ha.alpha = c->alpha;
+    { StageTimer tm(c, "mdr_head", stream); k_mdr_head<<<B, 256, 0, st>>>(ha); }
+    GATOR_HIP_CHECK(hipGetLastError());
+    c->taps["mdr_lbf2"] = {f->lbf, (int64_t)B * kV * kE};
+    c->taps["vert431"] = {f->vc, (int64_t)B * kV * 3};
+    return GATOR_OK;
+}
+
+}  // namespace gator
