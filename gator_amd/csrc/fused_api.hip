@@ -40,6 +40,92 @@ std::vector<float> d2h(const float* p, size_t n) {
     return v;
 }
 
+// B-operand / T-layout tile of a [32][32] table: tile[g][lane][j] = tab(row = lane&31, col = 8g + 4(lane>>5) + j)
+template <class F>
+void fill_tile(float* dst, F tab) {
+    for (int g = 0; g < 4; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) dst[(g * 64 + lane) * 4 + j] = tab(lane & 31, 8 * g + 4 * (lane >> 5) + j);
+}
+
+int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
+    const Weights& w = c->w;
+    const int J = c->J;
+    const size_t blk_tiles = 48 + 16 + 16 + 16 + 16 + 4 + 20 + 64 + 64 + 4 + 4 + 1 + 1;     // 274
+    const size_t total = (kDepth * blk_tiles + 8 + 2 + (size_t)3 * J * 4) * kTile;
+    GATOR_HIP_CHECK(hipMalloc(&f->gbuf, total * sizeof(float)));
+    float* p = f->gbuf;
+    auto take = [&](size_t tiles) { float* r = p; p += tiles * kTile; return r; };
+    std::vector<float> host;
+    auto upload = [&](const std::vector<float>& v) -> const float* {
+        float* d = take(v.size() / kTile);
+        (void)hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+        return d;
+    };
+    const std::vector<float> adiag = d2h(c->adj_diag, (size_t)kDepth * J), aoff = d2h(c->adj_off, (size_t)kDepth * J * J),
+                             m1 = d2h(c->mask1, (size_t)J * J), m2 = d2h(c->mask2, (size_t)J * J), hb = d2h(c->hop_bias, (size_t)kH * J * J);
+    for (int i = 0; i < kDepth; ++i) {
+        const GatBlockW& r = w.blk[i];
+        GatBlockPk& q = f->gblk[i];
+        struct { const float* src; int64_t wsn, wsk; int N, K; const float** dst; } items[] = {
+            {r.qkv_w, 128, 1, 384, 128, &q.qkv}, {r.proj_w, 128, 1, 128, 128, &q.proj},
+            {r.gcn_W, 1, 128, 128, 128, &q.w0}, {r.gcn_W + 128 * 128, 1, 128, 128, 128, &q.w1},     // applied as x @ W (modules.py:244-245)
+            {r.xl0_w, 128, 1, 128, 128, &q.lin0}, {r.xl1_w, 128, 1, 16, 128, &q.lin1}, {r.xlb_w, 144, 1, 128, 144, &q.back},
+            {r.fc1_w, 128, 1, 512, 128, &q.fc1}, {r.fc2_w, 512, 1, 128, 512, &q.fc2}};
+        for (auto& it : items) {
+            float* dst = take((size_t)nblk32(it.N) * nblk32(it.K));
+            int rc = fused_pack_linear(it.src, it.wsn, it.wsk, it.N, it.K, dst, stream);
+            if (rc) return rc;
+            *it.dst = dst;
+        }
+        const std::vector<float> M = d2h(r.gcn_M, (size_t)J * kC), b1 = d2h(r.xl1_b, 16);
+        // C-layout tiles (channel on the lane, token in the register): tile[nb][g][lane][j] <-> token 8g+4h+j, channel 32nb+(lane&31)
+        std::vector<float> mc(4 * kTile), md(4 * kTile);
+        for (int nb = 0; nb < 4; ++nb)
+            for (int g = 0; g < 4; ++g)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int tok = 8 * g + 4 * (lane >> 5) + j, n = 32 * nb + (lane & 31);
+                        const float mv = tok < J ? M[(size_t)tok * kC + n] : 0.f;
+                        mc[((nb * 4 + g) * 64 + lane) * 4 + j] = mv;
+                        md[((nb * 4 + g) * 64 + lane) * 4 + j] = tok < J ? adiag[i * J + tok] * mv : 0.f;
+                    }
+        q.mc = upload(mc);
+        q.md = upload(md);
+        std::vector<float> t1(kTile), t2(kTile);
+        fill_tile(t1.data(), [&](int t, int j) { return (t < J && j < J) ? aoff[((size_t)i * J + t) * J + j] : 0.f; });
+        q.aoffT = upload(t1);
+        fill_tile(t2.data(), [&](int t, int ch) {      // m2 @ (u1 + b1) = m2 @ u1 + rowsum(m2)[t] * b1[ch]
+            if (t >= J || ch >= 16) return 0.f;
+            float deg = 0.f;
+            for (int j = 0; j < J; ++j) deg += m2[(size_t)t * J + j];
+            return deg * b1[ch];
+        });
+        q.f1b = upload(t2);
+    }
+    std::vector<float> bt(8 * kTile), mt(kTile);
+    for (int hd = 0; hd < kH; ++hd)
+        fill_tile(bt.data() + (size_t)hd * kTile, [&](int t, int j) { return (t < J && j < J) ? hb[((size_t)hd * J + t) * J + j] : 0.f; });
+    f->g_biasT = upload(bt);
+    fill_tile(mt.data(), [&](int t, int j) { return (t < J && j < J) ? m1[(size_t)t * J + j] : 0.f; });
+    f->g_m1T = upload(mt);
+    fill_tile(mt.data(), [&](int t, int j) { return (t < J && j < J) ? m2[(size_t)t * J + j] : 0.f; });
+    f->g_m2T = upload(mt);
+    // lifter [3J][128J] -> per output o, 4 T-layout tiles: tile[kb][g][lane][j] = Wl[o][(lane&31)*128 + 32kb + 8g + 4h + j]
+    {
+        const std::vector<float> wl = d2h(w.lifter_w, (size_t)3 * J * kC * J);
+        std::vector<float> lp((size_t)3 * J * 4 * kTile, 0.f);
+        for (int o = 0; o < 3 * J; ++o)
+            for (int kb = 0; kb < 4; ++kb)
+                fill_tile(lp.data() + ((size_t)o * 4 + kb) * kTile,
+                          [&](int t, int ch) { return t < J ? wl[(size_t)o * kC * J + (size_t)t * kC + 32 * kb + ch] : 0.f; });
+        f->g_lifter = upload(lp);
+    }
+    GATOR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    GATOR_HIP_CHECK(hipGetLastError());
+    return GATOR_OK;
+}
+
 }  // namespace
 
 int fused_create(gator_ctx* c, void* stream) {
@@ -47,6 +133,10 @@ int fused_create(gator_ctx* c, void* stream) {
     FusedState* f = new FusedState();
     c->fused = f;
     const Weights& w = c->w;
+    if (c->parts & GATOR_PART_GAT) {
+        int rc = fused_create_gat(c, f, stream);
+        if (rc) return rc;
+    }
     if (!(c->parts & GATOR_PART_MDR)) return GATOR_OK;
     const size_t n_up = (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)56 * kTile;
     const size_t total = n_up + 3 * n_layer + 2 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
@@ -134,13 +224,14 @@ void fused_destroy(gator_ctx* c) {
     if (!c->fused) return;
     if (c->fused->ws) (void)hipFree(c->fused->ws);
     if (c->fused->wbuf) (void)hipFree(c->fused->wbuf);
+    if (c->fused->gbuf) (void)hipFree(c->fused->gbuf);
     delete c->fused;
     c->fused = nullptr;
 }
 
 int fused_gat_forward(gator_ctx* c, const float* pose2d, int B, float* x_out, float* feat, void* stream) {
     StageTimer tm(c, "gat", stream);
-    return basic_gat_forward(c, pose2d, B, x_out, feat, stream);     // TODO(round 1): GAT megakernel
+    return launch_gat(c, c->fused, pose2d, B, x_out, feat, stream);
 }
 
 int fused_upsample(gator_ctx* c, const float* vert431, int B, float* verts, void* stream) {

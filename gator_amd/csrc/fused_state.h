@@ -13,8 +13,16 @@ struct MdrLayerP {                      // packed weights of one LBF layer (devi
     const float *wq, *proj, *fc1, *fc2, *sa[4];
 };
 
+struct GatBlockPk {                     // packed tiles of one GATBlock
+    const float *qkv, *proj, *w0, *w1, *lin0, *lin1, *back, *fc1, *fc2;
+    const float *mc, *md, *aoffT, *f1b;  // M (C-layout), diag(A).M (C-layout), offdiag(A)^T B-operand tile, hop-2 bias term
+};
+
 struct FusedState {
     float* wbuf = nullptr;              // all packed weights
+    float* gbuf = nullptr;              // packed GAT weights + tables
+    GatBlockPk gblk[kDepth];
+    const float *g_biasT = nullptr, *g_m1T = nullptr, *g_m2T = nullptr, *g_lifter = nullptr;
     size_t wbuf_floats = 0;
     // upsample: Wp[tap][ob][cb][4][64][4]
     const float* up_w = nullptr;
@@ -43,6 +51,8 @@ inline int nblk32(int n) { return (n + 31) / 32; }
 // upsample_fused.hip
 int launch_pack_vc(const float* vc, int B, float* vcp, void* stream);
 int launch_upsample(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream);
+// gat_fused.hip
+int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream);
 // mdr_fused.hip
 int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream);
 
