@@ -64,6 +64,33 @@ __device__ __forceinline__ void layernorm128(const float* X, const float* __rest
     }
 }
 
+// sum over 4 k-blocks held in registers (xs) with two independent 64-term chains (fp32 accuracy), T- or C-layout output
+template <bool CL>
+__device__ __forceinline__ f32x16 lin4(const float* __restrict__ Wp, int tile0, const f32x16 (&xs)[4], int lane, f32x16 init) {
+    f32x16 a0 = init, a1 = zero16();
+    if (CL) {
+        a0 = mma_C(load_wtile(Wp, tile0 + 0, lane), xs[0], a0);
+        a1 = mma_C(load_wtile(Wp, tile0 + 1, lane), xs[1], a1);
+        a0 = mma_C(load_wtile(Wp, tile0 + 2, lane), xs[2], a0);
+        a1 = mma_C(load_wtile(Wp, tile0 + 3, lane), xs[3], a1);
+    } else {
+        a0 = mma_T(load_wtile(Wp, tile0 + 0, lane), xs[0], a0);
+        a1 = mma_T(load_wtile(Wp, tile0 + 1, lane), xs[1], a1);
+        a0 = mma_T(load_wtile(Wp, tile0 + 2, lane), xs[2], a0);
+        a1 = mma_T(load_wtile(Wp, tile0 + 3, lane), xs[3], a1);
+    }
+    return a0 + a1;
+}
+// same with the operand tiles read from LDS
+__device__ __forceinline__ f32x16 lin4_lds(const float* __restrict__ Wp, int tile0, const float* T, int lane, f32x16 init) {
+    f32x16 a0 = init, a1 = zero16();
+    a0 = mma_T(load_wtile(Wp, tile0 + 0, lane), load_block(T + 0 * kTile, lane), a0);
+    a1 = mma_T(load_wtile(Wp, tile0 + 1, lane), load_block(T + 1 * kTile, lane), a1);
+    a0 = mma_T(load_wtile(Wp, tile0 + 2, lane), load_block(T + 2 * kTile, lane), a0);
+    a1 = mma_T(load_wtile(Wp, tile0 + 3, lane), load_block(T + 3 * kTile, lane), a1);
+    return a0 + a1;
+}
+
 __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* X = lds;                       // residual stream, 4 tiles (T-layout)
@@ -129,13 +156,9 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             layernorm128<false>(X, w.n1w, w.n1b, lane, y);
             // ---- Attention (modules.py:121-138): wave owns heads 2*wave, 2*wave+1 ----
             {
-                f32x16 q = load_chanvec_T(w.qkv_b, 32 * wave, h), k = load_chanvec_T(w.qkv_b, 128 + 32 * wave, h), v = zero16();
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    q = mma_T(load_wtile(w.qkv, (wave) * 4 + kb, lane), y[kb], q);
-                    k = mma_T(load_wtile(w.qkv, (4 + wave) * 4 + kb, lane), y[kb], k);
-                    v = mma_C(load_wtile(w.qkv, (8 + wave) * 4 + kb, lane), y[kb], v);
-                }
+                const f32x16 q = lin4<false>(w.qkv, wave * 4, y, lane, load_chanvec_T(w.qkv_b, 32 * wave, h));
+                const f32x16 k = lin4<false>(w.qkv, (4 + wave) * 4, y, lane, load_chanvec_T(w.qkv_b, 128 + 32 * wave, h));
+                const f32x16 v = lin4<true>(w.qkv, (8 + wave) * 4, y, lane, zero16());
                 const float vb = w.qkv_b[256 + 32 * wave + (lane & 31)];
                 f32x16 sa = zero16(), sb = zero16();
 #pragma unroll
@@ -178,12 +201,8 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             }
             // ---- MGCN (modules.py:243-255): h_k = y @ W[k]; out = diag(A)(M.h0) + offdiag(A)(M.h1) + bias ----
             {
-                f32x16 h0 = zero16(), h1 = zero16();
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    h0 = mma_C(load_wtile(w.w0, wave * 4 + kb, lane), y[kb], h0);
-                    h1 = mma_C(load_wtile(w.w1, wave * 4 + kb, lane), y[kb], h1);
-                }
+                f32x16 h0 = lin4<true>(w.w0, wave * 4, y, lane, zero16());
+                f32x16 h1 = lin4<true>(w.w1, wave * 4, y, lane, zero16());
                 h0 = h0 * load_block(w.md + (size_t)wave * kTile, lane);                    // diag(A)[t] * M[t][n] * h0[t][n]
                 h1 = h1 * load_block(w.mc + (size_t)wave * kTile, lane);                    // M[t][n] * h1[t][n]
                 const f32x16 aoff = load_block(w.aoffT, lane);
@@ -196,9 +215,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         }
         __syncthreads();
         {   // proj + (attention + MGCN) sum  -> SB
-            f32x16 acc = load_chanvec_T(w.proj_b, 32 * wave, h);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc = mma_T(load_wtile(w.proj, wave * 4 + kb, lane), load_block(AT + kb * kTile, lane), acc);
+            const f32x16 acc = lin4_lds(w.proj, wave * 4, AT, lane, load_chanvec_T(w.proj_b, 32 * wave, h));
             store_block(SB + wave * kTile, lane, acc + g_out);
         }
         __syncthreads();
@@ -206,9 +223,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             f32x16 s[4];
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) s[kb] = load_block(SB + kb * kTile, lane);
-            f32x16 u0 = zero16();
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) u0 = mma_C(load_wtile(w.lin0, wave * 4 + kb, lane), s[kb], u0);
+            const f32x16 u0 = lin4<true>(w.lin0, wave * 4, s, lane, zero16());
             const float b0 = w.lin0_b[32 * wave + (lane & 31)];
             const f32x16 m1 = load_block(a.m1T, lane), m2 = load_block(a.m2T, lane);
             f32x16 f0 = zero16();
@@ -224,9 +239,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         }
         __syncthreads();
         {   // linearback(144->128) + residual
-            f32x16 acc = load_chanvec_T(w.back_b, 32 * wave, h);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc = mma_T(load_wtile(w.back, wave * 5 + kb, lane), load_block(FB + kb * kTile, lane), acc);
+            f32x16 acc = lin4_lds(w.back, wave * 5, FB, lane, load_chanvec_T(w.back_b, 32 * wave, h));
             f32x16 f1 = load_block(w.f1b, lane);                                            // rowsum(m2)[t] * linears[1].bias[n]
 #pragma unroll
             for (int q = 0; q < 4; ++q) f1 += load_block(F1P + q * kTile, lane);
@@ -245,9 +258,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
 #pragma unroll 1
             for (int q = 0; q < 4; ++q) {
                 const int nb = 4 * wave + q;
-                f32x16 hd = load_chanvec_T(w.fc1_b, 32 * nb, h);
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) hd = mma_T(load_wtile(w.fc1, nb * 4 + kb, lane), y2[kb], hd);
+                f32x16 hd = lin4<false>(w.fc1, nb * 4, y2, lane, load_chanvec_T(w.fc1_b, 32 * nb, h));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
                 store_block(HB + nb * kTile, lane, hd);
@@ -255,13 +266,15 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         }
         __syncthreads();
         {
-            f32x16 acc0 = load_chanvec_T(w.fc2_b, 32 * wave, h), acc1 = zero16();           // two chains of 256 products each
-#pragma unroll 2
-            for (int kb = 0; kb < 16; kb += 2) {
+            f32x16 acc0 = load_chanvec_T(w.fc2_b, 32 * wave, h), acc1 = zero16(), acc2 = zero16(), acc3 = zero16();   // 4 chains x 128
+#pragma unroll 1
+            for (int kb = 0; kb < 16; kb += 4) {
                 acc0 = mma_T(load_wtile(w.fc2, wave * 16 + kb, lane), load_block(HB + kb * kTile, lane), acc0);
                 acc1 = mma_T(load_wtile(w.fc2, wave * 16 + kb + 1, lane), load_block(HB + (kb + 1) * kTile, lane), acc1);
+                acc2 = mma_T(load_wtile(w.fc2, wave * 16 + kb + 2, lane), load_block(HB + (kb + 2) * kTile, lane), acc2);
+                acc3 = mma_T(load_wtile(w.fc2, wave * 16 + kb + 3, lane), load_block(HB + (kb + 3) * kTile, lane), acc3);
             }
-            xw += acc0 + acc1;
+            xw += (acc0 + acc1) + (acc2 + acc3);
             store_block(X + wave * kTile, lane, xw);     // every wave finished reading X (LN2) before the HB barrier
         }
         __syncthreads();

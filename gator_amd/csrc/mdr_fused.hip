@@ -75,11 +75,10 @@ __device__ __forceinline__ void linear64_T(const float* __restrict__ Wp, const f
                                            int lane, f32x16 (&y)[2]) {
     const int h = lane >> 5;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        f32x16 acc = bias ? load_chanvec_T(bias, 32 * nb, h) : zero16();
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) acc = mma_T(load_wtile(Wp, nb * 2 + kb, lane), x[kb], acc);
-        y[nb] = acc;
+    for (int nb = 0; nb < 2; ++nb) {   // one 32-term chain per k-block, then one add: halves the fp32 chain length
+        const f32x16 a0 = mma_T(load_wtile(Wp, nb * 2 + 0, lane), x[0], bias ? load_chanvec_T(bias, 32 * nb, h) : zero16());
+        const f32x16 a1 = mma_T(load_wtile(Wp, nb * 2 + 1, lane), x[1], zero16());
+        y[nb] = a0 + a1;
     }
 }
 
@@ -88,9 +87,10 @@ __device__ __forceinline__ f32x16 self_attention_head(const float* __restrict__ 
                                                       const float* __restrict__ vbase, int lane) {
     const int h = lane >> 5;
     const f32x16 qv = load_block(qt, lane);
-    f32x16 O = zero16();
+    f32x16 O = zero16(), O2 = zero16(), O3 = zero16(), O4 = zero16();   // key tile kt -> chain kt&3: four chains of ~110 products
     float m = -1e30f, l = 0.f;
     const float c = kLog2e * 0.17677669529663688110f;      // log2(e) / sqrt(d_k): scores kept in the exp2 domain
+#pragma unroll 4
     for (int kt = 0; kt < kVT; ++kt) {
         const f32x16 kb = load_block(kbase + (size_t)kt * 2 * kTile, lane);
         const f32x16 vb = load_block(vbase + (size_t)kt * 2 * kTile, lane);
@@ -110,6 +110,9 @@ __device__ __forceinline__ f32x16 self_attention_head(const float* __restrict__ 
             const float mn = fmaxf(m, bm);
             const float al = __builtin_amdgcn_exp2f(m - mn);
             O = O * al;
+            O2 = O2 * al;
+            O3 = O3 * al;
+            O4 = O4 * al;
             l *= al;
             m = mn;
         }
@@ -121,11 +124,23 @@ __device__ __forceinline__ f32x16 self_attention_head(const float* __restrict__ 
             ps += p;
         }
         l += ps;
+        // O^T[d][query] += V^T[d][key] P^T[key][query]
+        if ((kt & 3) == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) O = GATOR_MFMA(vb[r], S[r], O);       // O^T[d][query] += V^T[d][key] P^T[key][query]
+            for (int r = 0; r < 16; ++r) O = GATOR_MFMA(vb[r], S[r], O);
+        } else if ((kt & 3) == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O2 = GATOR_MFMA(vb[r], S[r], O2);
+        } else if ((kt & 3) == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O3 = GATOR_MFMA(vb[r], S[r], O3);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O4 = GATOR_MFMA(vb[r], S[r], O4);
+        }
     }
     l += xhalf(l);
-    return O * (1.0f / l);
+    return ((O + O2) + (O3 + O4)) * (1.0f / l);
 }
 
 // ---- cross-attention over the J joint tokens (keys/values precomputed per sample by k_mdr_joint) -------------------------
@@ -235,22 +250,23 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         vf[1] += y[1];
     }
     {
-        f32x16 y2[2], acc2[2];
+        f32x16 y2[2], acc2[2][2];
         layernorm64(vf, w.n2w, w.n2b, h, y2);
-        acc2[0] = load_chanvec_T(w.fc2_b, 0, h);
-        acc2[1] = load_chanvec_T(w.fc2_b, 32, h);
+        acc2[0][0] = load_chanvec_T(w.fc2_b, 0, h);
+        acc2[1][0] = load_chanvec_T(w.fc2_b, 32, h);
+        acc2[0][1] = zero16();
+        acc2[1][1] = zero16();
 #pragma unroll 2
         for (int c = 0; c < 8; ++c) {           // 256 hidden units in 8 chunks of 32: fc1 -> GELU -> fc2 partial
-            f32x16 hdn = load_chanvec_T(w.fc1_b, 32 * c, h);
-            hdn = mma_T(load_wtile(w.fc1, c * 2 + 0, lane), y2[0], hdn);
-            hdn = mma_T(load_wtile(w.fc1, c * 2 + 1, lane), y2[1], hdn);
+            f32x16 hdn = mma_T(load_wtile(w.fc1, c * 2 + 0, lane), y2[0], load_chanvec_T(w.fc1_b, 32 * c, h));
+            hdn += mma_T(load_wtile(w.fc1, c * 2 + 1, lane), y2[1], zero16());
 #pragma unroll
             for (int r = 0; r < 16; ++r) hdn[r] = gelu_f(hdn[r]);
-            acc2[0] = mma_T(load_wtile(w.fc2, 0 * 8 + c, lane), hdn, acc2[0]);
-            acc2[1] = mma_T(load_wtile(w.fc2, 1 * 8 + c, lane), hdn, acc2[1]);
+            acc2[0][c & 1] = mma_T(load_wtile(w.fc2, 0 * 8 + c, lane), hdn, acc2[0][c & 1]);   // even / odd chunks:
+            acc2[1][c & 1] = mma_T(load_wtile(w.fc2, 1 * 8 + c, lane), hdn, acc2[1][c & 1]);   // 2 chains of 128 products
         }
-        vf[0] += acc2[0];
-        vf[1] += acc2[1];
+        vf[0] += acc2[0][0] + acc2[0][1];
+        vf[1] += acc2[1][0] + acc2[1][1];
     }
     custom_ln64(vf, w.a2, w.b2, h);                                           // MDR.py:142 self.norm
     store_block(a.vf_out + (tile + 0) * kTile, lane, vf[0]);
@@ -424,7 +440,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         a.vf_out = out[0]; a.q_out = out[1]; a.k_out = out[2]; a.v_out = out[3];
         if (li > 0) a.prev = make_layer(f, c, li - 1);
         if (li < 3) a.cur = make_layer(f, c, li);
-        StageTimer tm(c, li == 0 ? "mdr_tok" : "mdr_layer", stream);
+        StageTimer tm(c, li == 0 ? "mdr_layer0" : (li < 3 ? "mdr_layer" : "mdr_attn_head"), stream);
         if (li == 0) k_mdr_layer<0><<<nwg, 256, 0, st>>>(a, nwg);
         else if (li < 3) k_mdr_layer<1><<<nwg, 256, 0, st>>>(a, nwg);
         else k_mdr_layer<2><<<nwg, 256, 0, st>>>(a, nwg);

@@ -60,10 +60,9 @@ __global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ vcp,
                 acc[2] = GATOR_MFMA(a2[j], w1[j], acc[2]);
             }
         }
-        if (cb & 1) {   // two-level summation: chains of <= 192 products, then 7 partial sums (fp32 accuracy)
+        // two-level summation: chains of <= 96 products per 32-vertex block, then 14 partial sums (fp32 accuracy)
 #pragma unroll
-            for (int l = 0; l < 3; ++l) { tot[l] += acc[l]; acc[l] = zero16(); }
-        }
+        for (int l = 0; l < 3; ++l) { tot[l] += acc[l]; acc[l] = zero16(); }
     }
     const int o = 32 * ob + (lane & 31), h = lane >> 5;
     if (o >= kNV) return;
