@@ -138,8 +138,8 @@ int fused_create(gator_ctx* c, void* stream) {
         if (rc) return rc;
     }
     if (!(c->parts & GATOR_PART_MDR)) return GATOR_OK;
-    const size_t n_up = (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)56 * kTile;
-    const size_t total = n_up + 3 * n_layer + 2 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
+    const size_t n_up = (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)64 * kTile;
+    const size_t total = n_up + 3 * n_layer + 14 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
     GATOR_HIP_CHECK(hipMalloc(&f->wbuf, total * sizeof(float)));
     f->wbuf_floats = total;
     float* p = f->wbuf;
@@ -155,7 +155,7 @@ int fused_create(gator_ctx* c, void* stream) {
         const MdrLayerW& r = w.lay[li];
         MdrLayerP& q = f->lay[li];
         struct { const float* src; int N, K; const float** dst; } items[] = {
-            {r.wq, 64, 64, &q.wq}, {r.proj_w, 64, 64, &q.proj}, {r.fc1_w, 256, 64, &q.fc1}, {r.fc2_w, 64, 256, &q.fc2},
+            {r.wq, 64, 64, &q.wq}, {r.wk, 64, 64, &q.wk}, {r.wv, 64, 64, &q.wv}, {r.proj_w, 64, 64, &q.proj}, {r.fc1_w, 256, 64, &q.fc1}, {r.fc2_w, 64, 256, &q.fc2},
             {r.sa_w[0], 64, 64, &q.sa[0]}, {r.sa_w[1], 64, 64, &q.sa[1]}, {r.sa_w[2], 64, 64, &q.sa[2]}, {r.sa_w[3], 64, 64, &q.sa[3]}};
         for (auto& it : items) {
             float* dst = take((size_t)nblk32(it.N) * nblk32(it.K) * kTile);
@@ -191,6 +191,19 @@ int fused_create(gator_ctx* c, void* stream) {
         float* hbd = take(64);
         GATOR_HIP_CHECK(hipMemcpy(hbd, hb.data(), 32 * sizeof(float), hipMemcpyHostToDevice));
         f->head_b = hbd;
+    }
+    {   // joint tokens: get_joint_feature packed, pos_j_id_embed[1..J] as T-layout tiles (MDR.py:130-134)
+        float* dst = take(10 * kTile);
+        int rc = fused_pack_linear(w.jfeat_w, 133, 1, 64, 133, dst, stream);
+        if (rc) return rc;
+        f->jfeat_p = dst;
+        const std::vector<float> pj = d2h(w.pos_j, (size_t)(c->J + 1) * 64);
+        std::vector<float> pt(2 * kTile);
+        for (int nb = 0; nb < 2; ++nb)
+            fill_tile(pt.data() + (size_t)nb * kTile, [&](int t, int ch) { return t < c->J ? pj[(size_t)(t + 1) * 64 + 32 * nb + ch] : 0.f; });
+        float* pd = take(2 * kTile);
+        GATOR_HIP_CHECK(hipMemcpy(pd, pt.data(), pt.size() * sizeof(float), hipMemcpyHostToDevice));
+        f->posj_T = pd;
     }
     // tokenise constants: get_verts_feature on [v431 | pose3d_nn] + pos_v (MDR.py:126-137); v431/bias/pos part folded per token
     {
@@ -248,9 +261,10 @@ int fused_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* 
     int rc = fused_ensure_ws(c, B);
     if (rc) return rc;
     FusedState* f = c->fused;
-    rc = launch_mdr(c, f, pc, B, stream);
+    rc = launch_mdr(c, f, pc, B, stream);        // also writes the packed vertex-GEMM operand f->vcp
     if (rc) return rc;
-    return fused_upsample(c, f->vc, B, verts, stream);
+    StageTimer tm(c, "upsample", stream);
+    return launch_upsample(f, c, B, verts, stream);
 }
 
 int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream) {

@@ -10,7 +10,7 @@ constexpr int kCB = 14;                 // 32-wide k blocks over the 431 coarse 
 constexpr int kTile = 32 * 32;          // floats in one packed 32x32 tile ([4 g][64 lanes][4])
 
 struct MdrLayerP {                      // packed weights of one LBF layer (device pointers into FusedState::wbuf)
-    const float *wq, *proj, *fc1, *fc2, *sa[4];
+    const float *wq, *wk, *wv, *proj, *fc1, *fc2, *sa[4];
 };
 
 struct GatBlockPk {                     // packed tiles of one GATBlock
@@ -31,7 +31,9 @@ struct FusedState {
     const float* head_w = nullptr;      // [1 nb][2 kb] combined motion/bias/scale linear
     const float* head_b = nullptr;      // [32]
     const float* tok_base = nullptr;    // [14][2][4][64][4]  v431 part of get_verts_feature + bias + pos_v  (T-layout tiles)
-    const float* tok_w3 = nullptr;      // [3][64]            pose3d part of get_verts_feature (columns 3..5), row-major [i][ch]
+    const float* tok_w3 = nullptr;
+    const float* jfeat_p = nullptr;     // get_joint_feature.weight packed [2 nb][5 kb]
+    const float* posj_T = nullptr;      // [2] T-layout tiles of pos_j_id_embed[1..J]      // [3][64]            pose3d part of get_verts_feature (columns 3..5), row-major [i][ch]
     // workspace (per cap batch)
     float* ws = nullptr;
     size_t ws_floats = 0;

@@ -296,77 +296,77 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
 
 // Joint tokens: jf = Linear(133->64)(pose_combine) + pos_j (MDR.py:130-134); per layer k = wk(LN1(jf)), v = wv(LN1(jf))
 // (MDR.py:37-38 with norm1 applied to the concatenated tokens, :65).  jf does not change across the three layers.
-// Output in MFMA operand order: K tile [hd][g][lane=(joint,h)][j] = k[joint][32hd+8g+4h+j];
-//                               V tile [hd][g][lane=(d,h)][j]     = v[joint=8g+4h+j][32hd+d].
+// One workgroup (2 waves) per sample; wave w owns channel block w (= head w).  Output in MFMA operand order:
+//   K tile [hd][g][lane=(joint,h)][j] = k[joint][32hd+8g+4h+j]  (T-layout block hd)
+//   V tile [hd][g][lane=(d,h)][j]     = v[joint=8g+4h+j][32hd+d] (C-layout block hd)
 struct JointArgs {
-    const float *pc, *jw, *jb, *pos_j;
-    const float *n1w[3], *n1b[3], *wk[3], *wv[3];
+    const float *pc, *jw_p, *jb, *posj_T;       // jw_p: packed [2 nb][5 kb]; posj_T: [2] T-layout tiles of pos_j[1..J]
+    const float *n1w[3], *n1b[3], *wk_p[3], *wv_p[3];
     float* jkv;
     int J;
 };
-__global__ __launch_bounds__(256) void k_mdr_joint(const JointArgs a) {
-    __shared__ float pcs[kMaxJ][136];
-    __shared__ float jf[kMaxJ][kE], fz[kMaxJ][kE], kk[kMaxJ][kE], vv[kMaxJ][kE];
-    const int b = blockIdx.x, t = threadIdx.x, J = a.J;
-    for (int e = t; e < J * 133; e += 256) pcs[e / 133][e % 133] = a.pc[(size_t)b * J * 133 + e];
-    __syncthreads();
-    const int ch = t & 63;
-    for (int j = t >> 6; j < J; j += 4) {
-        double s = (double)a.jb[ch];
-        for (int k = 0; k < 133; ++k) s += (double)a.jw[ch * 133 + k] * (double)pcs[j][k];
-        jf[j][ch] = (float)(s + (double)a.pos_j[(j + 1) * kE + ch]);
+__global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
+    __shared__ __attribute__((aligned(16))) float PCt[5 * kTile];
+    __shared__ __attribute__((aligned(16))) float JF[2 * kTile];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, J = a.J;
+    for (int e = t; e < 5 * kTile; e += 128) {
+        const int j4 = e & 3, ln = (e >> 2) & 63, g = (e >> 8) & 3, kb = e >> 10;
+        const int tok = ln & 31, k = 32 * kb + 8 * g + 4 * (ln >> 5) + j4;
+        PCt[e] = (tok < J && k < 133) ? a.pc[((size_t)b * J + tok) * 133 + k] : 0.f;
     }
     __syncthreads();
+    {
+        f32x16 a0 = load_chanvec_T(a.jb, 32 * wave, h) + load_block(a.posj_T + wave * kTile, lane), a1 = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 5; ++kb) {
+            if (kb & 1) a1 = mma_T(load_wtile(a.jw_p, wave * 5 + kb, lane), load_block(PCt + kb * kTile, lane), a1);
+            else a0 = mma_T(load_wtile(a.jw_p, wave * 5 + kb, lane), load_block(PCt + kb * kTile, lane), a0);
+        }
+        store_block(JF + wave * kTile, lane, a0 + a1);
+    }
+    __syncthreads();
+    f32x16 jf[2];
+    jf[0] = load_block(JF, lane);
+    jf[1] = load_block(JF + kTile, lane);
+    const bool tok_ok = (lane & 31) < J;
+#pragma unroll 1
     for (int li = 0; li < 3; ++li) {
-        for (int j = t >> 6; j < J; j += 4) {        // one wave per joint: LayerNorm over 64 channels
-            double x = (double)jf[j][ch], s = x;
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            const double mean = s / 64.0;
-            double q = (x - mean) * (x - mean);
-            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-            fz[j][ch] = (float)((x - mean) / sqrt(q / 64.0 + 1e-5) * (double)a.n1w[li][ch] + (double)a.n1b[li][ch]);
-        }
-        __syncthreads();
-        for (int j = t >> 6; j < kMaxJ; j += 4) {
-            double sk = 0.0, sv = 0.0;
-            if (j < J)
-                for (int k = 0; k < kE; ++k) {
-                    sk += (double)a.wk[li][ch * kE + k] * (double)fz[j][k];
-                    sv += (double)a.wv[li][ch * kE + k] * (double)fz[j][k];
-                }
-            kk[j][ch] = (float)sk;      // rows >= J are zero: masked in the softmax / contribute nothing to PV
-            vv[j][ch] = (float)sv;
-        }
-        __syncthreads();
+        f32x16 fz[2];
+        layernorm64(jf, a.n1w[li], a.n1b[li], h, fz);
         float* out = a.jkv + (((size_t)b * 3 + li) * 4) * kTile;
-        for (int e = t; e < 2 * kTile; e += 256) {
-            const int j4 = e & 3, lane = (e >> 2) & 63, g = (e >> 8) & 3, hd = e >> 10;
-            out[e] = kk[lane & 31][32 * hd + 8 * g + 4 * (lane >> 5) + j4];
-            out[2 * kTile + e] = vv[8 * g + 4 * (lane >> 5) + j4][32 * hd + (lane & 31)];
-        }
-        __syncthreads();
+        f32x16 kt = mma_T(load_wtile(a.wk_p[li], wave * 2 + 0, lane), fz[0], zero16()) +
+                    mma_T(load_wtile(a.wk_p[li], wave * 2 + 1, lane), fz[1], zero16());
+        if (!tok_ok) kt = zero16();             // joints >= J: zero rows (masked in the softmax anyway)
+        store_block(out + wave * kTile, lane, kt);
+        f32x16 vt = mma_C(load_wtile(a.wv_p[li], wave * 2 + 0, lane), fz[0], zero16()) +
+                    mma_C(load_wtile(a.wv_p[li], wave * 2 + 1, lane), fz[1], zero16());
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vt[r] = (kap(r) + 4 * h < J) ? vt[r] : 0.f;
+        store_block(out + (2 + wave) * kTile, lane, vt);
     }
 }
 
 // MDR head (MDR.py:156-166) from the per-token head features hf[b][v][32]:
 //   ch 0..19 = mat_A, 24..26 = bias_linear out, 27 = scale_linear out, 28..30 = mat_C   (our own packing order)
+// Writes vert431 both in the reference layout (tap / stage API) and as the packed A operand of the vertex GEMM.
 struct HeadArgs {
     const float *hf, *bn_w, *bn_b, *bn_mean, *bn_var, *bconv_w, *bconv_b;
-    float* vc;
+    float *vc, *vcp;
     int alpha;
 };
 __global__ __launch_bounds__(256) void k_mdr_head(const HeadArgs a) {
-    __shared__ float bn[kV + 1][3];
-    __shared__ double part[4][60];
+    __shared__ float bn[kV][3];
+    __shared__ float part[4][60];
     __shared__ float bc[20][3];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* hf = a.hf + (size_t)b * kV * 32;
     for (int v = t; v < kV; v += 256) {
-        double x[3] = {(double)hf[v * 32 + 24], (double)hf[v * 32 + 25], (double)hf[v * 32 + 26]};
+        const f32x4 q = *reinterpret_cast<const f32x4*>(hf + v * 32 + 24);
+        double x[3] = {(double)q[0], (double)q[1], (double)q[2]};
         if (a.alpha) {      // LayerNorm(3)
             const double m = (x[0] + x[1] + x[2]) / 3.0;
-            const double q = ((x[0] - m) * (x[0] - m) + (x[1] - m) * (x[1] - m) + (x[2] - m) * (x[2] - m)) / 3.0;
-            const double rs = 1.0 / sqrt(q + 1e-5);
+            const double qq = ((x[0] - m) * (x[0] - m) + (x[1] - m) * (x[1] - m) + (x[2] - m) * (x[2] - m)) / 3.0;
+            const double rs = 1.0 / sqrt(qq + 1e-5);
             for (int c = 0; c < 3; ++c) x[c] = (x[c] - m) * rs * (double)a.bn_w[c] + (double)a.bn_b[c];
         } else {            // BatchNorm1d(431) eval: channel = vertex
             const double rs = 1.0 / sqrt((double)a.bn_var[v] + 1e-5);
@@ -375,32 +375,60 @@ __global__ __launch_bounds__(256) void k_mdr_head(const HeadArgs a) {
         for (int c = 0; c < 3; ++c) bn[v][c] = (float)(0.5 * x[c] * (1.0 + erf(x[c] * 0.70710678118654752440)));
     }
     __syncthreads();
-    if (t < 240) {          // Conv1d(431->20,k3,p1): 60 outputs x 4 slices of the 431 input channels
-        const int o = t % 60, sl = t / 60, m = o / 3, l = o % 3;
-        double s = 0.0;
-        for (int c = sl; c < kV; c += 4)
-            for (int k = 0; k < 3; ++k) {
-                const int ll = l + k - 1;
-                if (ll >= 0 && ll < 3) s += (double)a.bconv_w[(m * kV + c) * 3 + k] * (double)bn[c][ll];
+    {   // Conv1d(431->20,k3,p1) over the xyz axis: every thread walks the (c,k) axis with coalesced weight reads
+        float acc[20][3];
+#pragma unroll
+        for (int m = 0; m < 20; ++m) acc[m][0] = acc[m][1] = acc[m][2] = 0.f;
+        for (int e = t; e < kV * 3; e += 256) {
+            const int c = e / 3, k = e - 3 * c;
+            // tap k of channel c meets input position ll = l + k - 1 (zero padding outside 0..2)
+            const float in0 = (k >= 1) ? bn[c][k - 1] : 0.f;        // l=0: ll = k-1
+            const float in1 = bn[c][k];                             // l=1: ll = k
+            const float in2 = (k <= 1) ? bn[c][k + 1] : 0.f;        // l=2: ll = k+1
+#pragma unroll
+            for (int m = 0; m < 20; ++m) {
+                const float w = a.bconv_w[m * (kV * 3) + e];
+                acc[m][0] += w * in0;
+                acc[m][1] += w * in1;
+                acc[m][2] += w * in2;
             }
-        part[sl][o] = s;
+        }
+#pragma unroll
+        for (int m = 0; m < 20; ++m)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                float s = acc[m][l];
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                if (lane == 0) part[wave][m * 3 + l] = s;
+            }
     }
     __syncthreads();
-    if (t < 60) bc[t / 3][t % 3] = (float)(part[0][t] + part[1][t] + part[2][t] + part[3][t] + (double)a.bconv_b[t / 3]);
+    if (t < 60) bc[t / 3][t % 3] = (float)(((double)part[0][t] + (double)part[1][t]) + ((double)part[2][t] + (double)part[3][t]) + (double)a.bconv_b[t / 3]);
     __syncthreads();
+    const int mt = b >> 5, sl = b & 31;
     for (int v = t; v < kV; v += 256) {
         const float* r = hf + v * 32;
+        float av[20];
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(r + 4 * g);
+            av[4 * g] = q[0]; av[4 * g + 1] = q[1]; av[4 * g + 2] = q[2]; av[4 * g + 3] = q[3];
+        }
+        const f32x4 tail = *reinterpret_cast<const f32x4*>(r + 24), cc = *reinterpret_cast<const f32x4*>(r + 28);
         double mx = -1e300, p[20], l = 0.0;
-        for (int m = 0; m < 20; ++m) mx = fmax(mx, (double)r[m]);
+        for (int m = 0; m < 20; ++m) mx = fmax(mx, (double)av[m]);
         for (int m = 0; m < 20; ++m) {
-            p[m] = exp((double)r[m] - mx);
+            p[m] = exp((double)av[m] - mx);
             l += p[m];
         }
-        const double sc = a.alpha ? pow(1.1, (double)r[27]) : 1.0;
+        const double sc = a.alpha ? pow(1.1, (double)tail[3]) : 1.0;
+        const int cb = v >> 5, g = (v & 31) >> 3, hh = (v & 7) >> 2, j = v & 3;
         for (int c = 0; c < 3; ++c) {
             double o = 0.0;
             for (int m = 0; m < 20; ++m) o += (p[m] / l) * (double)bc[m][c];
-            a.vc[((size_t)b * kV + v) * 3 + c] = (float)(sc * o + (double)r[28 + c]);
+            const float val = (float)(sc * o + (double)cc[c]);
+            a.vc[((size_t)b * kV + v) * 3 + c] = val;
+            a.vcp[(((((size_t)mt * 3 + c) * kCB + cb) * 4 + g) * 64 + hh * 32 + sl) * 4 + j] = val;
         }
     }
 }
@@ -423,9 +451,9 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     hipStream_t st = (hipStream_t)stream;
     const Weights& w = c->w;
     JointArgs ja;
-    ja.pc = pc; ja.jw = w.jfeat_w; ja.jb = w.jfeat_b; ja.pos_j = w.pos_j; ja.jkv = f->jkv; ja.J = c->J;
-    for (int i = 0; i < 3; ++i) { ja.n1w[i] = w.lay[i].n1w; ja.n1b[i] = w.lay[i].n1b; ja.wk[i] = w.lay[i].wk; ja.wv[i] = w.lay[i].wv; }
-    { StageTimer tm(c, "mdr_joint", stream); k_mdr_joint<<<B, 256, 0, st>>>(ja); }
+    ja.pc = pc; ja.jw_p = f->jfeat_p; ja.jb = w.jfeat_b; ja.posj_T = f->posj_T; ja.jkv = f->jkv; ja.J = c->J;
+    for (int i = 0; i < 3; ++i) { ja.n1w[i] = w.lay[i].n1w; ja.n1b[i] = w.lay[i].n1b; ja.wk_p[i] = f->lay[i].wk; ja.wv_p[i] = f->lay[i].wv; }
+    { StageTimer tm(c, "mdr_joint", stream); k_mdr_joint<<<B, 128, 0, st>>>(ja); }
     const size_t per = (size_t)f->cap * kVT * 2 * kTile;      // one [B][14][2] tile set
     float* set[2][4] = {{f->vf, f->q, f->k, f->v}, {f->vf + per, f->q + per, f->k + per, f->v + per}};
     MdrArgs a{};
@@ -447,7 +475,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     }
     HeadArgs ha;
     ha.hf = f->hf; ha.bn_w = w.bn_w; ha.bn_b = w.bn_b; ha.bn_mean = w.bn_mean; ha.bn_var = w.bn_var;
-    ha.bconv_w = w.bconv_w; ha.bconv_b = w.bconv_b; ha.vc = f->vc; ha.alpha = c->alpha;
+    ha.bconv_w = w.bconv_w; ha.bconv_b = w.bconv_b; ha.vc = f->vc; ha.vcp = f->vcp; ha.alpha = c->alpha;
     { StageTimer tm(c, "mdr_head", stream); k_mdr_head<<<B, 256, 0, st>>>(ha); }
     GATOR_HIP_CHECK(hipGetLastError());
     c->taps["mdr_lbf2"] = {f->lbf, (int64_t)B * kV * kE};
