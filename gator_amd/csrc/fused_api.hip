@@ -52,7 +52,7 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
     const Weights& w = c->w;
     const int J = c->J;
     const size_t blk_tiles = 48 + 16 + 16 + 16 + 16 + 4 + 20 + 64 + 64 + 4 + 4 + 1 + 1;     // 274
-    const size_t total = (kDepth * blk_tiles + 8 + 2 + (size_t)3 * J * 4) * kTile;
+    const size_t total = (kDepth * blk_tiles + 8 + 2 + 8 + 4 + 12 + (size_t)3 * J * 4) * kTile;
     GATOR_HIP_CHECK(hipMalloc(&f->gbuf, total * sizeof(float)));
     float* p = f->gbuf;
     auto take = [&](size_t tiles) { float* r = p; p += tiles * kTile; return r; };
@@ -111,6 +111,32 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
     f->g_m1T = upload(mt);
     fill_tile(mt.data(), [&](int t, int j) { return (t < J && j < J) ? m2[(size_t)t * J + j] : 0.f; });
     f->g_m2T = upload(mt);
+    {   // per-block small vectors, concatenated in the order of gat_fused.hip's V_* enum (2048 floats per block)
+        std::vector<float> vv((size_t)kDepth * 2048);
+        for (int i = 0; i < kDepth; ++i) {
+            const GatBlockW& r = w.blk[i];
+            const struct { const float* p; int n; } parts[] = {{r.n1w, 128}, {r.n1b, 128}, {r.qkv_b, 384}, {r.proj_b, 128}, {r.gcn_bias, 128},
+                                                               {r.xl0_b, 128}, {r.xlb_b, 128}, {r.n2w, 128}, {r.n2b, 128}, {r.fc1_b, 512}, {r.fc2_b, 128}};
+            size_t off = (size_t)i * 2048;
+            for (auto& pt : parts) {
+                const std::vector<float> h = d2h(pt.p, pt.n);
+                std::copy(h.begin(), h.end(), vv.begin() + off);
+                off += pt.n;
+            }
+        }
+        f->g_vecs = upload(vv);
+    }
+    {   // embed: GLinear.3 packed, pos_id_embed[1..J] + pos_num_embed[deg] as T-layout tiles (GAT.py:141-144)
+        float* dst = take(8);
+        int rc = fused_pack_linear(w.gl3_W, 64, 1, 128, 64, dst, stream);
+        if (rc) return rc;
+        f->g_gl3 = dst;
+        const std::vector<float> pe = d2h(c->pos_embed, (size_t)J * kC);
+        std::vector<float> pt(4 * kTile);
+        for (int kb = 0; kb < 4; ++kb)
+            fill_tile(pt.data() + (size_t)kb * kTile, [&](int t, int ch) { return t < J ? pe[(size_t)t * kC + 32 * kb + ch] : 0.f; });
+        f->g_posT = upload(pt);
+    }
     // lifter [3J][128J] -> per output o, 4 T-layout tiles: tile[kb][g][lane][j] = Wl[o][(lane&31)*128 + 32kb + 8g + 4h + j]
     {
         const std::vector<float> wl = d2h(w.lifter_w, (size_t)3 * J * kC * J);

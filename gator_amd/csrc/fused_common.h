@@ -96,7 +96,47 @@ __device__ __forceinline__ void store_block(float* __restrict__ p, int lane, con
     }
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf to < 1 ulp (N. Juffa's two-range minimax form), both ranges evaluated and selected branch-free: ~23 VALU ops against
+// ~60 for the branchy library erff, which costs both sides whenever a wave's lanes straddle |x| = 1.
+__device__ __forceinline__ float erf_fast(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = copysignf(1.0f - __builtin_amdgcn_exp2f(r * 1.4426950408889634f), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    const float small = fmaf(q, a, a);
+    return t > 0.927734375f ? big : small;
+}
+// exact (erf) GELU, as nn.GELU() / F.gelu default
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+
+// Per-channel vector in T-layout through the SCALAR cache: the value depends only on (register, lane half), so the 8
+// floats of each g are fetched with wave-uniform s_load (constant address space -> SMEM, counted on lgkmcnt) and selected
+// by half.  Unlike a vector load this never queues behind the in-order vmcnt of a weight prefetch in flight.
+// `vec + base` must be wave-uniform (kernel-argument pointer, compile-time or readfirstlane'd base).
+typedef const float __attribute__((address_space(4))) gator_cfloat;
+__device__ __forceinline__ f32x16 load_chanvec_S(const float* vec, int base, int h) {
+    const gator_cfloat* cv = (const gator_cfloat*)(unsigned long long)(vec + base);
+    f32x16 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = cv[8 * g + j], hi = cv[8 * g + 4 + j];
+            v[4 * g + j] = h ? hi : lo;
+        }
+    return v;
+}
 
 // XCD-aware bijective remap of a 1-D grid: blocks that share an XCD (equal blockIdx % 8) get CONTIGUOUS logical ids,
 // so the workgroups of one sample hit one L2.  Speed only -- never correctness (cdna_hip_programming.md T1).

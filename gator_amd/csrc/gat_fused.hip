@@ -11,6 +11,8 @@
 #include "fused_common.h"
 #include "fused_state.h"
 
+#include <cstdlib>
+
 namespace gator {
 namespace {
 
@@ -19,18 +21,35 @@ constexpr float kLog2eG = 1.4426950408889634f;
 struct GatBlockP {   // per-GATBlock packed tiles + reference-layout vectors
     const float *qkv, *proj, *w0, *w1, *lin0, *lin1, *back, *fc1, *fc2;      // packed [NB][KB] tile grids
     const float *mc, *md, *aoffT, *f1b;                                        // packed tables (see GatTables)
-    const float *n1w, *n1b, *qkv_b, *proj_b, *gcn_b, *lin0_b, *back_b, *n2w, *n2b, *fc1_b, *fc2_b;
+    const float* vecs;                                                         // V_TOTAL floats, order above
 };
 
 struct GatArgs {
     int B, J;
     const float* pose2d;
-    const float *gl0_W, *gl0_b, *gn_w, *gn_b, *gl3_W, *gl3_b, *pos;            // embed (reference layout; pos = folded table [J][128])
+    const float *gl0_W, *gl0_b, *gn_w, *gn_b, *gl3_p, *gl3_b, *posT;           // embed: gl3_p packed [4][2]; posT = 4 folded T-layout tiles
     const float *biasT, *m1T, *m2T;                                            // [8] tiles, 1 tile, 1 tile
     const float *norm_w, *norm_b, *lifter_p, *lifter_b;                        // lifter_p: [3J][4 kb] tiles
     GatBlockP blk[kDepth];
     float *x_out, *feat;
+    unsigned long long* stamps;     // diagnostic only (GATOR_GAT_STAMPS=1): per-phase cycle sums of workgroup 0, wave 0
 };
+
+// Per-block small vectors (LayerNorm weights, biases) are staged in LDS one block ahead: 2048 floats in this order.
+// A global load issued at its point of use would queue behind the weight prefetch in flight (vmcnt is in-order).
+enum { V_N1W = 0, V_N1B = 128, V_QKVB = 256, V_PROJB = 640, V_GCNB = 768, V_LIN0B = 896, V_BACKB = 1024, V_N2W = 1152,
+       V_N2B = 1280, V_FC1B = 1408, V_FC2B = 1920, V_TOTAL = 2048 };
+// per-channel vector in T-layout from LDS: v[r] = V[off + kap(r) + 4h]  (two distinct addresses per ds_read_b128: broadcast)
+__device__ __forceinline__ f32x16 load_chanvec_L(const float* V, int off, int h) {
+    f32x16 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(V + off + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * g + j] = t[j];
+    }
+    return v;
+}
 
 __device__ __forceinline__ float row_sum128(const f32x16 (&x)[4]) {
     float s = 0.f;
@@ -41,8 +60,7 @@ __device__ __forceinline__ float row_sum128(const f32x16 (&x)[4]) {
 
 // nn.LayerNorm(128); reads the residual stream X (4 tiles in LDS), result in registers
 template <bool GELU>
-__device__ __forceinline__ void layernorm128(const float* X, const float* __restrict__ w, const float* __restrict__ b, int lane,
-                                             f32x16 (&y)[4]) {
+__device__ __forceinline__ void layernorm128(const float* X, const float* w, const float* b, int lane, f32x16 (&y)[4]) {
     const int h = lane >> 5;
     f32x16 x[4];
 #pragma unroll
@@ -56,7 +74,7 @@ __device__ __forceinline__ void layernorm128(const float* X, const float* __rest
     const float rstd = 1.0f / sqrtf(row_sum128(sq) * (1.0f / 128.0f) + 1e-5f);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-        y[kb] = x[kb] * rstd * load_chanvec_T(w, 32 * kb, h) + load_chanvec_T(b, 32 * kb, h);
+        y[kb] = x[kb] * rstd * load_chanvec_L(w, 32 * kb, h) + load_chanvec_L(b, 32 * kb, h);
         if (GELU) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) y[kb][r] = gelu_f(y[kb][r]);
@@ -64,30 +82,45 @@ __device__ __forceinline__ void layernorm128(const float* X, const float* __rest
     }
 }
 
-// sum over 4 k-blocks held in registers (xs) with two independent 64-term chains (fp32 accuracy), T- or C-layout output
+// Fence for the hand-built pipeline: memory ops may not cross (keeps a prefetch from sinking to its first use) and the
+// machine scheduler may not move anything across (measured: phase 1 of a block 51k -> 36k cycles with these fences).
+#define GATOR_PIN()                          \
+    do {                                     \
+        asm volatile("" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+struct WG4 { WTile t[4]; };     // one 4-tile weight group = 16 float4 per lane (64 VGPRs)
+__device__ __forceinline__ WG4 ldg4(const float* __restrict__ Wp, int tile0, int lane) {
+    WG4 g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g.t[i] = load_wtile(Wp, tile0 + i, lane);
+    return g;
+}
+// sum over 4 k-blocks with two independent 64-term chains (fp32 accuracy); operands in registers, T- or C-layout output
 template <bool CL>
-__device__ __forceinline__ f32x16 lin4(const float* __restrict__ Wp, int tile0, const f32x16 (&xs)[4], int lane, f32x16 init) {
+__device__ __forceinline__ f32x16 lin4r(const WG4& g, const f32x16 (&xs)[4], f32x16 init) {
     f32x16 a0 = init, a1 = zero16();
     if (CL) {
-        a0 = mma_C(load_wtile(Wp, tile0 + 0, lane), xs[0], a0);
-        a1 = mma_C(load_wtile(Wp, tile0 + 1, lane), xs[1], a1);
-        a0 = mma_C(load_wtile(Wp, tile0 + 2, lane), xs[2], a0);
-        a1 = mma_C(load_wtile(Wp, tile0 + 3, lane), xs[3], a1);
+        a0 = mma_C(g.t[0], xs[0], a0);
+        a1 = mma_C(g.t[1], xs[1], a1);
+        a0 = mma_C(g.t[2], xs[2], a0);
+        a1 = mma_C(g.t[3], xs[3], a1);
     } else {
-        a0 = mma_T(load_wtile(Wp, tile0 + 0, lane), xs[0], a0);
-        a1 = mma_T(load_wtile(Wp, tile0 + 1, lane), xs[1], a1);
-        a0 = mma_T(load_wtile(Wp, tile0 + 2, lane), xs[2], a0);
-        a1 = mma_T(load_wtile(Wp, tile0 + 3, lane), xs[3], a1);
+        a0 = mma_T(g.t[0], xs[0], a0);
+        a1 = mma_T(g.t[1], xs[1], a1);
+        a0 = mma_T(g.t[2], xs[2], a0);
+        a1 = mma_T(g.t[3], xs[3], a1);
     }
     return a0 + a1;
 }
-// same with the operand tiles read from LDS
-__device__ __forceinline__ f32x16 lin4_lds(const float* __restrict__ Wp, int tile0, const float* T, int lane, f32x16 init) {
+// same with the 4 operand tiles read from LDS (consecutive tiles at T)
+__device__ __forceinline__ f32x16 lin4l(const WG4& g, const float* T, int lane, f32x16 init) {
     f32x16 a0 = init, a1 = zero16();
-    a0 = mma_T(load_wtile(Wp, tile0 + 0, lane), load_block(T + 0 * kTile, lane), a0);
-    a1 = mma_T(load_wtile(Wp, tile0 + 1, lane), load_block(T + 1 * kTile, lane), a1);
-    a0 = mma_T(load_wtile(Wp, tile0 + 2, lane), load_block(T + 2 * kTile, lane), a0);
-    a1 = mma_T(load_wtile(Wp, tile0 + 3, lane), load_block(T + 3 * kTile, lane), a1);
+    a0 = mma_T(g.t[0], load_block(T + 0 * kTile, lane), a0);
+    a1 = mma_T(g.t[1], load_block(T + 1 * kTile, lane), a1);
+    a0 = mma_T(g.t[2], load_block(T + 2 * kTile, lane), a0);
+    a1 = mma_T(g.t[3], load_block(T + 3 * kTile, lane), a1);
     return a0 + a1;
 }
 
@@ -96,12 +129,22 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
     float* X = lds;                       // residual stream, 4 tiles (T-layout)
     float* R = lds + 4 * kTile;           // 16 tiles of phase-local scratch
     float *AT = R, *SB = R + 4 * kTile, *FB = R + 8 * kTile, *F1P = R + 12 * kTile, *HB = R;
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, J = a.J;
+    float* V = lds + 20 * kTile;          // per-block vectors (V_TOTAL floats)
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // provably wave-uniform (scalar loads, scalar addressing)
+    unsigned long long st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = a.stamps ? clock64() : 0;
+#define GAT_STAMP(i)                                      \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    if (a.stamps) {                                       \
+        const unsigned long long now_ = clock64();        \
+        st_acc[i] += now_ - st_last;                      \
+        st_last = now_;                                   \
+    }
 
     // ---------------- embedding: GraphLinear(2->64) . GroupNorm(4,64) . GELU . GraphLinear(64->128) + pos (GAT.py:135-144)
     {
         float* hbuf = R;                  // [64][32]
-        float* gbuf = R + 2 * kTile;      // [64][32]
+        float* gt = R + 2 * kTile;        // 2 T-layout tiles
         float* stat = R + 4 * kTile;      // [4][2]
         const float* p = a.pose2d + (size_t)b * J * 2;
         for (int e = t; e < 64 * 32; e += 256) {
@@ -123,50 +166,74 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             if (lane == 0) { stat[wave * 2] = mean; stat[wave * 2 + 1] = 1.0f / sqrtf(q / (16.0f * J) + 1e-5f); }
         }
         __syncthreads();
-        for (int e = t; e < 64 * 32; e += 256) {
-            const int c = e >> 5;
-            gbuf[e] = gelu_f((hbuf[e] - stat[(c >> 4) * 2]) * stat[(c >> 4) * 2 + 1] * a.gn_w[c] + a.gn_b[c]);
+        // GroupNorm affine + GELU, written as two T-layout operand tiles gt[kb][g][lane][j] <-> token lane&31, channel 32kb+8g+4h+j
+        for (int e = t; e < 2 * kTile; e += 256) {
+            const int j4 = e & 3, ln = (e >> 2) & 63, g = (e >> 8) & 3, kb = e >> 10;
+            const int tok = ln & 31, c = 32 * kb + 8 * g + 4 * (ln >> 5) + j4;
+            gt[e] = tok < J ? gelu_f((hbuf[c * 32 + tok] - stat[(c >> 4) * 2]) * stat[(c >> 4) * 2 + 1] * a.gn_w[c] + a.gn_b[c]) : 0.f;
         }
         __syncthreads();
-        // x[token][n] -> X tiles: X[kb][g][lane][j] <-> token = lane&31, ch = 32kb + 8g + 4(lane>>5) + j
-        for (int e = t; e < 4 * kTile; e += 256) {
-            const int j4 = e & 3, ln = (e >> 2) & 63, g = (e >> 8) & 3, kb = e >> 10;
-            const int tok = ln & 31, n = 32 * kb + 8 * g + 4 * (ln >> 5) + j4;
-            float v = 0.f;
-            if (tok < J) {
-                v = a.gl3_b[n];
-                for (int c = 0; c < 64; ++c) v += a.gl3_W[n * 64 + c] * gbuf[c * 32 + tok];
-                v += a.pos[tok * kC + n];
-            }
-            X[e] = v;
+        for (int e = t; e < V_TOTAL / 4; e += 256)
+            reinterpret_cast<f32x4*>(V)[e] = reinterpret_cast<const f32x4*>(a.blk[0].vecs)[e];
+        // GraphLinear(64->128) on the MFMA: wave w -> channel block w;  + pos_id_embed + pos_num_embed (folded T-layout tiles)
+        {
+            f32x16 acc = load_chanvec_S(a.gl3_b, 32 * wave, h) + load_block(a.posT + (size_t)wave * kTile, lane);
+            acc = mma_T(load_wtile(a.gl3_p, wave * 2 + 0, lane), load_block(gt, lane), acc);
+            acc = mma_T(load_wtile(a.gl3_p, wave * 2 + 1, lane), load_block(gt + kTile, lane), acc);
+            store_block(X + wave * kTile, lane, acc);
         }
         __syncthreads();
     }
-
+    GAT_STAMP(0)
     f32x16 xw = load_block(X + wave * kTile, lane);       // this wave's block of the residual stream
     f32x16 ident;                                          // identity as a B operand: I[t_out = lane&31][j = kap(r)+4h]
 #pragma unroll
     for (int r = 0; r < 16; ++r) ident[r] = (kap(r) + 4 * h == (lane & 31)) ? 1.f : 0.f;
 
+    // Software pipeline of the weight stream.  One wave per SIMD means nobody hides this wave's L2 latency, so the next
+    // 4-tile weight group (16 x 1 KiB wave loads) is always in flight while the current one feeds the MFMAs: two group
+    // buffers G0/G1 alternate through the fixed per-block order q,k,v,W0,W1,proj,lin0,back,fc1[4],fc2[4].  GATOR_PIN keeps
+    // the compiler from sinking a prefetch back down to its first use.
+    WG4 G0 = ldg4(a.blk[0].qkv, wave * 4, lane);
+    WG4 G1 = ldg4(a.blk[0].qkv, (4 + wave) * 4, lane);
+    GATOR_PIN();
+
     for (int bi = 0; bi < kDepth; ++bi) {
         const GatBlockP& w = a.blk[bi];
+        const GatBlockP& wn = a.blk[bi + 1 < kDepth ? bi + 1 : bi];     // next block (prefetch target; harmless re-load at the end)
         f32x16 g_out;
+        f32x4 vn0, vn1;
         {
+            // next block's vectors: requested now (behind nothing that is needed soon), written to LDS after the last read of V
+            vn0 = reinterpret_cast<const f32x4*>(wn.vecs)[t];
+            vn1 = reinterpret_cast<const f32x4*>(wn.vecs)[256 + t];
+            GATOR_PIN();
+            const f32x16 bq = load_chanvec_L(V, V_QKVB + 32 * wave, h), bk = load_chanvec_L(V, V_QKVB + 128 + 32 * wave, h);
+            const float vb = V[V_QKVB + 256 + 32 * wave + (lane & 31)];
             f32x16 y[4];
-            layernorm128<false>(X, w.n1w, w.n1b, lane, y);
+            layernorm128<false>(X, V + V_N1W, V + V_N1B, lane, y);
+            GAT_STAMP(10)
             // ---- Attention (modules.py:121-138): wave owns heads 2*wave, 2*wave+1 ----
+            const f32x16 q = lin4r<false>(G0, y, bq);
+            G0 = ldg4(w.qkv, (8 + wave) * 4, lane);
+            GATOR_PIN();
+            GAT_STAMP(11)
+            const f32x16 k = lin4r<false>(G1, y, bk);
+            G1 = ldg4(w.w0, wave * 4, lane);
+            const f32x16 ba = load_block(a.biasT + (size_t)(2 * wave) * kTile, lane);
+            const f32x16 bb = load_block(a.biasT + (size_t)(2 * wave + 1) * kTile, lane);
+            GATOR_PIN();
+            GAT_STAMP(12)
+            const f32x16 v = lin4r<true>(G0, y, zero16());
+            G0 = ldg4(w.w1, wave * 4, lane);
+            GATOR_PIN();
+            GAT_STAMP(13)
             {
-                const f32x16 q = lin4<false>(w.qkv, wave * 4, y, lane, load_chanvec_T(w.qkv_b, 32 * wave, h));
-                const f32x16 k = lin4<false>(w.qkv, (4 + wave) * 4, y, lane, load_chanvec_T(w.qkv_b, 128 + 32 * wave, h));
-                const f32x16 v = lin4<true>(w.qkv, (8 + wave) * 4, y, lane, zero16());
-                const float vb = w.qkv_b[256 + 32 * wave + (lane & 31)];
                 f32x16 sa = zero16(), sb = zero16();
 #pragma unroll
                 for (int r = 0; r < 8; ++r) sa = GATOR_MFMA(k[r], q[r], sa);            // head 2w:   channels 0..15 of the block
 #pragma unroll
                 for (int r = 8; r < 16; ++r) sb = GATOR_MFMA(k[r], q[r], sb);           // head 2w+1: channels 16..31
-                const f32x16 ba = load_block(a.biasT + (size_t)(2 * wave) * kTile, lane);
-                const f32x16 bb = load_block(a.biasT + (size_t)(2 * wave + 1) * kTile, lane);
                 float ma = -1e30f, mb = -1e30f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -199,112 +266,187 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
                 }
                 store_block(AT + wave * kTile, lane, O);
             }
+            GAT_STAMP(14)
             // ---- MGCN (modules.py:243-255): h_k = y @ W[k]; out = diag(A)(M.h0) + offdiag(A)(M.h1) + bias ----
-            {
-                f32x16 h0 = lin4<true>(w.w0, wave * 4, y, lane, zero16());
-                f32x16 h1 = lin4<true>(w.w1, wave * 4, y, lane, zero16());
-                h0 = h0 * load_block(w.md + (size_t)wave * kTile, lane);                    // diag(A)[t] * M[t][n] * h0[t][n]
-                h1 = h1 * load_block(w.mc + (size_t)wave * kTile, lane);                    // M[t][n] * h1[t][n]
-                const f32x16 aoff = load_block(w.aoffT, lane);
-                g_out = load_chanvec_T(w.gcn_b, 32 * wave, h);
+            const f32x16 mdt = load_block(w.md + (size_t)wave * kTile, lane), mct = load_block(w.mc + (size_t)wave * kTile, lane);
+            const f32x16 aoff = load_block(w.aoffT, lane);
+            const f32x16 bg = load_chanvec_L(V, V_GCNB + 32 * wave, h), bp = load_chanvec_L(V, V_PROJB + 32 * wave, h);
+            GATOR_PIN();
+            f32x16 h0 = lin4r<true>(G1, y, zero16());
+            G1 = ldg4(w.proj, wave * 4, lane);
+            GATOR_PIN();
+            GAT_STAMP(15)
+            f32x16 h1 = lin4r<true>(G0, y, zero16());
+            G0 = ldg4(w.lin0, wave * 4, lane);
+            GATOR_PIN();
+            GAT_STAMP(16)
+            h0 = h0 * mdt;                                                                  // diag(A)[t] * M[t][n] * h0[t][n]
+            h1 = h1 * mct;                                                                  // M[t][n] * h1[t][n]
+            g_out = bg;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) g_out = GATOR_MFMA(h1[r], aoff[r], g_out);  // sum_j (M.h1)[j][n] * Aoff[t][j]
+            for (int r = 0; r < 16; ++r) g_out = GATOR_MFMA(h1[r], aoff[r], g_out);      // sum_j (M.h1)[j][n] * Aoff[t][j]
 #pragma unroll
-                for (int r = 0; r < 16; ++r) g_out = GATOR_MFMA(h0[r], ident[r], g_out); // C-layout -> T-layout of the diagonal term
-            }
-        }
-        __syncthreads();
-        {   // proj + (attention + MGCN) sum  -> SB
-            const f32x16 acc = lin4_lds(w.proj, wave * 4, AT, lane, load_chanvec_T(w.proj_b, 32 * wave, h));
+            for (int r = 0; r < 16; ++r) g_out = GATOR_MFMA(h0[r], ident[r], g_out);     // C-layout -> T-layout of the diagonal term
+            GAT_STAMP(17)
+            __syncthreads();
+            GAT_STAMP(2)
+            // proj + (attention + MGCN) sum  -> SB
+            const f32x16 acc = lin4l(G1, AT, lane, bp);
+            G1 = ldg4(w.back, wave * 5, lane);
+            GATOR_PIN();
             store_block(SB + wave * kTile, lane, acc + g_out);
         }
+        // small operands of the X_Feat phase, requested before the barrier
+        const WTile wl1 = load_wtile(w.lin1, wave, lane), wb4 = load_wtile(w.back, wave * 5 + 4, lane);
+        const f32x16 m1 = load_block(a.m1T, lane), m2 = load_block(a.m2T, lane), f1bias = load_block(w.f1b, lane);
+        const float b0 = V[V_LIN0B + 32 * wave + (lane & 31)];
+        const f32x16 bback = load_chanvec_L(V, V_BACKB + 32 * wave, h);
+        GATOR_PIN();
         __syncthreads();
+        GAT_STAMP(3)
         {   // ---- X_Feat (modules.py:158-177) ----
             f32x16 s[4];
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) s[kb] = load_block(SB + kb * kTile, lane);
-            const f32x16 u0 = lin4<true>(w.lin0, wave * 4, s, lane, zero16());
-            const float b0 = w.lin0_b[32 * wave + (lane & 31)];
-            const f32x16 m1 = load_block(a.m1T, lane), m2 = load_block(a.m2T, lane);
+            const f32x16 u0 = lin4r<true>(G0, s, zero16());
+            G0 = ldg4(w.fc1, (4 * wave + 0) * 4, lane);
+            GATOR_PIN();
             f32x16 f0 = zero16();
 #pragma unroll
             for (int r = 0; r < 16; ++r) f0 = GATOR_MFMA(u0[r] + b0, m1[r], f0);           // hop<=1 aggregation
             store_block(FB + wave * kTile, lane, f0);
             // linears[1] (128->16): this wave contributes k-block `wave`; partial hop-2 aggregation, summed by the reader
-            f32x16 u1 = mma_C(load_wtile(w.lin1, wave, lane), s[wave], zero16());
+            const f32x16 u1 = mma_C(wl1, load_block(SB + wave * kTile, lane), zero16());   // (s[wave] would index registers dynamically)
             f32x16 f1 = zero16();
 #pragma unroll
             for (int r = 0; r < 16; ++r) f1 = GATOR_MFMA(u1[r], m2[r], f1);
             store_block(F1P + wave * kTile, lane, f1);
         }
         __syncthreads();
+        GAT_STAMP(4)
         {   // linearback(144->128) + residual
-            f32x16 acc = lin4_lds(w.back, wave * 5, FB, lane, load_chanvec_T(w.back_b, 32 * wave, h));
-            f32x16 f1 = load_block(w.f1b, lane);                                            // rowsum(m2)[t] * linears[1].bias[n]
+            f32x16 acc = lin4l(G1, FB, lane, bback);
+            G1 = ldg4(w.fc1, (4 * wave + 1) * 4, lane);
+            GATOR_PIN();
+            f32x16 f1 = f1bias;                                                             // rowsum(m2)[t] * linears[1].bias[n]
 #pragma unroll
             for (int q = 0; q < 4; ++q) f1 += load_block(F1P + q * kTile, lane);
-            const WTile wt = load_wtile(w.back, wave * 5 + 4, lane);
 #pragma unroll
             for (int g = 0; g < 2; ++g)                                                     // channels 128..143 only (r < 8)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = GATOR_MFMA(wt.g[g][j], f1[4 * g + j], acc);
+                for (int j = 0; j < 4; ++j) acc = GATOR_MFMA(wb4.g[g][j], f1[4 * g + j], acc);
             xw += acc;
             store_block(X + wave * kTile, lane, xw);
         }
         __syncthreads();
+        GAT_STAMP(5)
         {   // ---- MLP (modules.py:188-196): fc1 + GELU -> HB (16 tiles), fc2 + residual ----
             f32x16 y2[4];
-            layernorm128<false>(X, w.n2w, w.n2b, lane, y2);
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-                const int nb = 4 * wave + q;
-                f32x16 hd = lin4<false>(w.fc1, nb * 4, y2, lane, load_chanvec_T(w.fc1_b, 32 * nb, h));
+            layernorm128<false>(X, V + V_N2W, V + V_N2B, lane, y2);
+            f32x16 hd = lin4r<false>(G0, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 0), h));
+            G0 = ldg4(w.fc1, (4 * wave + 2) * 4, lane);
+            GATOR_PIN();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
-                store_block(HB + nb * kTile, lane, hd);
-            }
+            for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
+            store_block(HB + (4 * wave + 0) * kTile, lane, hd);
+            hd = lin4r<false>(G1, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 1), h));
+            G1 = ldg4(w.fc1, (4 * wave + 3) * 4, lane);
+            GATOR_PIN();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
+            store_block(HB + (4 * wave + 1) * kTile, lane, hd);
+            hd = lin4r<false>(G0, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 2), h));
+            G0 = ldg4(w.fc2, wave * 16 + 0, lane);
+            GATOR_PIN();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
+            store_block(HB + (4 * wave + 2) * kTile, lane, hd);
+            hd = lin4r<false>(G1, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 3), h));
+            G1 = ldg4(w.fc2, wave * 16 + 4, lane);
+            GATOR_PIN();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
+            store_block(HB + (4 * wave + 3) * kTile, lane, hd);
         }
+        const f32x16 bfc2 = load_chanvec_L(V, V_FC2B + 32 * wave, h);
+        GAT_STAMP(6)
         __syncthreads();
-        {
-            f32x16 acc0 = load_chanvec_T(w.fc2_b, 32 * wave, h), acc1 = zero16(), acc2 = zero16(), acc3 = zero16();   // 4 chains x 128
-#pragma unroll 1
-            for (int kb = 0; kb < 16; kb += 4) {
-                acc0 = mma_T(load_wtile(w.fc2, wave * 16 + kb, lane), load_block(HB + kb * kTile, lane), acc0);
-                acc1 = mma_T(load_wtile(w.fc2, wave * 16 + kb + 1, lane), load_block(HB + (kb + 1) * kTile, lane), acc1);
-                acc2 = mma_T(load_wtile(w.fc2, wave * 16 + kb + 2, lane), load_block(HB + (kb + 2) * kTile, lane), acc2);
-                acc3 = mma_T(load_wtile(w.fc2, wave * 16 + kb + 3, lane), load_block(HB + (kb + 3) * kTile, lane), acc3);
-            }
-            xw += (acc0 + acc1) + (acc2 + acc3);
+        GAT_STAMP(7)
+        reinterpret_cast<f32x4*>(V)[t] = vn0;          // every read of this block's vectors happened before the barrier above
+        reinterpret_cast<f32x4*>(V)[256 + t] = vn1;
+        {   // fc2: four independent 128-product chains (one per group of 4 hidden blocks)
+            const f32x16 c0 = lin4l(G0, HB + 0 * kTile, lane, bfc2);
+            G0 = ldg4(w.fc2, wave * 16 + 8, lane);
+            GATOR_PIN();
+            const f32x16 c1 = lin4l(G1, HB + 4 * kTile, lane, zero16());
+            G1 = ldg4(w.fc2, wave * 16 + 12, lane);
+            GATOR_PIN();
+            const f32x16 c2 = lin4l(G0, HB + 8 * kTile, lane, zero16());
+            G0 = ldg4(wn.qkv, wave * 4, lane);                      // next block's q / k groups
+            GATOR_PIN();
+            const f32x16 c3 = lin4l(G1, HB + 12 * kTile, lane, zero16());
+            G1 = ldg4(wn.qkv, (4 + wave) * 4, lane);
+            GATOR_PIN();
+            xw += (c0 + c1) + (c2 + c3);
             store_block(X + wave * kTile, lane, xw);     // every wave finished reading X (LN2) before the HB barrier
         }
         __syncthreads();
+        GAT_STAMP(8)
     }
     // ---------------- tail: LN -> GELU -> feat ; lifter Linear(128J -> 3J)  (GAT.py:148-152)
-    f32x16 ft[4];
-    layernorm128<true>(X, a.norm_w, a.norm_b, lane, ft);
-    const int tok = lane & 31;
-    if (tok < J) {
+    {
+        f32x16 x[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v4;
+        for (int kb = 0; kb < 4; ++kb) x[kb] = load_block(X + kb * kTile, lane);
+        const float mean = row_sum128(x) * (1.0f / 128.0f);
+        f32x16 sq[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v4[j] = ft[wave][4 * g + j];
-            *reinterpret_cast<f32x4*>(a.feat + ((size_t)b * J + tok) * kC + 32 * wave + 8 * g + 4 * h) = v4;
+        for (int kb = 0; kb < 4; ++kb) { x[kb] = x[kb] - mean; sq[kb] = x[kb] * x[kb]; }
+        const float rstd = 1.0f / sqrtf(row_sum128(sq) * (1.0f / 128.0f) + 1e-5f);
+        f32x16 mine = (xw - mean) * rstd * load_chanvec_S(a.norm_w, 32 * wave, h) + load_chanvec_S(a.norm_b, 32 * wave, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[r] = gelu_f(mine[r]);      // each wave finishes only its own channel block
+        store_block(R + wave * kTile, lane, mine);
+        const int tok = lane & 31;
+        if (tok < J) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v4[j] = mine[4 * g + j];
+                *reinterpret_cast<f32x4*>(a.feat + ((size_t)b * J + tok) * kC + 32 * wave + 8 * g + 4 * h) = v4;
+            }
         }
     }
+    f32x16 wl[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) wl[kb] = load_block(a.lifter_p + ((size_t)wave * 4 + kb) * kTile, lane);
+    __syncthreads();
+    f32x16 ft[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) ft[kb] = load_block(R + kb * kTile, lane);
     for (int o = wave; o < 3 * J; o += 4) {
+        const int on = o + 4 < 3 * J ? o + 4 : o;                     // prefetch the next output's weight tiles
+        f32x16 nx[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) nx[kb] = load_block(a.lifter_p + ((size_t)on * 4 + kb) * kTile, lane);
+        GATOR_PIN();
         float s = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const f32x16 wl = load_block(a.lifter_p + ((size_t)o * 4 + kb) * kTile, lane);
             float p = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p += ft[kb][r] * wl[r];
+            for (int r = 0; r < 16; ++r) p += ft[kb][r] * wl[kb][r];
             s += p;
         }
         for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
         if (lane == 0) a.x_out[(size_t)b * 3 * J + o] = s + a.lifter_b[o];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) wl[kb] = nx[kb];
     }
+    GAT_STAMP(9)
+    if (a.stamps && b == 0 && t == 0)
+        for (int i = 0; i < 20; ++i) a.stamps[i] = st_acc[i];
 }
 
 }  // namespace
@@ -313,7 +455,7 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
     GatArgs a;
     const Weights& w = c->w;
     a.B = B; a.J = c->J; a.pose2d = pose2d;
-    a.gl0_W = w.gl0_W; a.gl0_b = w.gl0_b; a.gn_w = w.gn_w; a.gn_b = w.gn_b; a.gl3_W = w.gl3_W; a.gl3_b = w.gl3_b; a.pos = c->pos_embed;
+    a.gl0_W = w.gl0_W; a.gl0_b = w.gl0_b; a.gn_w = w.gn_w; a.gn_b = w.gn_b; a.gl3_p = f->g_gl3; a.gl3_b = w.gl3_b; a.posT = f->g_posT;
     a.biasT = f->g_biasT; a.m1T = f->g_m1T; a.m2T = f->g_m2T;
     a.norm_w = w.norm_w; a.norm_b = w.norm_b; a.lifter_p = f->g_lifter; a.lifter_b = w.lifter_b;
     for (int i = 0; i < kDepth; ++i) {
@@ -322,11 +464,18 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         GatBlockP& q = a.blk[i];
         q.qkv = p.qkv; q.proj = p.proj; q.w0 = p.w0; q.w1 = p.w1; q.lin0 = p.lin0; q.lin1 = p.lin1; q.back = p.back; q.fc1 = p.fc1; q.fc2 = p.fc2;
         q.mc = p.mc; q.md = p.md; q.aoffT = p.aoffT; q.f1b = p.f1b;
-        q.n1w = r.n1w; q.n1b = r.n1b; q.qkv_b = r.qkv_b; q.proj_b = r.proj_b; q.gcn_b = r.gcn_bias; q.lin0_b = r.xl0_b; q.back_b = r.xlb_b;
-        q.n2w = r.n2w; q.n2b = r.n2b; q.fc1_b = r.fc1_b; q.fc2_b = r.fc2_b;
+        q.vecs = f->g_vecs + (size_t)i * 2048;
+        (void)r;
     }
     a.x_out = x_out; a.feat = feat;
-    constexpr size_t kLds = 20 * kTile * sizeof(float);     // 80 KB: two workgroups per CU
+    a.stamps = nullptr;
+    static const bool want_stamps = getenv("GATOR_GAT_STAMPS") != nullptr;
+    unsigned long long* d_st = nullptr;
+    if (want_stamps) {
+        GATOR_HIP_CHECK(hipMalloc(&d_st, 20 * sizeof(unsigned long long)));
+        a.stamps = d_st;
+    }
+    constexpr size_t kLds = (20 * kTile + 2048) * sizeof(float);     // 88 KB
     static bool attr = false;
     if (!attr) {
         GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
@@ -334,6 +483,20 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
     }
     k_gat<<<B, 256, kLds, (hipStream_t)stream>>>(a);
     GATOR_HIP_CHECK(hipGetLastError());
+    if (d_st) {     // diagnostic build path: synchronous read-back, never used in timed runs
+        unsigned long long hst[20];
+        GATOR_HIP_CHECK(hipMemcpy(hst, d_st, sizeof(hst), hipMemcpyDeviceToHost));
+        GATOR_HIP_CHECK(hipFree(d_st));
+        static const char* nm[10] = {"embed", "ln1+qkv+attn+mgcn", "barrier1", "proj+prefetch+barrier2", "xfeat+barrier3",
+                                     "back+barrier4", "ln2+fc1+gelu", "barrier5", "fc2+barrier6", "tail"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 10; ++i) tot += hst[i];
+        hst[1] += hst[10] + hst[11] + hst[12] + hst[13] + hst[14] + hst[15] + hst[16] + hst[17];
+        fprintf(stderr, "[k_gat stamps, wg0 wave0, B=%d] total %llu cycles:", B, tot);
+        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%llu", nm[i], hst[i]);
+        fprintf(stderr, " | phase1 detail: ln1=%llu q=%llu k=%llu v=%llu attn=%llu h0=%llu h1=%llu mgcn=%llu", hst[10], hst[11], hst[12], hst[13], hst[14], hst[15], hst[16], hst[17]);
+        fprintf(stderr, "\n");
+    }
     return GATOR_OK;
 }
 

@@ -56,8 +56,8 @@ __device__ __forceinline__ void layernorm64(const f32x16 (&x)[2], const float* _
     f32x16 d0 = x[0] - mean, d1 = x[1] - mean;
     const float var = row_sum64(d0 * d0, d1 * d1) * (1.0f / 64.0f);
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    y[0] = d0 * rstd * load_chanvec_T(w, 0, h) + load_chanvec_T(b, 0, h);
-    y[1] = d1 * rstd * load_chanvec_T(w, 32, h) + load_chanvec_T(b, 32, h);
+    y[0] = d0 * rstd * load_chanvec_S(w, 0, h) + load_chanvec_S(b, 0, h);
+    y[1] = d1 * rstd * load_chanvec_S(w, 32, h) + load_chanvec_S(b, 32, h);
 }
 
 // Annotated-Transformer LayerNorm: a_2 * (x - mean) / (std_unbiased + 1e-6) + b_2
@@ -66,8 +66,8 @@ __device__ __forceinline__ void custom_ln64(f32x16 (&x)[2], const float* __restr
     f32x16 d0 = x[0] - mean, d1 = x[1] - mean;
     const float std = sqrtf(row_sum64(d0 * d0, d1 * d1) * (1.0f / 63.0f));
     const float inv = 1.0f / (std + 1e-6f);
-    x[0] = load_chanvec_T(a2, 0, h) * d0 * inv + load_chanvec_T(b2, 0, h);
-    x[1] = load_chanvec_T(a2, 32, h) * d1 * inv + load_chanvec_T(b2, 32, h);
+    x[0] = load_chanvec_S(a2, 0, h) * d0 * inv + load_chanvec_S(b2, 0, h);
+    x[1] = load_chanvec_S(a2, 32, h) * d1 * inv + load_chanvec_S(b2, 32, h);
 }
 
 // y(T-layout, 64 ch) = W[64][64] x (+bias)
@@ -76,7 +76,7 @@ __device__ __forceinline__ void linear64_T(const float* __restrict__ Wp, const f
     const int h = lane >> 5;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {   // one 32-term chain per k-block, then one add: halves the fp32 chain length
-        const f32x16 a0 = mma_T(load_wtile(Wp, nb * 2 + 0, lane), x[0], bias ? load_chanvec_T(bias, 32 * nb, h) : zero16());
+        const f32x16 a0 = mma_T(load_wtile(Wp, nb * 2 + 0, lane), x[0], bias ? load_chanvec_S(bias, 32 * nb, h) : zero16());
         const f32x16 a1 = mma_T(load_wtile(Wp, nb * 2 + 1, lane), x[1], zero16());
         y[nb] = a0 + a1;
     }
@@ -193,9 +193,9 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             f32x16 v = load_block(a.tok_base + ((size_t)t * 2 + nb) * kTile, lane);
-            v += load_chanvec_T(a.tok_w3, 32 * nb, h) * x0;
-            v += load_chanvec_T(a.tok_w3 + 64, 32 * nb, h) * x1;
-            v += load_chanvec_T(a.tok_w3 + 128, 32 * nb, h) * x2;
+            v += load_chanvec_S(a.tok_w3, 32 * nb, h) * x0;
+            v += load_chanvec_S(a.tok_w3 + 64, 32 * nb, h) * x1;
+            v += load_chanvec_S(a.tok_w3 + 128, 32 * nb, h) * x2;
             vf[nb] = v;
         }
     } else {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
                     *reinterpret_cast<f32x4*>(a.lbf + ((size_t)b * kV + token) * kE + 32 * nb + 8 * g + 4 * h) = v4;
                 }
         }
-        f32x16 acc = load_chanvec_T(a.head_b, 0, h);
+        f32x16 acc = load_chanvec_S(a.head_b, 0, h);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) acc = mma_T(load_wtile(a.head_w, kb, lane), vf[kb], acc);
         if (token < kV) {
@@ -252,13 +252,13 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
     {
         f32x16 y2[2], acc2[2][2];
         layernorm64(vf, w.n2w, w.n2b, h, y2);
-        acc2[0][0] = load_chanvec_T(w.fc2_b, 0, h);
-        acc2[1][0] = load_chanvec_T(w.fc2_b, 32, h);
+        acc2[0][0] = load_chanvec_S(w.fc2_b, 0, h);
+        acc2[1][0] = load_chanvec_S(w.fc2_b, 32, h);
         acc2[0][1] = zero16();
         acc2[1][1] = zero16();
 #pragma unroll 2
         for (int c = 0; c < 8; ++c) {           // 256 hidden units in 8 chunks of 32: fc1 -> GELU -> fc2 partial
-            f32x16 hdn = mma_T(load_wtile(w.fc1, c * 2 + 0, lane), y2[0], load_chanvec_T(w.fc1_b, 32 * c, h));
+            f32x16 hdn = mma_T(load_wtile(w.fc1, c * 2 + 0, lane), y2[0], load_chanvec_S(w.fc1_b, 32 * c, h));
             hdn += mma_T(load_wtile(w.fc1, c * 2 + 1, lane), y2[1], zero16());
 #pragma unroll
             for (int r = 0; r < 16; ++r) hdn[r] = gelu_f(hdn[r]);
@@ -308,7 +308,8 @@ struct JointArgs {
 __global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
     __shared__ __attribute__((aligned(16))) float PCt[5 * kTile];
     __shared__ __attribute__((aligned(16))) float JF[2 * kTile];
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, J = a.J;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     for (int e = t; e < 5 * kTile; e += 128) {
         const int j4 = e & 3, ln = (e >> 2) & 63, g = (e >> 8) & 3, kb = e >> 10;
         const int tok = ln & 31, k = 32 * kb + 8 * g + 4 * (ln >> 5) + j4;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
     }
     __syncthreads();
     {
-        f32x16 a0 = load_chanvec_T(a.jb, 32 * wave, h) + load_block(a.posj_T + wave * kTile, lane), a1 = zero16();
+        f32x16 a0 = load_chanvec_S(a.jb, 32 * wave, h) + load_block(a.posj_T + wave * kTile, lane), a1 = zero16();
 #pragma unroll
         for (int kb = 0; kb < 5; ++kb) {
             if (kb & 1) a1 = mma_T(load_wtile(a.jw_p, wave * 5 + kb, lane), load_block(PCt + kb * kTile, lane), a1);
