@@ -18,6 +18,8 @@
 #include "fused_common.h"
 #include "fused_state.h"
 
+#include <cstdlib>
+
 namespace gator {
 namespace {
 
@@ -39,6 +41,7 @@ struct MdrArgs {
     const float *head_w, *head_b;
     float *hf, *lbf;
     LayerW prev, cur;        // prev: layer whose attention/out-proj runs first; cur: layer whose tokenwise part runs
+    unsigned long long* stamps;   // diagnostic only (GATOR_MDR_STAMPS=1)
 };
 
 // ---- row-wise helpers over the 64 channels (2 blocks) of a token (lane pair l, l^32) -------------------------------
@@ -82,62 +85,82 @@ __device__ __forceinline__ void linear64_T(const float* __restrict__ Wp, const f
     }
 }
 
+#define MDR_PIN()                            \
+    do {                                     \
+        asm volatile("" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+// one 32-key tile of the flash attention: scores, online softmax, P.V into accumulator OACC
+#define ATTN_TILE(KT, KB, VB, OACC)                                                                         \
+    {                                                                                                       \
+        f32x16 S = zero16();                                                                                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) S = GATOR_MFMA(KB[r], qv[r], S);  /* S^T[key][query] */ \
+        float bm = -1e30f;                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+            float sc = S[r] * c;                                                                            \
+            if ((KT) == kVT - 1 && kap(r) + 4 * h >= kV - 32 * (kVT - 1)) sc = -1e30f; /* keys 431..447 do not exist */ \
+            S[r] = sc;                                                                                      \
+            bm = fmaxf(bm, sc);                                                                             \
+        }                                                                                                   \
+        bm = fmaxf(bm, xhalf(bm));                                                                          \
+        if (!__all(bm <= m + 8.0f)) { /* lazy rescale (wave-uniform): P stays <= 2^8, exact in fp32 */      \
+            const float mn = fmaxf(m, bm);                                                                  \
+            const float al = __builtin_amdgcn_exp2f(m - mn);                                                \
+            O = O * al;                                                                                     \
+            O2 = O2 * al;                                                                                   \
+            O3 = O3 * al;                                                                                   \
+            O4 = O4 * al;                                                                                   \
+            l *= al;                                                                                        \
+            m = mn;                                                                                         \
+        }                                                                                                   \
+        float ps = 0.f;                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+            const float pe = __builtin_amdgcn_exp2f(S[r] - m);                                              \
+            S[r] = pe;                                                                                      \
+            ps += pe;                                                                                       \
+        }                                                                                                   \
+        l += ps;                                                                                            \
+        /* O^T[d][query] += V^T[d][key] P^T[key][query] */                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) OACC = GATOR_MFMA(VB[r], S[r], OACC);                \
+    }
+
 // ---- flash attention of one 32-query tile against the 431 keys of its sample, one head --------------------------------
+// Key tile kt accumulates into chain kt&3 (four fp32 chains of ~110 products).  (Explicit K/V double buffering was measured:
+// no gain -- the co-resident wave already covers the tile loads -- and it costs 32 VGPRs.)
 __device__ __forceinline__ f32x16 self_attention_head(const float* __restrict__ qt, const float* __restrict__ kbase,
                                                       const float* __restrict__ vbase, int lane) {
     const int h = lane >> 5;
     const f32x16 qv = load_block(qt, lane);
-    f32x16 O = zero16(), O2 = zero16(), O3 = zero16(), O4 = zero16();   // key tile kt -> chain kt&3: four chains of ~110 products
+    f32x16 O = zero16(), O2 = zero16(), O3 = zero16(), O4 = zero16();
     float m = -1e30f, l = 0.f;
     const float c = kLog2e * 0.17677669529663688110f;      // log2(e) / sqrt(d_k): scores kept in the exp2 domain
-#pragma unroll 4
-    for (int kt = 0; kt < kVT; ++kt) {
-        const f32x16 kb = load_block(kbase + (size_t)kt * 2 * kTile, lane);
-        const f32x16 vb = load_block(vbase + (size_t)kt * 2 * kTile, lane);
-        f32x16 S = zero16();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S = GATOR_MFMA(kb[r], qv[r], S);      // S^T[key][query]
-        float bm = -1e30f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float s = S[r] * c;
-            if (kt == kVT - 1 && kap(r) + 4 * h >= kV - 32 * (kVT - 1)) s = -1e30f;   // keys 431..447 do not exist
-            S[r] = s;
-            bm = fmaxf(bm, s);
+#pragma unroll 1
+    for (int kt = 0; kt < kVT - 2; kt += 4) {               // 12 tiles in 3 trips of 4 (chain kt&3), then the last two
+        {
+            const f32x16 kb = load_block(kbase + (size_t)kt * 2 * kTile, lane), vb = load_block(vbase + (size_t)kt * 2 * kTile, lane);
+            ATTN_TILE(kt, kb, vb, O)
         }
-        bm = fmaxf(bm, xhalf(bm));
-        if (!__all(bm <= m + 8.0f)) {            // lazy rescale (wave-uniform): P stays <= 2^8, exact in fp32
-            const float mn = fmaxf(m, bm);
-            const float al = __builtin_amdgcn_exp2f(m - mn);
-            O = O * al;
-            O2 = O2 * al;
-            O3 = O3 * al;
-            O4 = O4 * al;
-            l *= al;
-            m = mn;
+        {
+            const f32x16 kb = load_block(kbase + (size_t)(kt + 1) * 2 * kTile, lane), vb = load_block(vbase + (size_t)(kt + 1) * 2 * kTile, lane);
+            ATTN_TILE(kt + 1, kb, vb, O2)
         }
-        float ps = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(S[r] - m);
-            S[r] = p;
-            ps += p;
+        {
+            const f32x16 kb = load_block(kbase + (size_t)(kt + 2) * 2 * kTile, lane), vb = load_block(vbase + (size_t)(kt + 2) * 2 * kTile, lane);
+            ATTN_TILE(kt + 2, kb, vb, O3)
         }
-        l += ps;
-        // O^T[d][query] += V^T[d][key] P^T[key][query]
-        if ((kt & 3) == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O = GATOR_MFMA(vb[r], S[r], O);
-        } else if ((kt & 3) == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O2 = GATOR_MFMA(vb[r], S[r], O2);
-        } else if ((kt & 3) == 2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O3 = GATOR_MFMA(vb[r], S[r], O3);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O4 = GATOR_MFMA(vb[r], S[r], O4);
+        {
+            const f32x16 kb = load_block(kbase + (size_t)(kt + 3) * 2 * kTile, lane), vb = load_block(vbase + (size_t)(kt + 3) * 2 * kTile, lane);
+            ATTN_TILE(kt + 3, kb, vb, O4)
         }
+    }
+    {
+        const f32x16 kb = load_block(kbase + (size_t)(kVT - 2) * 2 * kTile, lane), vb = load_block(vbase + (size_t)(kVT - 2) * 2 * kTile, lane);
+        ATTN_TILE(kVT - 2, kb, vb, O)
+    }
+    {
+        const f32x16 kb = load_block(kbase + (size_t)(kVT - 1) * 2 * kTile, lane), vb = load_block(vbase + (size_t)(kVT - 1) * 2 * kTile, lane);
+        ATTN_TILE(kVT - 1, kb, vb, O2)
     }
     l += xhalf(l);
     return ((O + O2) + (O3 + O4)) * (1.0f / l);
@@ -176,16 +199,46 @@ __device__ __forceinline__ f32x16 cross_attention_head(const float* __restrict__
     return O;
 }
 
+// ---- weight stream of the tokenwise part: two buffers of one tile pair each (2 x 32 VGPRs).  The pair for the NEXT
+// product is requested right after the current product's MFMAs are queued, so its L2 latency hides behind them and
+// behind the co-resident wave.  MDR_PIN keeps the order (memory ops and scheduler).
+struct W2 { WTile t[2]; };
+__device__ __forceinline__ W2 ldw2(const float* __restrict__ Wp, int i0, int i1, int lane) {
+    W2 w;
+    w.t[0] = load_wtile(Wp, i0, lane);
+    w.t[1] = load_wtile(Wp, i1, lane);
+    return w;
+}
+// 64-term contraction as two independent 32-term chains (one per k-block)
+__device__ __forceinline__ f32x16 lin2_T(const W2& w, const f32x16 (&x)[2], f32x16 init) {
+    return mma_T(w.t[0], x[0], init) + mma_T(w.t[1], x[1], zero16());
+}
+__device__ __forceinline__ f32x16 lin2_C(const W2& w, const f32x16 (&x)[2]) {
+    return mma_C(w.t[0], x[0], zero16()) + mma_C(w.t[1], x[1], zero16());
+}
+
 template <int MODE>   // 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
 __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int id = xcd_remap(blockIdx.x, nwg) * 4 + wave;
     if (id >= a.B * kVT) return;
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = a.stamps ? clock64() : 0;
+#define MDR_STAMP(i)                                      \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    if (a.stamps) {                                       \
+        const unsigned long long now_ = clock64();        \
+        st_acc[i] += now_ - st_last;                      \
+        st_last = now_;                                   \
+    }
     const int b = id / kVT, t = id % kVT;
     const size_t tile = ((size_t)b * kVT + t) * 2;          // index of this wave's first block in vf/q/k/v
     const int token = 32 * t + (lane & 31);
+    const LayerW& w = a.cur;
     f32x16 vf[2];
+    W2 A, B;
     if (MODE == 0) {
+        A = ldw2(w.wq, 0, 1, lane);
+        B = ldw2(w.wq, 2, 3, lane);
         // verts tokens = Linear(6->64)([v431, pose3d[vj]/1000]) + pos_v   (MDR.py:126-137); the v431/bias/pos part is folded
         const int tk = token < kV ? token : kV - 1;
         const float* p3 = a.pc + ((size_t)b * a.J + a.vj[tk]) * 133 + 2;
@@ -200,14 +253,25 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         }
     } else {
         f32x16 att[2];
-#pragma unroll
-        for (int hd = 0; hd < 2; ++hd)
-            att[hd] = self_attention_head(a.q_in + (tile + hd) * kTile, a.k_in + ((size_t)b * kVT * 2 + hd) * kTile,
-                                          a.v_in + ((size_t)b * kVT * 2 + hd) * kTile, lane);
-        f32x16 y[2];
-        linear64_T(a.prev.sa3, a.prev.sa3_b, att, lane, y);                 // linears[-1], vanilla_transformer_encoder.py:94
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) vf[nb] = load_block(a.vf_in + (tile + nb) * kTile, lane) + y[nb];   // MDR.py:143
+        att[0] = self_attention_head(a.q_in + (tile + 0) * kTile, a.k_in + ((size_t)b * kVT * 2 + 0) * kTile,
+                                     a.v_in + ((size_t)b * kVT * 2 + 0) * kTile, lane);
+        att[1] = self_attention_head(a.q_in + (tile + 1) * kTile, a.k_in + ((size_t)b * kVT * 2 + 1) * kTile,
+                                     a.v_in + ((size_t)b * kVT * 2 + 1) * kTile, lane);
+        A = ldw2(a.prev.sa3, 0, 1, lane);
+        B = ldw2(a.prev.sa3, 2, 3, lane);
+        vf[0] = load_block(a.vf_in + (tile + 0) * kTile, lane);
+        vf[1] = load_block(a.vf_in + (tile + 1) * kTile, lane);
+        MDR_PIN();
+        MDR_STAMP(0)
+        // linears[-1] + residual (vanilla_transformer_encoder.py:94, MDR.py:143)
+        const f32x16 y0 = lin2_T(A, att, load_chanvec_S(a.prev.sa3_b, 0, h));
+        if (MODE == 1) A = ldw2(w.wq, 0, 1, lane); else A = ldw2(a.head_w, 0, 1, lane);
+        MDR_PIN();
+        const f32x16 y1 = lin2_T(B, att, load_chanvec_S(a.prev.sa3_b, 32, h));
+        if (MODE == 1) B = ldw2(w.wq, 2, 3, lane);
+        MDR_PIN();
+        vf[0] += y0;
+        vf[1] += y1;
     }
     if (MODE == 2) {
         if (token < kV) {
@@ -221,9 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
                     *reinterpret_cast<f32x4*>(a.lbf + ((size_t)b * kV + token) * kE + 32 * nb + 8 * g + 4 * h) = v4;
                 }
         }
-        f32x16 acc = load_chanvec_S(a.head_b, 0, h);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) acc = mma_T(load_wtile(a.head_w, kb, lane), vf[kb], acc);
+        const f32x16 acc = mma_T(A.t[1], vf[1], mma_T(A.t[0], vf[0], load_chanvec_S(a.head_b, 0, h)));
         if (token < kV) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -235,20 +297,30 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         }
         return;
     }
-    const LayerW& w = a.cur;
+    MDR_STAMP(1)
     // ---- CrossAttentionBlock (MDR.py:64-69) ----
     {
         f32x16 fz[2], q[2], o[2];
         layernorm64(vf, w.n1w, w.n1b, h, fz);
-        linear64_T(w.wq, nullptr, fz, lane, q);
         const float* jb = a.jkv + (((size_t)b * 3 + a.layer) * 4) * kTile;       // [k/v][head] tiles
+        q[0] = lin2_T(A, fz, zero16());
+        A = ldw2(w.proj, 0, 1, lane);
+        MDR_PIN();
+        q[1] = lin2_T(B, fz, zero16());
+        B = ldw2(w.proj, 2, 3, lane);
+        MDR_PIN();
 #pragma unroll
         for (int hd = 0; hd < 2; ++hd) o[hd] = cross_attention_head(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], a.J, lane);
-        f32x16 y[2];
-        linear64_T(w.proj, w.proj_b, o, lane, y);
-        vf[0] += y[0];
-        vf[1] += y[1];
+        const f32x16 y0 = lin2_T(A, o, load_chanvec_S(w.proj_b, 0, h));
+        A = ldw2(w.fc1, 0, 1, lane);                                            // MLP chunk 0: fc1 rows 0..31
+        MDR_PIN();
+        const f32x16 y1 = lin2_T(B, o, load_chanvec_S(w.proj_b, 32, h));
+        B = ldw2(w.fc2, 0, 8, lane);                                            //              fc2 columns 0..31, both row blocks
+        MDR_PIN();
+        vf[0] += y0;
+        vf[1] += y1;
     }
+    MDR_STAMP(2)
     {
         f32x16 y2[2], acc2[2][2];
         layernorm64(vf, w.n2w, w.n2b, h, y2);
@@ -256,42 +328,59 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         acc2[1][0] = load_chanvec_S(w.fc2_b, 32, h);
         acc2[0][1] = zero16();
         acc2[1][1] = zero16();
-#pragma unroll 2
+#pragma unroll
         for (int c = 0; c < 8; ++c) {           // 256 hidden units in 8 chunks of 32: fc1 -> GELU -> fc2 partial
-            f32x16 hdn = mma_T(load_wtile(w.fc1, c * 2 + 0, lane), y2[0], load_chanvec_S(w.fc1_b, 32 * c, h));
-            hdn += mma_T(load_wtile(w.fc1, c * 2 + 1, lane), y2[1], zero16());
+            f32x16 hdn = lin2_T(A, y2, load_chanvec_S(w.fc1_b, 32 * c, h));
+            if (c < 7) A = ldw2(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw2(w.sa0, 0, 1, lane);
+            MDR_PIN();
 #pragma unroll
             for (int r = 0; r < 16; ++r) hdn[r] = gelu_f(hdn[r]);
-            acc2[0][c & 1] = mma_T(load_wtile(w.fc2, 0 * 8 + c, lane), hdn, acc2[0][c & 1]);   // even / odd chunks:
-            acc2[1][c & 1] = mma_T(load_wtile(w.fc2, 1 * 8 + c, lane), hdn, acc2[1][c & 1]);   // 2 chains of 128 products
+            acc2[0][c & 1] = mma_T(B.t[0], hdn, acc2[0][c & 1]);   // even / odd chunks: 2 chains of 128 products
+            acc2[1][c & 1] = mma_T(B.t[1], hdn, acc2[1][c & 1]);
+            if (c < 7) B = ldw2(w.fc2, c + 1, 8 + c + 1, lane); else B = ldw2(w.sa0, 2, 3, lane);
+            MDR_PIN();
         }
         vf[0] += acc2[0][0] + acc2[0][1];
         vf[1] += acc2[1][0] + acc2[1][1];
     }
+    MDR_STAMP(3)
     custom_ln64(vf, w.a2, w.b2, h);                                           // MDR.py:142 self.norm
     store_block(a.vf_out + (tile + 0) * kTile, lane, vf[0]);
     store_block(a.vf_out + (tile + 1) * kTile, lane, vf[1]);
     // ---- in-projections of the self-attention (vanilla_transformer_encoder.py:87-89) in the consumer's operand order ----
     {
-        f32x16 y[2];
-        linear64_T(w.sa0, w.sa0_b, vf, lane, y);
-        store_block(a.q_out + (tile + 0) * kTile, lane, y[0]);
-        store_block(a.q_out + (tile + 1) * kTile, lane, y[1]);
-        linear64_T(w.sa1, w.sa1_b, vf, lane, y);
-        if (token >= kV) { y[0] = zero16(); y[1] = zero16(); }               // pad keys: finite (they are masked anyway)
-        store_block(a.k_out + (tile + 0) * kTile, lane, y[0]);
-        store_block(a.k_out + (tile + 1) * kTile, lane, y[1]);
+        f32x16 y0 = lin2_T(A, vf, load_chanvec_S(w.sa0_b, 0, h));
+        A = ldw2(w.sa1, 0, 1, lane);
+        MDR_PIN();
+        f32x16 y1 = lin2_T(B, vf, load_chanvec_S(w.sa0_b, 32, h));
+        B = ldw2(w.sa1, 2, 3, lane);
+        MDR_PIN();
+        store_block(a.q_out + (tile + 0) * kTile, lane, y0);
+        store_block(a.q_out + (tile + 1) * kTile, lane, y1);
+        y0 = lin2_T(A, vf, load_chanvec_S(w.sa1_b, 0, h));
+        A = ldw2(w.sa2, 0, 1, lane);
+        MDR_PIN();
+        y1 = lin2_T(B, vf, load_chanvec_S(w.sa1_b, 32, h));
+        B = ldw2(w.sa2, 2, 3, lane);
+        const float bv0 = w.sa2_b[lane & 31], bv1 = w.sa2_b[32 + (lane & 31)];
+        MDR_PIN();
+        if (token >= kV) { y0 = zero16(); y1 = zero16(); }                   // pad keys: finite (they are masked anyway)
+        store_block(a.k_out + (tile + 0) * kTile, lane, y0);
+        store_block(a.k_out + (tile + 1) * kTile, lane, y1);
+        y0 = lin2_C(A, vf);                                                   // V in C-layout: channel on the lane
+        y1 = lin2_C(B, vf);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {                                       // V in C-layout: channel on the lane
-            f32x16 acc = zero16();
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) acc = mma_C(load_wtile(w.sa2, nb * 2 + kb, lane), vf[kb], acc);
-            const float bv = w.sa2_b[32 * nb + (lane & 31)];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = (32 * t + kap(r) + 4 * h < kV) ? acc[r] + bv : 0.f;
-            store_block(a.v_out + (tile + nb) * kTile, lane, acc);
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = 32 * t + kap(r) + 4 * h < kV;
+            y0[r] = ok ? y0[r] + bv0 : 0.f;
+            y1[r] = ok ? y1[r] + bv1 : 0.f;
         }
+        store_block(a.v_out + (tile + 0) * kTile, lane, y0);
+        store_block(a.v_out + (tile + 1) * kTile, lane, y1);
     }
+    MDR_STAMP(4)
+    if (a.stamps && id == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) a.stamps[i] = st_acc[i];
 }
 
 // Joint tokens: jf = Linear(133->64)(pose_combine) + pos_j (MDR.py:130-134); per layer k = wk(LN1(jf)), v = wv(LN1(jf))
@@ -461,7 +550,11 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
     a.head_w = f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = f->lbf;
     const int nwg = (B * kVT + 3) / 4;
+    static const bool want_stamps = getenv("GATOR_MDR_STAMPS") != nullptr;
+    unsigned long long* d_st = nullptr;
+    if (want_stamps) GATOR_HIP_CHECK(hipMalloc(&d_st, 8 * sizeof(unsigned long long)));
     for (int li = 0; li <= 3; ++li) {
+        a.stamps = (li == 1) ? d_st : nullptr;
         float** in = set[(li + 1) & 1];
         float** out = set[li & 1];
         a.layer = li;
@@ -473,6 +566,13 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         if (li == 0) k_mdr_layer<0><<<nwg, 256, 0, st>>>(a, nwg);
         else if (li < 3) k_mdr_layer<1><<<nwg, 256, 0, st>>>(a, nwg);
         else k_mdr_layer<2><<<nwg, 256, 0, st>>>(a, nwg);
+    }
+    if (d_st) {     // diagnostic path only
+        unsigned long long hst[8];
+        GATOR_HIP_CHECK(hipMemcpy(hst, d_st, sizeof(hst), hipMemcpyDeviceToHost));
+        GATOR_HIP_CHECK(hipFree(d_st));
+        fprintf(stderr, "[k_mdr_layer<1> stamps, tile 0] attention(2 heads)=%llu outproj+res=%llu cross-attn block=%llu mlp=%llu customLN+qkv=%llu\n",
+                hst[0], hst[1], hst[2], hst[3], hst[4]);
     }
     HeadArgs ha;
     ha.hf = f->hf; ha.bn_w = w.bn_w; ha.bn_b = w.bn_b; ha.bn_mean = w.bn_mean; ha.bn_var = w.bn_var;
