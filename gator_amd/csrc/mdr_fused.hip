@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
     const int id = xcd_remap(blockIdx.x, nwg) * 4 + wave;
     if (id >= a.B * kVT) return;
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = a.stamps ? clock64() : 0;
+    const unsigned long long rt0 = a.stamps ? wall_clock64() : 0, ck0 = st_last;
 #define MDR_STAMP(i)                                      \
     __builtin_amdgcn_sched_barrier(0);                    \
     if (a.stamps) {                                       \
@@ -381,6 +382,16 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
     MDR_STAMP(4)
     if (a.stamps && id == 0 && lane == 0)
         for (int i = 0; i < 8; ++i) a.stamps[i] = st_acc[i];
+    if (a.stamps && (id % 64) == 0 && lane == 0) {      // timeline sample: [start, end] in 100 MHz ticks, cycles, XCC id
+        unsigned long long* q = a.stamps + 8 + 4 * (id / 64);
+        q[0] = rt0;
+        q[1] = wall_clock64();
+        q[2] = clock64() - ck0;
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        q[3] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+    }
 }
 
 // Joint tokens: jf = Linear(133->64)(pose_combine) + pos_j (MDR.py:130-134); per layer k = wk(LN1(jf)), v = wv(LN1(jf))
@@ -552,7 +563,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     const int nwg = (B * kVT + 3) / 4;
     static const bool want_stamps = getenv("GATOR_MDR_STAMPS") != nullptr;
     unsigned long long* d_st = nullptr;
-    if (want_stamps) GATOR_HIP_CHECK(hipMalloc(&d_st, 8 * sizeof(unsigned long long)));
+    if (want_stamps) { GATOR_HIP_CHECK(hipMalloc(&d_st, 512 * sizeof(unsigned long long))); GATOR_HIP_CHECK(hipMemset(d_st, 0, 512 * sizeof(unsigned long long))); }
     for (int li = 0; li <= 3; ++li) {
         a.stamps = (li == 1) ? d_st : nullptr;
         float** in = set[(li + 1) & 1];
@@ -568,8 +579,16 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         else k_mdr_layer<2><<<nwg, 256, 0, st>>>(a, nwg);
     }
     if (d_st) {     // diagnostic path only
-        unsigned long long hst[8];
+        unsigned long long hst[512];
         GATOR_HIP_CHECK(hipMemcpy(hst, d_st, sizeof(hst), hipMemcpyDeviceToHost));
+        const int ns = (B * kVT + 63) / 64;
+        unsigned long long t0 = ~0ull;
+        for (int i = 0; i < ns && i < 120; ++i) if (hst[8 + 4 * i] && hst[8 + 4 * i] < t0) t0 = hst[8 + 4 * i];
+        fprintf(stderr, "[k_mdr_layer<1> timeline, every 64th tile: tile:(start_us end_us kcycles xcc cu)]");
+        for (int i = 0; i < ns && i < 120; ++i)
+            fprintf(stderr, " %d:(%.0f,%.0f,%llu,x%llu,cu%llu.se%llu)", i * 64, (hst[8 + 4 * i] - t0) / 100.0, (hst[9 + 4 * i] - t0) / 100.0,
+                    hst[10 + 4 * i] / 1000, hst[11 + 4 * i] >> 32, (hst[11 + 4 * i] >> 8) & 0xf, (hst[11 + 4 * i] >> 13) & 0x7);
+        fprintf(stderr, "\n");
         GATOR_HIP_CHECK(hipFree(d_st));
         fprintf(stderr, "[k_mdr_layer<1> stamps, tile 0] attention(2 heads)=%llu outproj+res=%llu cross-attn block=%llu mlp=%llu customLN+qkv=%llu\n",
                 hst[0], hst[1], hst[2], hst[3], hst[4]);
