@@ -61,6 +61,46 @@ __device__ __forceinline__ f32x16 mma_C(const WTile& w, const f32x16& x, f32x16 
     return acc;
 }
 
+// Two independent chains, MFMAs interleaved so that consecutive instructions never write the same accumulator: a 32x32x2
+// MFMA that reads the previous one's result does NOT issue back to back (measured ~21 extra cycles per dependent pair,
+// i.e. 75 % of the pipe on a fully dependent chain when no second wave fills the gaps).
+__device__ __forceinline__ void mma2_T(const WTile& w0, const f32x16& x0, f32x16& a0, const WTile& w1, const f32x16& x1, f32x16& a1) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a0 = GATOR_MFMA(w0.g[g][j], x0[4 * g + j], a0);
+            a1 = GATOR_MFMA(w1.g[g][j], x1[4 * g + j], a1);
+        }
+}
+__device__ __forceinline__ void mma2_C(const WTile& w0, const f32x16& x0, f32x16& a0, const WTile& w1, const f32x16& x1, f32x16& a1) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a0 = GATOR_MFMA(x0[4 * g + j], w0.g[g][j], a0);
+            a1 = GATOR_MFMA(x1[4 * g + j], w1.g[g][j], a1);
+        }
+}
+// sum_r A[r] x B[r] over the 16 registers of two operand blocks, as two interleaved 8-term chains: init + even + odd
+__device__ __forceinline__ f32x16 dot16(const f32x16& A, const f32x16& B, f32x16 init) {
+    f32x16 e = init, o = zero16();
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        e = GATOR_MFMA(A[r], B[r], e);
+        o = GATOR_MFMA(A[r + 1], B[r + 1], o);
+    }
+    return e + o;
+}
+// two independent 16-register products interleaved: a0 += A0.B0 ; a1 += A1.B1
+__device__ __forceinline__ void dot16x2(const f32x16& A0, const f32x16& B0, f32x16& a0, const f32x16& A1, const f32x16& B1, f32x16& a1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        a0 = GATOR_MFMA(A0[r], B0[r], a0);
+        a1 = GATOR_MFMA(A1[r], B1[r], a1);
+    }
+}
+
 // per-channel vector (bias / norm weight) in T-layout: v[r] = vec[base + kap(r) + 4h]
 __device__ __forceinline__ f32x16 load_chanvec_T(const float* __restrict__ vec, int base, int h) {
     f32x16 v;

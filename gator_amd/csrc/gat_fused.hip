@@ -90,6 +90,19 @@ __device__ __forceinline__ void layernorm128(const float* X, const float* w, con
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
 
+// one weight tile as B operand (C-layout output), two interleaved 8-step chains
+__device__ __forceinline__ f32x16 dot16_C(const WTile& w, const f32x16& x) {
+    f32x16 e = zero16(), o = zero16();
+#pragma unroll
+    for (int g = 0; g < 4; g += 2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e = GATOR_MFMA(x[4 * g + j], w.g[g][j], e);
+            o = GATOR_MFMA(x[4 * (g + 1) + j], w.g[g + 1][j], o);
+        }
+    return e + o;
+}
+
 struct WG4 { WTile t[4]; };     // one 4-tile weight group = 16 float4 per lane (64 VGPRs)
 __device__ __forceinline__ WG4 ldg4(const float* __restrict__ Wp, int tile0, int lane) {
     WG4 g;
@@ -102,25 +115,19 @@ template <bool CL>
 __device__ __forceinline__ f32x16 lin4r(const WG4& g, const f32x16 (&xs)[4], f32x16 init) {
     f32x16 a0 = init, a1 = zero16();
     if (CL) {
-        a0 = mma_C(g.t[0], xs[0], a0);
-        a1 = mma_C(g.t[1], xs[1], a1);
-        a0 = mma_C(g.t[2], xs[2], a0);
-        a1 = mma_C(g.t[3], xs[3], a1);
+        mma2_C(g.t[0], xs[0], a0, g.t[1], xs[1], a1);
+        mma2_C(g.t[2], xs[2], a0, g.t[3], xs[3], a1);
     } else {
-        a0 = mma_T(g.t[0], xs[0], a0);
-        a1 = mma_T(g.t[1], xs[1], a1);
-        a0 = mma_T(g.t[2], xs[2], a0);
-        a1 = mma_T(g.t[3], xs[3], a1);
+        mma2_T(g.t[0], xs[0], a0, g.t[1], xs[1], a1);
+        mma2_T(g.t[2], xs[2], a0, g.t[3], xs[3], a1);
     }
     return a0 + a1;
 }
 // same with the 4 operand tiles read from LDS (consecutive tiles at T)
 __device__ __forceinline__ f32x16 lin4l(const WG4& g, const float* T, int lane, f32x16 init) {
     f32x16 a0 = init, a1 = zero16();
-    a0 = mma_T(g.t[0], load_block(T + 0 * kTile, lane), a0);
-    a1 = mma_T(g.t[1], load_block(T + 1 * kTile, lane), a1);
-    a0 = mma_T(g.t[2], load_block(T + 2 * kTile, lane), a0);
-    a1 = mma_T(g.t[3], load_block(T + 3 * kTile, lane), a1);
+    mma2_T(g.t[0], load_block(T + 0 * kTile, lane), a0, g.t[1], load_block(T + 1 * kTile, lane), a1);
+    mma2_T(g.t[2], load_block(T + 2 * kTile, lane), a0, g.t[3], load_block(T + 3 * kTile, lane), a1);
     return a0 + a1;
 }
 
@@ -177,10 +184,10 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             reinterpret_cast<f32x4*>(V)[e] = reinterpret_cast<const f32x4*>(a.blk[0].vecs)[e];
         // GraphLinear(64->128) on the MFMA: wave w -> channel block w;  + pos_id_embed + pos_num_embed (folded T-layout tiles)
         {
-            f32x16 acc = load_chanvec_S(a.gl3_b, 32 * wave, h) + load_block(a.posT + (size_t)wave * kTile, lane);
-            acc = mma_T(load_wtile(a.gl3_p, wave * 2 + 0, lane), load_block(gt, lane), acc);
-            acc = mma_T(load_wtile(a.gl3_p, wave * 2 + 1, lane), load_block(gt + kTile, lane), acc);
-            store_block(X + wave * kTile, lane, acc);
+            f32x16 acc = load_chanvec_S(a.gl3_b, 32 * wave, h) + load_block(a.posT + (size_t)wave * kTile, lane), ac1 = zero16();
+            mma2_T(load_wtile(a.gl3_p, wave * 2 + 0, lane), load_block(gt, lane), acc, load_wtile(a.gl3_p, wave * 2 + 1, lane),
+                   load_block(gt + kTile, lane), ac1);
+            store_block(X + wave * kTile, lane, acc + ac1);
         }
         __syncthreads();
     }
@@ -231,9 +238,10 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             {
                 f32x16 sa = zero16(), sb = zero16();
 #pragma unroll
-                for (int r = 0; r < 8; ++r) sa = GATOR_MFMA(k[r], q[r], sa);            // head 2w:   channels 0..15 of the block
-#pragma unroll
-                for (int r = 8; r < 16; ++r) sb = GATOR_MFMA(k[r], q[r], sb);           // head 2w+1: channels 16..31
+                for (int r = 0; r < 8; ++r) {
+                    sa = GATOR_MFMA(k[r], q[r], sa);                                    // head 2w:   channels 0..15 of the block
+                    sb = GATOR_MFMA(k[r + 8], q[r + 8], sb);                            // head 2w+1: channels 16..31
+                }
                 float ma = -1e30f, mb = -1e30f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -257,14 +265,14 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
                 lb += xhalf(lb);
                 const float ia = 1.0f / la, ib = 1.0f / lb;
                 const bool lo = (lane & 31) < 16;
-                f32x16 O = zero16();
+                f32x16 O = zero16(), Ob = zero16();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float vv = v[r] + vb;
                     O = GATOR_MFMA(lo ? vv : 0.f, sa[r] * ia, O);                          // rows (channels) 0..15  <- head 2w
-                    O = GATOR_MFMA(lo ? 0.f : vv, sb[r] * ib, O);                          // rows 16..31            <- head 2w+1
+                    Ob = GATOR_MFMA(lo ? 0.f : vv, sb[r] * ib, Ob);                        // rows 16..31            <- head 2w+1
                 }
-                store_block(AT + wave * kTile, lane, O);
+                store_block(AT + wave * kTile, lane, O + Ob);
             }
             GAT_STAMP(14)
             // ---- MGCN (modules.py:243-255): h_k = y @ W[k]; out = diag(A)(M.h0) + offdiag(A)(M.h1) + bias ----
@@ -282,11 +290,13 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             GAT_STAMP(16)
             h0 = h0 * mdt;                                                                  // diag(A)[t] * M[t][n] * h0[t][n]
             h1 = h1 * mct;                                                                  // M[t][n] * h1[t][n]
-            g_out = bg;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g_out = GATOR_MFMA(h1[r], aoff[r], g_out);      // sum_j (M.h1)[j][n] * Aoff[t][j]
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g_out = GATOR_MFMA(h0[r], ident[r], g_out);     // C-layout -> T-layout of the diagonal term
+            {
+                f32x16 gd = zero16();
+                g_out = bg;
+                // sum_j (M.h1)[j][n] * Aoff[t][j]   and   the diagonal term moved from C- to T-layout by an identity product
+                dot16x2(h1, aoff, g_out, h0, ident, gd);
+                g_out += gd;
+            }
             GAT_STAMP(17)
             __syncthreads();
             GAT_STAMP(2)
@@ -311,15 +321,11 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             const f32x16 u0 = lin4r<true>(G0, s, zero16());
             G0 = ldg4(w.fc1, (4 * wave + 0) * 4, lane);
             GATOR_PIN();
-            f32x16 f0 = zero16();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) f0 = GATOR_MFMA(u0[r] + b0, m1[r], f0);           // hop<=1 aggregation
-            store_block(FB + wave * kTile, lane, f0);
             // linears[1] (128->16): this wave contributes k-block `wave`; partial hop-2 aggregation, summed by the reader
-            const f32x16 u1 = mma_C(wl1, load_block(SB + wave * kTile, lane), zero16());   // (s[wave] would index registers dynamically)
-            f32x16 f1 = zero16();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) f1 = GATOR_MFMA(u1[r], m2[r], f1);
+            const f32x16 u1 = dot16_C(wl1, load_block(SB + wave * kTile, lane));            // (s[wave] would index registers dynamically)
+            f32x16 f0 = zero16(), f1 = zero16();
+            dot16x2(u0 + b0, m1, f0, u1, m2, f1);                                           // hop<=1 and hop==2 aggregations
+            store_block(FB + wave * kTile, lane, f0);
             store_block(F1P + wave * kTile, lane, f1);
         }
         __syncthreads();
@@ -331,11 +337,13 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             f32x16 f1 = f1bias;                                                             // rowsum(m2)[t] * linears[1].bias[n]
 #pragma unroll
             for (int q = 0; q < 4; ++q) f1 += load_block(F1P + q * kTile, lane);
+            f32x16 acb = zero16();
 #pragma unroll
-            for (int g = 0; g < 2; ++g)                                                     // channels 128..143 only (r < 8)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = GATOR_MFMA(wb4.g[g][j], f1[4 * g + j], acc);
-            xw += acc;
+            for (int j = 0; j < 4; ++j) {                                                   // channels 128..143 only (r < 8)
+                acc = GATOR_MFMA(wb4.g[0][j], f1[j], acc);
+                acb = GATOR_MFMA(wb4.g[1][j], f1[4 + j], acb);
+            }
+            xw += acc + acb;
             store_block(X + wave * kTile, lane, xw);
         }
         __syncthreads();

@@ -78,9 +78,9 @@ __device__ __forceinline__ void linear64_T(const float* __restrict__ Wp, const f
                                            int lane, f32x16 (&y)[2]) {
     const int h = lane >> 5;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {   // one 32-term chain per k-block, then one add: halves the fp32 chain length
-        const f32x16 a0 = mma_T(load_wtile(Wp, nb * 2 + 0, lane), x[0], bias ? load_chanvec_S(bias, 32 * nb, h) : zero16());
-        const f32x16 a1 = mma_T(load_wtile(Wp, nb * 2 + 1, lane), x[1], zero16());
+    for (int nb = 0; nb < 2; ++nb) {   // one 32-term chain per k-block (interleaved), then one add
+        f32x16 a0 = bias ? load_chanvec_S(bias, 32 * nb, h) : zero16(), a1 = zero16();
+        mma2_T(load_wtile(Wp, nb * 2 + 0, lane), x[0], a0, load_wtile(Wp, nb * 2 + 1, lane), x[1], a1);
         y[nb] = a0 + a1;
     }
 }
@@ -92,10 +92,9 @@ __device__ __forceinline__ void linear64_T(const float* __restrict__ Wp, const f
     } while (0)
 
 // one 32-key tile of the flash attention: scores, online softmax, P.V into accumulator OACC
-#define ATTN_TILE(KT, KB, VB, OACC)                                                                         \
+#define ATTN_TILE(KT, KB, VB, OACC, OACB)                                                                       \
     {                                                                                                       \
-        f32x16 S = zero16();                                                                                \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) S = GATOR_MFMA(KB[r], qv[r], S);  /* S^T[key][query] */ \
+        f32x16 S = dot16(KB, qv, zero16());   /* S^T[key][query], two interleaved 8-step chains */            \
         float bm = -1e30f;                                                                                  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
             float sc = S[r] * c;                                                                            \
@@ -122,11 +121,15 @@ __device__ __forceinline__ void linear64_T(const float* __restrict__ Wp, const f
         }                                                                                                   \
         l += ps;                                                                                            \
         /* O^T[d][query] += V^T[d][key] P^T[key][query] */                                                  \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) OACC = GATOR_MFMA(VB[r], S[r], OACC);                \
+        _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                 \
+            OACC = GATOR_MFMA(VB[r], S[r], OACC);                                                           \
+            OACB = GATOR_MFMA(VB[r + 1], S[r + 1], OACB);                                                   \
+        }                                                                                                   \
     }
 
 // ---- flash attention of one 32-query tile against the 431 keys of its sample, one head --------------------------------
-// Key tile kt accumulates into chain kt&3 (four fp32 chains of ~110 products).  (Explicit K/V double buffering was measured:
+// Even key tiles accumulate into chains O/O2 (even/odd key of the tile), odd tiles into O3/O4: four fp32 chains of ~110 products,
+// and no two consecutive MFMAs write the same accumulator.  (Explicit K/V double buffering was measured:
 // no gain -- the co-resident wave already covers the tile loads -- and it costs 32 VGPRs.)
 __device__ __forceinline__ f32x16 self_attention_head(const float* __restrict__ qt, const float* __restrict__ kbase,
                                                       const float* __restrict__ vbase, int lane) {
@@ -139,28 +142,28 @@ __device__ __forceinline__ f32x16 self_attention_head(const float* __restrict__ 
     for (int kt = 0; kt < kVT - 2; kt += 4) {               // 12 tiles in 3 trips of 4 (chain kt&3), then the last two
         {
             const f32x16 kb = load_block(kbase + (size_t)kt * 2 * kTile, lane), vb = load_block(vbase + (size_t)kt * 2 * kTile, lane);
-            ATTN_TILE(kt, kb, vb, O)
+            ATTN_TILE(kt, kb, vb, O, O2)
         }
         {
             const f32x16 kb = load_block(kbase + (size_t)(kt + 1) * 2 * kTile, lane), vb = load_block(vbase + (size_t)(kt + 1) * 2 * kTile, lane);
-            ATTN_TILE(kt + 1, kb, vb, O2)
+            ATTN_TILE(kt + 1, kb, vb, O3, O4)
         }
         {
             const f32x16 kb = load_block(kbase + (size_t)(kt + 2) * 2 * kTile, lane), vb = load_block(vbase + (size_t)(kt + 2) * 2 * kTile, lane);
-            ATTN_TILE(kt + 2, kb, vb, O3)
+            ATTN_TILE(kt + 2, kb, vb, O, O2)
         }
         {
             const f32x16 kb = load_block(kbase + (size_t)(kt + 3) * 2 * kTile, lane), vb = load_block(vbase + (size_t)(kt + 3) * 2 * kTile, lane);
-            ATTN_TILE(kt + 3, kb, vb, O4)
+            ATTN_TILE(kt + 3, kb, vb, O3, O4)
         }
     }
     {
         const f32x16 kb = load_block(kbase + (size_t)(kVT - 2) * 2 * kTile, lane), vb = load_block(vbase + (size_t)(kVT - 2) * 2 * kTile, lane);
-        ATTN_TILE(kVT - 2, kb, vb, O)
+        ATTN_TILE(kVT - 2, kb, vb, O, O2)
     }
     {
         const f32x16 kb = load_block(kbase + (size_t)(kVT - 1) * 2 * kTile, lane), vb = load_block(vbase + (size_t)(kVT - 1) * 2 * kTile, lane);
-        ATTN_TILE(kVT - 1, kb, vb, O2)
+        ATTN_TILE(kVT - 1, kb, vb, O3, O4)
     }
     l += xhalf(l);
     return ((O + O2) + (O3 + O4)) * (1.0f / l);
@@ -171,9 +174,7 @@ __device__ __forceinline__ f32x16 cross_attention_head(const float* __restrict__
                                                        const f32x16& qh, int J, int lane) {
     const int h = lane >> 5;
     const f32x16 kb = load_block(kj, lane);
-    f32x16 S = zero16();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S = GATOR_MFMA(kb[r], qh[r], S);          // S^T[joint][token]
+    f32x16 S = dot16(kb, qh, zero16());                                    // S^T[joint][token]
     const float c = kLog2e * 0.17677669529663688110f;                      // head_dim ** -0.5 (MDR.py:25), exp2 domain
     float mx = -1e30f;
 #pragma unroll
@@ -193,10 +194,7 @@ __device__ __forceinline__ f32x16 cross_attention_head(const float* __restrict__
     sum += xhalf(sum);
     const float inv = 1.0f / sum;
     const f32x16 vb = load_block(vjp, lane);
-    f32x16 O = zero16();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) O = GATOR_MFMA(vb[r], S[r] * inv, O);
-    return O;
+    return dot16(vb, S * inv, zero16());
 }
 
 // ---- weight stream of the tokenwise part: two buffers of one tile pair each (2 x 32 VGPRs).  The pair for the NEXT
@@ -211,10 +209,14 @@ __device__ __forceinline__ W2 ldw2(const float* __restrict__ Wp, int i0, int i1,
 }
 // 64-term contraction as two independent 32-term chains (one per k-block)
 __device__ __forceinline__ f32x16 lin2_T(const W2& w, const f32x16 (&x)[2], f32x16 init) {
-    return mma_T(w.t[0], x[0], init) + mma_T(w.t[1], x[1], zero16());
+    f32x16 a1 = zero16();
+    mma2_T(w.t[0], x[0], init, w.t[1], x[1], a1);
+    return init + a1;
 }
 __device__ __forceinline__ f32x16 lin2_C(const W2& w, const f32x16 (&x)[2]) {
-    return mma_C(w.t[0], x[0], zero16()) + mma_C(w.t[1], x[1], zero16());
+    f32x16 a0 = zero16(), a1 = zero16();
+    mma2_C(w.t[0], x[0], a0, w.t[1], x[1], a1);
+    return a0 + a1;
 }
 
 template <int MODE>   // 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
                     *reinterpret_cast<f32x4*>(a.lbf + ((size_t)b * kV + token) * kE + 32 * nb + 8 * g + 4 * h) = v4;
                 }
         }
-        const f32x16 acc = mma_T(A.t[1], vf[1], mma_T(A.t[0], vf[0], load_chanvec_S(a.head_b, 0, h)));
+        const f32x16 acc = lin2_T(A, vf, load_chanvec_S(a.head_b, 0, h));
         if (token < kV) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -336,8 +338,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
             MDR_PIN();
 #pragma unroll
             for (int r = 0; r < 16; ++r) hdn[r] = gelu_f(hdn[r]);
-            acc2[0][c & 1] = mma_T(B.t[0], hdn, acc2[0][c & 1]);   // even / odd chunks: 2 chains of 128 products
-            acc2[1][c & 1] = mma_T(B.t[1], hdn, acc2[1][c & 1]);
+            mma2_T(B.t[0], hdn, acc2[0][c & 1], B.t[1], hdn, acc2[1][c & 1]);   // even / odd chunks: 2 chains of 128 products each
             if (c < 7) B = ldw2(w.fc2, c + 1, 8 + c + 1, lane); else B = ldw2(w.sa0, 2, 3, lane);
             MDR_PIN();
         }
@@ -435,12 +436,15 @@ __global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
         f32x16 fz[2];
         layernorm64(jf, a.n1w[li], a.n1b[li], h, fz);
         float* out = a.jkv + (((size_t)b * 3 + li) * 4) * kTile;
-        f32x16 kt = mma_T(load_wtile(a.wk_p[li], wave * 2 + 0, lane), fz[0], zero16()) +
-                    mma_T(load_wtile(a.wk_p[li], wave * 2 + 1, lane), fz[1], zero16());
+        f32x16 kt, k1 = zero16();
+        kt = zero16();
+        mma2_T(load_wtile(a.wk_p[li], wave * 2 + 0, lane), fz[0], kt, load_wtile(a.wk_p[li], wave * 2 + 1, lane), fz[1], k1);
+        kt += k1;
         if (!tok_ok) kt = zero16();             // joints >= J: zero rows (masked in the softmax anyway)
         store_block(out + wave * kTile, lane, kt);
-        f32x16 vt = mma_C(load_wtile(a.wv_p[li], wave * 2 + 0, lane), fz[0], zero16()) +
-                    mma_C(load_wtile(a.wv_p[li], wave * 2 + 1, lane), fz[1], zero16());
+        f32x16 vt = zero16(), v1 = zero16();
+        mma2_C(load_wtile(a.wv_p[li], wave * 2 + 0, lane), fz[0], vt, load_wtile(a.wv_p[li], wave * 2 + 1, lane), fz[1], v1);
+        vt += v1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) vt[r] = (kap(r) + 4 * h < J) ? vt[r] : 0.f;
         store_block(out + (2 + wave) * kTile, lane, vt);

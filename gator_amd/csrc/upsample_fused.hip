@@ -42,23 +42,34 @@ __global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ vcp,
     f32x16 acc[3], tot[3];
 #pragma unroll
     for (int l = 0; l < 3; ++l) { acc[l] = zero16(); tot[l] = zero16(); }
+    // software pipeline over the 56 (cb,g) steps: the 6 operand fragments of step s+1 are requested before the 28 MFMAs of
+    // step s are queued (fence keeps the order), so their L2 latency hides behind ~1.8k MFMA cycles
+    f32x4 a0 = a_base[0], a1 = a_base[a_lp], a2 = a_base[2 * a_lp];
+    f32x4 w0 = w_base[0], w1 = w_base[w_tap], w2 = w_base[2 * w_tap];
+#pragma unroll 1
     for (int cb = 0; cb < kCB; ++cb) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const size_t o = ((size_t)cb * 4 + g) * 64;
-            const f32x4 a0 = a_base[o], a1 = a_base[a_lp + o], a2 = a_base[2 * a_lp + o];
-            const f32x4 w0 = w_base[o], w1 = w_base[w_tap + o], w2 = w_base[2 * w_tap + o];
+            const int sn = cb * 4 + g + 1 < kCB * 4 ? cb * 4 + g + 1 : cb * 4 + g;     // next step (last one re-loads itself)
+            const size_t o = (size_t)sn * 64;
+            const f32x4 na0 = a_base[o], na1 = a_base[a_lp + o], na2 = a_base[2 * a_lp + o];
+            const f32x4 nw0 = w_base[o], nw1 = w_base[w_tap + o], nw2 = w_base[2 * w_tap + o];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // out l gets input l' = l + k - 1
+                // consecutive MFMAs never share an accumulator (a dependent 32x32x2 pair does not issue back to back)
                 acc[0] = GATOR_MFMA(a0[j], w1[j], acc[0]);
-                acc[0] = GATOR_MFMA(a1[j], w2[j], acc[0]);
                 acc[1] = GATOR_MFMA(a0[j], w0[j], acc[1]);
-                acc[1] = GATOR_MFMA(a1[j], w1[j], acc[1]);
-                acc[1] = GATOR_MFMA(a2[j], w2[j], acc[1]);
                 acc[2] = GATOR_MFMA(a1[j], w0[j], acc[2]);
+                acc[0] = GATOR_MFMA(a1[j], w2[j], acc[0]);
+                acc[1] = GATOR_MFMA(a1[j], w1[j], acc[1]);
                 acc[2] = GATOR_MFMA(a2[j], w1[j], acc[2]);
+                acc[1] = GATOR_MFMA(a2[j], w2[j], acc[1]);
             }
+            a0 = na0; a1 = na1; a2 = na2;
+            w0 = nw0; w1 = nw1; w2 = nw2;
         }
         // two-level summation: chains of <= 96 products per 32-vertex block, then 14 partial sums (fp32 accuracy)
 #pragma unroll
