@@ -68,6 +68,22 @@ def build_model(J, impl, device):
     return m.to(device).eval(), base, alpha
 
 
+STAGE_KERNEL = {'gat': 'k_gat', 'mdr_layer0': 'k_mdr_layer<0>', 'mdr_layer': 'k_mdr_layer<1>', 'mdr_attn_head': 'k_mdr_layer<2>',
+                'upsample': 'k_upsample'}
+
+
+def pmc_traffic(stage, B):
+    """HBM-side bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 as the gfx950
+    guide prescribes, + WRITE_SIZE), collected with this same command at B=256; None for other batch sizes / kernels."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary_B256.json')
+    if B != 256 or not os.path.exists(path):
+        return None
+    for row in json.load(open(path)):
+        if row['kernel'] == STAGE_KERNEL.get(stage):
+            return {'bytes_per_launch': int((row['fetch_MB_corrected'] + row['write_MB']) * 1048576), 'source': 'profiles/r01_pmc_summary_B256.json'}
+    return None
+
+
 def cpu_baseline(model, base, alpha, J, seconds):
     """Oracle fp32 on the host cores: bounded sample of the same workload (synthetic poses, same weights).  The thread count
     is swept (all cores is pathological for these tiny tensors on a 100+-core host) and the best rate is reported."""
@@ -155,8 +171,9 @@ def main():
             mflop = STAGE_MFLOP.get(name.split(':')[0], None)
             if mflop is not None and avg_s > 0:
                 ach = mflop * 1e6 * B / avg_s / 1e12
+                traffic = pmc_traffic(name, B)
                 roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(ach / PEAK_F32_TFLOPS, 4), 'traffic': None, 'avg_launch_ms': round(avg_s * 1e3, 4),
+                        'frac': round(ach / PEAK_F32_TFLOPS, 4), 'traffic': traffic, 'avg_launch_ms': round(avg_s * 1e3, 4),
                         'stages_ms': {k: round(v[0] / v[1], 4) for k, v in prof.items()}}
         if roof is None:   # no per-kernel events available (bring-up path): price the whole forward
             ach = FLOPS_PER_MESH[J] * value / world / 1e12

@@ -247,3 +247,36 @@ def mpjpe(pred_joint, target_joint, eval_joints=None, root=0):
     if eval_joints is not None:
         p, t = p[:, eval_joints], t[:, eval_joints]
     return float(np.sqrt(((np.asarray(p) - np.asarray(t)) ** 2).sum(2)).mean())
+
+
+def rigid_transform_3d(A, B):
+    """lib/coord_utils.py:127-142 (numpy, float64)."""
+    A, B = np.asarray(A, np.float64), np.asarray(B, np.float64)
+    n = A.shape[0]
+    ca, cb = A.mean(0), B.mean(0)
+    H = (A - ca).T @ (B - cb) / n
+    U, s, V = np.linalg.svd(H)
+    R = V.T @ U.T
+    if np.linalg.det(R) < 0:
+        s[-1] = -s[-1]
+        V[2] = -V[2]
+        R = V.T @ U.T
+    c = 1 / np.var(A, axis=0).sum() * s.sum()
+    t = -(c * R) @ ca + cb
+    return c, R, t
+
+
+def rigid_align(A, B):
+    """lib/coord_utils.py:145-149."""
+    c, R, t = rigid_transform_3d(A, B)
+    return ((c * R) @ np.asarray(A, np.float64).T).T + t
+
+
+def pa_mpjpe(pred_joint, target_joint, eval_joints=None):
+    """data/PW3D/dataset.py:337-375 style: per-sample Procrustes alignment, then mean joint error."""
+    errs = []
+    for p, t in zip(np.asarray(pred_joint, np.float64), np.asarray(target_joint, np.float64)):
+        if eval_joints is not None:
+            p, t = p[list(eval_joints)], t[list(eval_joints)]
+        errs.append(np.sqrt(((rigid_align(p, t) - t) ** 2).sum(1)).mean())
+    return float(np.mean(errs))
