@@ -30,7 +30,7 @@ FLOPS_PER_MESH = {17: 4.10e8, 19: 4.18e8}      # dense algorithmic 
 # algorithmic MFLOP per mesh per stage, J=17
 # mdr_layer  = one middle LBF launch: 431x431 attention core of layer l-1 (47.6) + its out-proj (3.5) + cross-attn/Mlp of
 #              layer l (37.5) + q/k/v in-proj of layer l (10.6) = 99.2 ; mdr_layer0 = tokenise + the last two items
-STAGE_MFLOP = {'gat': 56.66, 'mdr_layer0': 48.7, 'mdr_layer': 99.2, 'mdr_attn_head': 51.4, 'mdr_head': 1.3, 'upsample': 53.45}
+STAGE_MFLOP = {'upsample_bf16': 53.45, 'gat': 56.66, 'mdr_layer0': 48.7, 'mdr_layer': 99.2, 'mdr_attn_head': 51.4, 'mdr_head': 1.3, 'upsample': 53.45}
 
 
 def parse():
@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=256, help='samples per GPU per step')
     ap.add_argument('--joints', type=int, default=17)
     ap.add_argument('--impl', default=os.environ.get('GATOR_AMD_IMPL', 'fused'))
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'], help='bf16: vertex regressor on bf16 MFMA (config 3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     return ap.parse_args()
@@ -80,7 +81,7 @@ def pmc_traffic(stage, B):
         return None
     for row in json.load(open(path)):
         if row['kernel'] == STAGE_KERNEL.get(stage):
-            return {'bytes_per_launch': int((row['fetch_MB_corrected'] + row['write_MB']) * 1048576), 'source': 'profiles/r01_pmc_summary_B256.json'}
+            return int((row['fetch_MB_corrected'] + row['write_MB']) * 1048576)
     return None
 
 
@@ -137,6 +138,7 @@ def main():
     from gator_amd.parallel import ShardedForward
     J, B = a.joints, a.batch
     model, base, alpha = build_model(J, a.impl, dev)
+    model.precision = a.precision
     runner = ShardedForward(model, world, rank, dist)
     x = torch.from_numpy(synthetic.synthetic_pose2d(B, J, seed=1000 + rank)).to(dev)     # this rank's shard, resident in HBM
 
@@ -181,7 +183,7 @@ def main():
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_TFLOPS, 4), 'traffic': None}
         line = {'metric': 'meshes/sec (B=256, J=17) GATOR forward', 'value': round(value, 1), 'unit': 'meshes/sec',
                 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
-                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'scaling': 'weak', 'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic',
                 'config': {'workload': 'B=%d synthetic Human3.6M %d-joint poses per GPU, GAT+MDR forward fp32%s'
                            % (B, J, ', RCCL all-gather of [%d,6890,3] vertices' % (B * world) if world > 1 else ''),
                            'batch_per_gpu': B, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world},

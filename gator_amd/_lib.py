@@ -27,6 +27,8 @@ SIGNATURES = {
     'gator_create': (_I, [ctypes.POINTER(GatorTensor), _I, ctypes.POINTER(GatorConfig), ctypes.POINTER(_P)]),
     'gator_destroy': (_I, [_P]),
     'gator_forward_f32': (_I, [_P, _P, _I, _P, _P, _P]),
+    'gator_forward_bf16': (_I, [_P, _P, _I, _P, _P, _P]),
+    'gator_upsample_bf16': (_I, [_P, _P, _I, _P, _P]),
     'gator_gat_forward_f32': (_I, [_P, _P, _I, _P, _P, _P]),
     'gator_mdr_forward_f32': (_I, [_P, _P, _I, _P, _P]),
     'gator_upsample_f32': (_I, [_P, _P, _I, _P, _P]),

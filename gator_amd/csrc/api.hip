@@ -353,6 +353,25 @@ extern "C" int gator_profile_read(gator_ctx* c, char* names, int64_t cap, float*
     return GATOR_OK;
 }
 
+extern "C" int gator_forward_bf16(gator_ctx* c, const float* pose2d, int32_t B, float* verts, float* pose3d, void* stream) {
+    int rc = check_fwd(c, pose2d, verts, B, "gator_forward_bf16");
+    if (rc) return rc;
+    if (!pose3d) return fail(GATOR_EINVAL, "gator_forward_bf16: pose3d is null");
+    if (c->parts != (GATOR_PART_GAT | GATOR_PART_MDR) || c->impl != GATOR_IMPL_FUSED)
+        return fail(GATOR_EUNSUPPORTED, "gator_forward_bf16: needs a fused ctx with both GAT and MDR weights");
+    c->last_batch = B;
+    c->taps.clear();
+    return fused_forward(c, pose2d, B, verts, pose3d, stream, true);
+}
+
+extern "C" int gator_upsample_bf16(gator_ctx* c, const float* vert431, int32_t B, float* verts, void* stream) {
+    int rc = check_fwd(c, vert431, verts, B, "gator_upsample_bf16");
+    if (rc) return rc;
+    if (!(c->parts & GATOR_PART_MDR) || c->impl != GATOR_IMPL_FUSED)
+        return fail(GATOR_EUNSUPPORTED, "gator_upsample_bf16: needs a fused ctx with the MDR weights");
+    return fused_upsample_bf16(c, vert431, B, verts, stream);
+}
+
 extern "C" int gator_get_tap(gator_ctx* c, const char* name, float* dst, int64_t capacity, int64_t* count, void* stream) {
     if (!c || !name || !dst) return fail(GATOR_EINVAL, "gator_get_tap: null argument");
     const float* src = nullptr;

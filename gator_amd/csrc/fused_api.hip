@@ -264,6 +264,8 @@ void fused_destroy(gator_ctx* c) {
     if (c->fused->ws) (void)hipFree(c->fused->ws);
     if (c->fused->wbuf) (void)hipFree(c->fused->wbuf);
     if (c->fused->gbuf) (void)hipFree(c->fused->gbuf);
+    if (c->fused->up_w16) (void)hipFree(c->fused->up_w16);
+    if (c->fused->vcp16) (void)hipFree(c->fused->vcp16);
     delete c->fused;
     c->fused = nullptr;
 }
@@ -283,17 +285,45 @@ int fused_upsample(gator_ctx* c, const float* vert431, int B, float* verts, void
     return launch_upsample(f, c, B, verts, stream);
 }
 
-int fused_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* stream) {
+static int ensure_bf16(gator_ctx* c, int B, void* stream) {
+    FusedState* f = c->fused;
+    if (!f->up_w16) {      // first bf16 call: pack the regressor weights once
+        GATOR_HIP_CHECK(hipMalloc(&f->up_w16, upsample_bf16_weight_elems() * 2));
+        int rc = pack_upsample_bf16(c->w.up_w, f->up_w16, stream);
+        if (rc) return rc;
+    }
+    if (B > f->vcp16_cap) {
+        if (f->vcp16) { GATOR_HIP_CHECK(hipDeviceSynchronize()); GATOR_HIP_CHECK(hipFree(f->vcp16)); }
+        GATOR_HIP_CHECK(hipMalloc(&f->vcp16, upsample_bf16_vcp_elems(B) * 2));
+        f->vcp16_cap = B;
+    }
+    return GATOR_OK;
+}
+
+int fused_upsample_bf16(gator_ctx* c, const float* vert431, int B, float* verts, void* stream) {
+    int rc = fused_ensure_ws(c, B);
+    if (rc == GATOR_OK) rc = ensure_bf16(c, B, stream);
+    if (rc) return rc;
+    StageTimer tm(c, "upsample_bf16", stream);
+    return launch_upsample_bf16(c->fused, c, vert431, B, verts, stream);
+}
+
+static int fused_mdr_forward_impl(gator_ctx* c, const float* pc, int B, float* verts, void* stream, bool bf16) {
     int rc = fused_ensure_ws(c, B);
     if (rc) return rc;
     FusedState* f = c->fused;
     rc = launch_mdr(c, f, pc, B, stream);        // also writes the packed vertex-GEMM operand f->vcp
     if (rc) return rc;
+    if (bf16) return fused_upsample_bf16(c, f->vc, B, verts, stream);
     StageTimer tm(c, "upsample", stream);
     return launch_upsample(f, c, B, verts, stream);
 }
 
-int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream) {
+int fused_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* stream) {
+    return fused_mdr_forward_impl(c, pc, B, verts, stream, false);
+}
+
+int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream, bool bf16) {
     int rc = fused_ensure_ws(c, B);
     if (rc) return rc;
     FusedState* f = c->fused;
@@ -302,7 +332,7 @@ int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float*
     c->taps["feat"] = {f->feat, (int64_t)B * c->J * kC};
     rc = basic_build_pc(c, pose2d, f->xout, f->feat, B, f->pc, pose3d, stream);
     if (rc) return rc;
-    return fused_mdr_forward(c, f->pc, B, verts, stream);
+    return fused_mdr_forward_impl(c, f->pc, B, verts, stream, bf16);
 }
 
 }  // namespace gator

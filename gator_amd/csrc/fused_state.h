@@ -26,6 +26,9 @@ struct FusedState {
     size_t wbuf_floats = 0;
     // upsample: Wp[tap][ob][cb][4][64][4]
     const float* up_w = nullptr;
+    void* up_w16 = nullptr;             // bf16 [tap][ob][28][64][8] (packed lazily on the first bf16 call)
+    void* vcp16 = nullptr;              // bf16 packed vert431 for the bf16 vertex GEMM (cap-sized)
+    int vcp16_cap = 0;
     // MDR
     MdrLayerP lay[3];
     const float* head_w = nullptr;      // [1 nb][2 kb] combined motion/bias/scale linear
@@ -55,6 +58,11 @@ int launch_pack_vc(const float* vc, int B, float* vcp, void* stream);
 int launch_upsample(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream);
 // gat_fused.hip
 int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream);
+// upsample_bf16.hip
+size_t upsample_bf16_weight_elems();
+size_t upsample_bf16_vcp_elems(int B);
+int pack_upsample_bf16(const float* up_w, void* dst, void* stream);
+int launch_upsample_bf16(const FusedState* f, const gator_ctx* c, const float* vc, int B, float* verts, void* stream);
 // mdr_fused.hip
 int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream);
 

@@ -101,7 +101,8 @@ void fused_destroy(gator_ctx* c);
 int fused_gat_forward(gator_ctx* c, const float* pose2d, int B, float* x_out, float* feat, void* stream);
 int fused_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* stream);
 int fused_upsample(gator_ctx* c, const float* vert431, int B, float* verts, void* stream);
-int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream);
+int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream, bool bf16 = false);
+int fused_upsample_bf16(gator_ctx* c, const float* vert431, int B, float* verts, void* stream);
 }  // namespace gator
 
 namespace gator {

@@ -13,6 +13,7 @@ class GATOR(HipModule):
     def __init__(self, num_joint, embed_dim, depth, graph_adj, GCN_depth, J_regressor, base_data=None, alpha=None):
         super().__init__()
         self.num_joint = num_joint
+        self.precision = 'f32'        # 'bf16': vertex regressor on bf16 MFMA (BASELINE config 3), the rest stays fp32
         self.pose_lifter = GAT.get_model(num_joint, embed_dim, depth, graph_adj, GCN_depth, J_regressor,
                                          pretrained=cfg.MODEL.posenet_pretrained, base_data=base_data)   # GATOR.py:13
         self.pose2mesh = MDR.get_model(num_joint, embed_dim, base_data=base_data, alpha=alpha)           # GATOR.py:14
@@ -32,8 +33,8 @@ class GATOR(HipModule):
         ctx = self._context(x.device)
         verts = torch.empty((B, 6890, 3), device=x.device, dtype=torch.float32)
         pose3d = torch.empty((B, self.num_joint, 3), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.load().gator_forward_f32(ctx, x.data_ptr(), B, verts.data_ptr(), pose3d.data_ptr(),
-                                                self._stream(x.device)), 'gator_forward_f32')
+        fn = _lib.load().gator_forward_bf16 if self.precision == 'bf16' else _lib.load().gator_forward_f32
+        _lib.check(fn(ctx, x.data_ptr(), B, verts.data_ptr(), pose3d.data_ptr(), self._stream(x.device)), 'gator_forward_' + self.precision)
         return verts, pose3d
 
 

@@ -87,14 +87,14 @@ class MDR(HipModule):
                    'gator_mdr_forward_f32')
         return verts
 
-    def upsample(self, vert431):
+    def upsample(self, vert431, precision='f32'):
         """upsample_conv + template add alone (MDR.py:167-168): [B,431,3] -> [B,6890,3]."""
         x = self._prep(vert431, 'MDR.upsample')
         B = x.shape[0]
         ctx = self._context(x.device)
         verts = torch.empty((B, 6890, 3), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.load().gator_upsample_f32(ctx, x.data_ptr(), B, verts.data_ptr(), self._stream(x.device)),
-                   'gator_upsample_f32')
+        fn = _lib.load().gator_upsample_bf16 if precision == 'bf16' else _lib.load().gator_upsample_f32
+        _lib.check(fn(ctx, x.data_ptr(), B, verts.data_ptr(), self._stream(x.device)), 'gator_upsample_' + precision)
         return verts
 
 

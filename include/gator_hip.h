@@ -76,6 +76,11 @@ int gator_destroy(gator_ctx* ctx);
  *   pose2d [B,J,2] f32 device, contiguous  ->  verts [B,6890,3] f32 (metres), pose3d [B,J,3] f32 (mm). */
 int gator_forward_f32(gator_ctx* ctx, const float* pose2d, int32_t batch, float* verts, float* pose3d, void* stream);
 
+/* BASELINE config 3: same forward with the vertex regressor (upsample_conv, lib/models/MDR.py:122,167-168) on bf16 MFMA
+ * (bf16 operands, fp32 accumulate/epilogue/output); everything upstream stays fp32.  MPJPE-level parity (sub-mm vertices). */
+int gator_forward_bf16(gator_ctx* ctx, const float* pose2d, int32_t batch, float* verts, float* pose3d, void* stream);
+int gator_upsample_bf16(gator_ctx* ctx, const float* vert431, int32_t batch, float* verts, void* stream);
+
 /* Stage entry points (parity tests; same semantics as the reference sub-modules):
  *   GAT.forward   lib/models/GAT.py:133-152 : pose2d [B,J,2] -> x_out [B,3J] (mm), feat [B,J,128]
  *   MDR.forward   lib/models/MDR.py:124-170 : pose_combine [B,J,133] -> verts [B,6890,3]
