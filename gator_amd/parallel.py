@@ -4,8 +4,10 @@ ranks (one process per GPU, weights replicated) and the ONLY collective is an al
 multi-GPU counterpart (no torch.distributed anywhere); correctness criterion: the gathered tensor equals the
 single-GPU output of the concatenated batch bit for bit (same kernels, per-sample arithmetic independent of B).
 
-The gather of micro-batch k runs on a side stream while micro-batch k+1 computes: xGMI is point-to-point (7 links x ~153
-GB/s per GPU), a ring all-gather of 21 MB/rank per 256 samples costs ~1 ms at 8 GPUs, comparable to the compute."""
+Overlap: the gather runs on a side stream and the compute stream never waits for it, so step k's gather (xGMI is
+point-to-point, 7 links x ~153 GB/s per GPU: a ring all-gather of 21 MB/rank per 256 samples costs ~1 ms at 8 GPUs, the same
+order as the 1.5 ms of compute) hides behind step k+1's kernels.  Outputs are double-buffered; `step()` returns the buffers
+of THIS step together with an event the consumer must wait on (`wait()` does it for the current stream)."""
 import torch
 
 
@@ -15,13 +17,21 @@ class ShardedForward:
         self.micro = micro_batch
         self._bufs = {}
         self._comm_stream = None
+        self._flip = 0
+        self.last_event = None
 
     def _buffers(self, B, J, device):
-        key = (B, J, str(device))
+        self._flip ^= 1
+        key = (B, J, str(device), self._flip)
         if key not in self._bufs:
             self._bufs[key] = (torch.empty((self.world * B, 6890, 3), device=device, dtype=torch.float32),
                                torch.empty((self.world * B, J, 3), device=device, dtype=torch.float32))
         return self._bufs[key]
+
+    def wait(self):
+        """Make the current stream wait for the gather of the last step (call before consuming its outputs)."""
+        if self.last_event is not None:
+            torch.cuda.current_stream().wait_event(self.last_event)
 
     def step(self, pose2d_shard):
         """pose2d_shard [B_local, J, 2] on this rank's GPU -> (verts [world*B_local,6890,3], pose3d [world*B_local,J,3])
@@ -60,7 +70,7 @@ class ShardedForward:
                     self.dist.all_gather(outs_p, pose3d)
                 verts.record_stream(self._comm_stream)
                 pose3d.record_stream(self._comm_stream)
-        cur.wait_stream(self._comm_stream)
+        self.last_event = self._comm_stream.record_event()     # the compute stream does NOT wait: next step overlaps the gather
         return gv, gp
 
     def _step_host(self, x, gv, gp, mb):
