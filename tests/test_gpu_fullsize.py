@@ -1,0 +1,73 @@
+"""Full-size checks at the bench configuration (BASELINE configs[1]: B=256, J=17, fp32) and at a sharded shape.
+
+Size-independent properties of the path (samples are independent):
+  * permutation equivariance and batch-size independence, BITWISE (same kernels, per-sample arithmetic does not depend on
+    the batch size or on the position in the batch) -- this is also the correctness criterion of the multi-GPU all-gather:
+    concatenated shard outputs == single-process output;
+  * determinism (no atomics, fixed reduction order): two runs are bit-identical;
+  * accuracy: max |verts - fp64 oracle| <= 1e-3 mm over all 256 x 6890 x 3 coordinates."""
+import numpy as np
+import pytest
+import torch
+
+from gator_amd import synthetic
+from tests.helpers import build_model, oracle_setup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def setup():
+    z, m = build_model('h36m17_bn', 'fused')
+    x = torch.from_numpy(synthetic.synthetic_pose2d(256, 17, seed=1000)).cuda()     # bench.py's rank-0 input
+    v, p = m(x)
+    torch.cuda.synchronize()
+    return m, x, v.clone(), p.clone()
+
+
+def test_b256_accuracy_vs_fp64_oracle(setup):
+    from oracle import gator_oracle as go
+    m, x, v, p = setup
+    zz, c, sd = oracle_setup('h36m17_bn')
+    ref, rp = go.gator_forward(sd, c, x.cpu(), torch.float64)
+    err = np.abs(v.cpu().numpy().astype(np.float64) - ref.numpy()) * 1e3
+    print('\n[B=256] max %.3e mm, mean %.3e mm over %d coordinates' % (err.max(), err.mean(), err.size))
+    assert err.max() <= 1e-3
+    assert np.abs(p.cpu().numpy() - rp.numpy()).max() <= 1e-3
+
+
+def test_deterministic_and_batch_independent(setup):
+    m, x, v, p = setup
+    v2, p2 = m(x)
+    assert torch.equal(v2, v) and torch.equal(p2, p)                      # run-to-run bitwise
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(0)).cuda()
+    vp, pp = m(x[perm])
+    assert torch.equal(vp, v[perm]) and torch.equal(pp, p[perm])          # permutation equivariance, bitwise
+    for lo, hi in ((0, 1), (37, 38), (100, 133), (128, 256), (5, 250)):   # ragged sub-batches == slices of the full batch
+        vs, ps = m(x[lo:hi].contiguous())
+        assert torch.equal(vs, v[lo:hi]) and torch.equal(ps, p[lo:hi]), (lo, hi)
+
+
+def test_shard_concat_equals_full(setup):
+    """What the 8-GPU all-gather assembles (rank r owns rows r*B/N...) equals the single-GPU output bit for bit."""
+    m, x, v, p = setup
+    for n in (2, 4, 8):
+        sh = 256 // n
+        parts = [m(x[r * sh:(r + 1) * sh].contiguous()) for r in range(n)]
+        assert torch.equal(torch.cat([a for a, _ in parts]), v)
+        assert torch.equal(torch.cat([b for _, b in parts]), p)
+
+
+def test_large_batch_b2048_j19():
+    """Config-3/4 shapes (B=2048 per GPU, J=19): finite, bitwise-consistent with small batches, sampled accuracy."""
+    from oracle import gator_oracle as go
+    z, m = build_model('coco19_alpha', 'fused')
+    zz, c, sd = oracle_setup('coco19_alpha')
+    x = torch.from_numpy(synthetic.synthetic_pose2d(2048, 19, seed=77)).cuda()
+    v, p = m(x)
+    assert torch.isfinite(v).all()
+    idx = [0, 1, 511, 1024, 2047]
+    vs, ps = m(x[idx].contiguous())
+    assert torch.equal(vs, v[idx]) and torch.equal(ps, p[idx])
+    ref, _ = go.gator_forward(sd, c, x[idx].cpu(), torch.float64)
+    assert np.abs(vs.cpu().numpy() - ref.numpy()).max() * 1e3 <= 1e-3
