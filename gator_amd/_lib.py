@@ -18,7 +18,7 @@ class GatorTensor(ctypes.Structure):
 
 class GatorConfig(ctypes.Structure):
     _fields_ = [('num_joint', ctypes.c_int32), ('alpha', ctypes.c_int32), ('impl', ctypes.c_int32),
-                ('max_batch', ctypes.c_int32), ('parts', ctypes.c_int32)]
+                ('max_batch', ctypes.c_int32), ('parts', ctypes.c_int32), ('subbatch_streams', ctypes.c_int32)]
 
 
 # every symbol include/gator_hip.h declares: name -> (restype, argtypes)

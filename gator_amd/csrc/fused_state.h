@@ -18,25 +18,9 @@ struct GatBlockPk {                     // packed tiles of one GATBlock
     const float *mc, *md, *aoffT, *f1b;  // M (C-layout), diag(A).M (C-layout), offdiag(A)^T B-operand tile, hop-2 bias term
 };
 
-struct FusedState {
-    float* wbuf = nullptr;              // all packed weights
-    float* gbuf = nullptr;              // packed GAT weights + tables
-    GatBlockPk gblk[kDepth];
-    const float *g_biasT = nullptr, *g_m1T = nullptr, *g_m2T = nullptr, *g_lifter = nullptr, *g_gl3 = nullptr, *g_posT = nullptr, *g_vecs = nullptr;
-    size_t wbuf_floats = 0;
-    // upsample: Wp[tap][ob][cb][4][64][4]
-    const float* up_w = nullptr;
-    void* up_w16 = nullptr;             // bf16 [tap][ob][28][64][8] (packed lazily on the first bf16 call)
-    void* vcp16 = nullptr;              // bf16 packed vert431 for the bf16 vertex GEMM (cap-sized)
-    int vcp16_cap = 0;
-    // MDR
-    MdrLayerP lay[3];
-    const float* head_w = nullptr;      // [1 nb][2 kb] combined motion/bias/scale linear
-    const float* head_b = nullptr;      // [32]
-    const float* tok_base = nullptr;    // [14][2][4][64][4]  v431 part of get_verts_feature + bias + pos_v  (T-layout tiles)
-    const float* tok_w3 = nullptr;
-    const float* jfeat_p = nullptr;     // get_joint_feature.weight packed [2 nb][5 kb]
-    const float* posj_T = nullptr;      // [2] T-layout tiles of pos_j_id_embed[1..J]      // [3][64]            pose3d part of get_verts_feature (columns 3..5), row-major [i][ch]
+// Per-sub-batch workspace.  FusedState derives from it so kernels launchers read `f->vf` etc.; fused_forward swaps the
+// base part between the two sets when it runs two half-batches on two streams.
+struct FusedWs {
     // workspace (per cap batch)
     float* ws = nullptr;
     size_t ws_floats = 0;
@@ -48,6 +32,31 @@ struct FusedState {
     float *hf = nullptr;                // [B][431][32] head features
     float *lbf = nullptr;               // [B][431][64] tap: verts tokens after LBF3 (reference layout)
     float *feat = nullptr, *xout = nullptr, *pc = nullptr;
+    void* vcp16 = nullptr;              // bf16 packed vert431 for the bf16 vertex GEMM (cap-sized)
+    int vcp16_cap = 0;
+};
+
+struct FusedState : FusedWs {
+    float* wbuf = nullptr;              // all packed weights
+    float* gbuf = nullptr;              // packed GAT weights + tables
+    GatBlockPk gblk[kDepth];
+    const float *g_biasT = nullptr, *g_m1T = nullptr, *g_m2T = nullptr, *g_lifter = nullptr, *g_gl3 = nullptr, *g_posT = nullptr, *g_vecs = nullptr;
+    size_t wbuf_floats = 0;
+    // upsample: Wp[tap][ob][cb][4][64][4]
+    const float* up_w = nullptr;
+    void* up_w16 = nullptr;             // bf16 [tap][ob][28][64][8] (packed lazily on the first bf16 call)
+    // MDR
+    MdrLayerP lay[3];
+    const float* head_w = nullptr;      // [1 nb][2 kb] combined motion/bias/scale linear
+    const float* head_b = nullptr;      // [32]
+    const float* tok_base = nullptr;    // [14][2][4][64][4]  v431 part of get_verts_feature + bias + pos_v  (T-layout tiles)
+    const float* tok_w3 = nullptr;
+    // sub-batch pipelining (two half-batches on two streams: one half's kernel tails are filled by the other's work)
+    FusedWs sets[2];
+    void* aux_stream = nullptr;
+    void *ev_fork = nullptr, *ev_join = nullptr;
+    const float* jfeat_p = nullptr;     // get_joint_feature.weight packed [2 nb][5 kb]
+    const float* posj_T = nullptr;      // [2] T-layout tiles of pos_j_id_embed[1..J]      // [3][64]            pose3d part of get_verts_feature (columns 3..5), row-major [i][ch]
 };
 
 // fused_pack.hip

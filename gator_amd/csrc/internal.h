@@ -60,7 +60,7 @@ struct ProfRec { const char* name; void* start; void* stop; };
 }  // namespace gator
 
 struct gator_ctx {
-    int J = 0, alpha = 0, impl = 0, device = 0, D = 0, parts = 3;
+    int J = 0, alpha = 0, impl = 0, device = 0, D = 0, parts = 3, subbatch_streams = 0;
     std::string prefix_gat, prefix_mdr;
     std::map<std::string, gator::TensorRef> t;
     char* arena = nullptr;
@@ -83,6 +83,7 @@ struct gator_ctx {
     // measurement hook (gator_profile_*): (stage name, start event, stop event) per launch
     bool profiling = false;
     std::vector<gator::ProfRec> prof;
+    std::vector<void*> ev_pool;
 };
 
 namespace gator {

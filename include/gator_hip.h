@@ -64,6 +64,7 @@ typedef struct {
     int32_t impl;        /* gator_impl */
     int32_t max_batch;   /* workspace is sized for this many samples up front (0 = grow on demand) */
     int32_t parts;       /* gator_parts bitmask: which sub-modules' weights are present (0 = both) */
+    int32_t subbatch_streams; /* 2: run batches >= 128 as two half-batches on two streams (identical results, better tails) */
 } gator_config;
 
 /* Replaces: models.GATOR.get_model(...) + load_state_dict + .cuda()  (lib/models/GATOR.py:24-27,
