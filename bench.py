@@ -150,14 +150,14 @@ def main():
     for _ in range(a.warmup):
         out = runner.step(x)
     sync()
-    model.profile(True)
+    model.profile(4)          # HIP-event brackets on every 4th timed step (the brackets themselves cost ~3 % of a step)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = runner.step(x)
     sync()
     dt = time.perf_counter() - t0
     prof = model.profile_read()
-    model.profile(False)
+    model.profile(0)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -188,6 +188,21 @@ def main():
                            % (B, J, ', RCCL all-gather of [%d,6890,3] vertices' % (B * world) if world > 1 else ''),
                            'batch_per_gpu': B, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world},
                 'roofline': roof}
+        if world == 1 and B >= 128:
+            # same workload with the library's sub-batch pipelining (two half-batches on two streams; bit-identical results).
+            # Reported beside the headline, not as it: concurrent streams make per-kernel durations (and so `roofline`) ambiguous.
+            m2, _, _ = build_model(J, a.impl, dev)
+            m2.precision = a.precision
+            m2.subbatch_streams = 2
+            for _ in range(a.warmup):
+                m2(x)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                m2(x)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            line['subbatch_streams_2'] = {'value': round(B * a.steps / dt2, 1), 'ms_per_step': round(dt2 / a.steps * 1e3, 4)}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(model, base, alpha, J, a.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -267,6 +267,7 @@ extern "C" int gator_create(const gator_tensor* tensors, int32_t n, const gator_
 
 static int check_fwd(gator_ctx* c, const void* a, const void* b, int B, const char* fn) {
     if (!c || !a || !b || B <= 0) return fail(GATOR_EINVAL, "%s: null pointer or batch <= 0", fn);
+    c->profiling = c->prof_stride > 0 && (c->prof_calls++ % c->prof_stride) == 0;
     GATOR_HIP_CHECK(hipSetDevice(c->device));
     return ensure_workspace(c, B);
 }
@@ -335,7 +336,9 @@ extern "C" int gator_profile_enable(gator_ctx* c, int32_t on) {
             if (hipEventCreate(&e) == hipSuccess) c->ev_pool.push_back(e);
         }
     }
-    c->profiling = on != 0;
+    c->prof_stride = on > 0 ? on : 0;      // on = n: bracket the stages of every n-th forward (sampling keeps the hook's cost low)
+    c->prof_calls = 0;
+    c->profiling = false;
     return GATOR_OK;
 }
 

@@ -81,7 +81,8 @@ struct gator_ctx {
     std::map<std::string, std::pair<const float*, int64_t>> taps;   // name -> (device ptr, numel) of the last forward
     gator::FusedState* fused = nullptr;
     // measurement hook (gator_profile_*): (stage name, start event, stop event) per launch
-    bool profiling = false;
+    bool profiling = false;       // StageTimer records only when set; forwards toggle it from prof_stride
+    int prof_stride = 0, prof_calls = 0;   // record every prof_stride-th forward (0 = off)
     std::vector<gator::ProfRec> prof;
     std::vector<void*> ev_pool;
 };

@@ -95,8 +95,8 @@ int gator_upsample_f32(gator_ctx* ctx, const float* vert431, int32_t batch, floa
  * dst is a device pointer with room for `capacity` floats; *count receives the element count. */
 int gator_get_tap(gator_ctx* ctx, const char* name, float* dst, int64_t capacity, int64_t* count, void* stream);
 
-/* Measurement hook (bench.py `roofline`): when enabled, every stage launch of a forward is bracketed by a hipEvent pair
- * recorded on the launch stream.  gator_profile_read synchronises those events and returns, per stage name
+/* Measurement hook (bench.py `roofline`): gator_profile_enable(ctx, n) with n >= 1 brackets every stage launch of every
+ * n-th forward by a hipEvent pair recorded on the launch stream (n = 0 switches it off).  gator_profile_read synchronises those events and returns, per stage name
  * ('\n'-separated in `names`), the summed duration in ms and the number of launches since the last enable/read. */
 int gator_profile_enable(gator_ctx* ctx, int32_t on);
 int gator_profile_read(gator_ctx* ctx, char* names, int64_t names_capacity, float* total_ms, int32_t* calls,
