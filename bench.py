@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--joints', type=int, default=17)
     ap.add_argument('--impl', default=os.environ.get('GATOR_AMD_IMPL', 'fused'))
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'], help='bf16: vertex regressor on bf16 MFMA (config 3)')
+    ap.add_argument('--subbatch-variant', action='store_true', help='also time the sub-batch-streams=2 mode (extra key)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     return ap.parse_args()
@@ -188,7 +189,7 @@ def main():
                            % (B, J, ', RCCL all-gather of [%d,6890,3] vertices' % (B * world) if world > 1 else ''),
                            'batch_per_gpu': B, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world},
                 'roofline': roof}
-        if world == 1 and B >= 128:
+        if world == 1 and B >= 128 and a.subbatch_variant:
             # same workload with the library's sub-batch pipelining (two half-batches on two streams; bit-identical results).
             # Reported beside the headline, not as it: concurrent streams make per-kernel durations (and so `roofline`) ambiguous.
             m2, _, _ = build_model(J, a.impl, dev)
