@@ -467,17 +467,17 @@ __global__ __launch_bounds__(256) void k_mdr_head(const HeadArgs a) {
     const float* hf = a.hf + (size_t)b * kV * 32;
     for (int v = t; v < kV; v += 256) {
         const f32x4 q = *reinterpret_cast<const f32x4*>(hf + v * 32 + 24);
-        double x[3] = {(double)q[0], (double)q[1], (double)q[2]};
+        float x[3] = {q[0], q[1], q[2]};
         if (a.alpha) {      // LayerNorm(3)
-            const double m = (x[0] + x[1] + x[2]) / 3.0;
-            const double qq = ((x[0] - m) * (x[0] - m) + (x[1] - m) * (x[1] - m) + (x[2] - m) * (x[2] - m)) / 3.0;
-            const double rs = 1.0 / sqrt(qq + 1e-5);
-            for (int c = 0; c < 3; ++c) x[c] = (x[c] - m) * rs * (double)a.bn_w[c] + (double)a.bn_b[c];
+            const float m = (x[0] + x[1] + x[2]) / 3.0f;
+            const float qq = ((x[0] - m) * (x[0] - m) + (x[1] - m) * (x[1] - m) + (x[2] - m) * (x[2] - m)) / 3.0f;
+            const float rs = 1.0f / sqrtf(qq + 1e-5f);
+            for (int c = 0; c < 3; ++c) x[c] = (x[c] - m) * rs * a.bn_w[c] + a.bn_b[c];
         } else {            // BatchNorm1d(431) eval: channel = vertex
-            const double rs = 1.0 / sqrt((double)a.bn_var[v] + 1e-5);
-            for (int c = 0; c < 3; ++c) x[c] = (x[c] - (double)a.bn_mean[v]) * rs * (double)a.bn_w[v] + (double)a.bn_b[v];
+            const float rs = 1.0f / sqrtf(a.bn_var[v] + 1e-5f);
+            for (int c = 0; c < 3; ++c) x[c] = (x[c] - a.bn_mean[v]) * rs * a.bn_w[v] + a.bn_b[v];
         }
-        for (int c = 0; c < 3; ++c) bn[v][c] = (float)(0.5 * x[c] * (1.0 + erf(x[c] * 0.70710678118654752440)));
+        for (int c = 0; c < 3; ++c) bn[v][c] = gelu_f(x[c]);
     }
     __syncthreads();
     {   // Conv1d(431->20,k3,p1) over the xyz axis: every thread walks the (c,k) axis with coalesced weight reads
@@ -520,18 +520,20 @@ __global__ __launch_bounds__(256) void k_mdr_head(const HeadArgs a) {
             av[4 * g] = q[0]; av[4 * g + 1] = q[1]; av[4 * g + 2] = q[2]; av[4 * g + 3] = q[3];
         }
         const f32x4 tail = *reinterpret_cast<const f32x4*>(r + 24), cc = *reinterpret_cast<const f32x4*>(r + 28);
-        double mx = -1e300, p[20], l = 0.0;
-        for (int m = 0; m < 20; ++m) mx = fmax(mx, (double)av[m]);
+        float mx = -1e30f, p[20], l = 0.f;
+        for (int m = 0; m < 20; ++m) mx = fmaxf(mx, av[m]);
         for (int m = 0; m < 20; ++m) {
-            p[m] = exp((double)av[m] - mx);
+            p[m] = __builtin_amdgcn_exp2f((av[m] - mx) * kLog2e);
             l += p[m];
         }
-        const double sc = a.alpha ? pow(1.1, (double)tail[3]) : 1.0;
+        const float il = 1.0f / l;
+        // alpha = 1.1 ** scale_linear(x)  (MDR.py:162): powf via double exp keeps it exact to fp32 rounding; once per token
+        const float sc = a.alpha ? (float)exp((double)tail[3] * 0.09531017980432493) : 1.0f;
         const int cb = v >> 5, g = (v & 31) >> 3, hh = (v & 7) >> 2, j = v & 3;
         for (int c = 0; c < 3; ++c) {
-            double o = 0.0;
-            for (int m = 0; m < 20; ++m) o += (p[m] / l) * (double)bc[m][c];
-            const float val = (float)(sc * o + (double)cc[c]);
+            float o = 0.f;
+            for (int m = 0; m < 20; ++m) o += (p[m] * il) * bc[m][c];
+            const float val = sc * o + cc[c];
             a.vc[((size_t)b * kV + v) * 3 + c] = val;
             a.vcp[(((((size_t)mt * 3 + c) * kCB + cb) * 4 + g) * 64 + hh * 32 + sl) * 4 + j] = val;
         }
