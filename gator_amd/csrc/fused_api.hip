@@ -175,7 +175,7 @@ int fused_create(gator_ctx* c, void* stream) {
     }
     if (!(c->parts & GATOR_PART_MDR)) return GATOR_OK;
     const size_t n_up = (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)64 * kTile;
-    const size_t total = n_up + 3 * n_layer + 14 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
+    const size_t total = n_up + 3 * n_layer + 24 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
     GATOR_HIP_CHECK(hipMalloc(&f->wbuf, total * sizeof(float)));
     f->wbuf_floats = total;
     float* p = f->wbuf;
@@ -233,6 +233,17 @@ int fused_create(gator_ctx* c, void* stream) {
         int rc = fused_pack_linear(w.jfeat_w, 133, 1, 64, 133, dst, stream);
         if (rc) return rc;
         f->jfeat_p = dst;
+        float* d128 = take(8 * kTile);                                  // feat columns 5..132 for the GAT-kernel epilogue
+        rc = fused_pack_linear(w.jfeat_w + 5, 133, 1, 64, 128, d128, stream);
+        if (rc) return rc;
+        f->jfeat128_p = d128;
+        const std::vector<float> jw = d2h(w.jfeat_w, 64 * 133);
+        std::vector<float> j5(5 * 64);
+        for (int i = 0; i < 5; ++i)
+            for (int n = 0; n < 64; ++n) j5[i * 64 + n] = jw[n * 133 + i];
+        float* j5d = take(kTile);
+        GATOR_HIP_CHECK(hipMemcpy(j5d, j5.data(), j5.size() * sizeof(float), hipMemcpyHostToDevice));
+        f->jfeat5 = j5d;
         const std::vector<float> pj = d2h(w.pos_j, (size_t)(c->J + 1) * 64);
         std::vector<float> pt(2 * kTile);
         for (int nb = 0; nb < 2; ++nb)
@@ -391,12 +402,17 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
     int rc = fused_ensure_ws(c, B);
     if (rc) return rc;
     FusedState* f = c->fused;
-    rc = fused_gat_forward(c, pose2d, B, f->xout, f->feat, stream);
+    {   // x_out [B,3J] IS pose3d [B,J,3]: the kernel writes the caller's buffer; its epilogue also produces the MDR joint K/V
+        StageTimer tm(c, "gat", stream);
+        rc = launch_gat(c, f, pose2d, B, pose3d, f->feat, stream, true);
+    }
     if (rc) return rc;
     c->taps["feat"] = {f->feat, (int64_t)B * c->J * kC};
-    rc = basic_build_pc(c, pose2d, f->xout, f->feat, B, f->pc, pose3d, stream);
+    rc = launch_mdr(c, f, nullptr, B, stream, pose3d, pose2d);      // pose_combine is never materialised on this path
     if (rc) return rc;
-    return fused_mdr_forward_impl(c, f->pc, B, verts, stream, bf16);
+    if (bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);
+    StageTimer tm(c, "upsample", stream);
+    return launch_upsample(f, c, B, verts, stream);
 }
 
 }  // namespace gator

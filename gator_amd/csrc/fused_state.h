@@ -56,6 +56,8 @@ struct FusedState : FusedWs {
     void* aux_stream = nullptr;
     void *ev_fork = nullptr, *ev_join = nullptr;
     const float* jfeat_p = nullptr;     // get_joint_feature.weight packed [2 nb][5 kb]
+    const float* jfeat5 = nullptr;      // its columns 0..4 (pose2d, pose3d/1000) as [5][64]
+    const float* jfeat128_p = nullptr;  // its columns 5..132 (feat) packed [2 nb][4 kb]
     const float* posj_T = nullptr;      // [2] T-layout tiles of pos_j_id_embed[1..J]      // [3][64]            pose3d part of get_verts_feature (columns 3..5), row-major [i][ch]
 };
 
@@ -66,13 +68,13 @@ inline int nblk32(int n) { return (n + 31) / 32; }
 int launch_pack_vc(const float* vc, int B, float* vcp, void* stream);
 int launch_upsample(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream);
 // gat_fused.hip
-int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream);
+int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue = false);
 // upsample_bf16.hip
 size_t upsample_bf16_weight_elems();
 size_t upsample_bf16_vcp_elems(int B);
 int pack_upsample_bf16(const float* up_w, void* dst, void* stream);
 int launch_upsample_bf16(const FusedState* f, const gator_ctx* c, const float* vc, int B, float* verts, void* stream);
 // mdr_fused.hip
-int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream);
+int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream, const float* x_out = nullptr, const float* pose2d = nullptr);
 
 }  // namespace gator

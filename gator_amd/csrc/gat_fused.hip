@@ -32,6 +32,11 @@ struct GatArgs {
     const float *norm_w, *norm_b, *lifter_p, *lifter_b;                        // lifter_p: [3J][4 kb] tiles
     GatBlockP blk[kDepth];
     float *x_out, *feat;
+    // optional epilogue (full forward): the MDR joint tokens and their per-layer cross-attention K/V (MDR.py:130-134,37-38,65),
+    // so that no separate launch has to re-read pose_combine.  jkv == nullptr: skipped (stand-alone GAT entry point).
+    float* jkv;
+    const float *jf5, *jf_p, *jf_b, *posj_T;       // get_joint_feature: columns 0..4 as [5][64], columns 5..132 packed [2][4], bias
+    const float *j_n1w[3], *j_n1b[3], *j_wk_p[3], *j_wv_p[3];
     unsigned long long* stamps;     // diagnostic only (GATOR_GAT_STAMPS=1): per-phase cycle sums of workgroup 0, wave 0
 };
 
@@ -51,6 +56,12 @@ __device__ __forceinline__ f32x16 load_chanvec_L(const float* V, int off, int h)
     return v;
 }
 
+__device__ __forceinline__ float row_sum32x2(const f32x16& a, const f32x16& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += a[r] + b[r];
+    return s + xhalf(s);
+}
 __device__ __forceinline__ float row_sum128(const f32x16 (&x)[4]) {
     float s = 0.f;
 #pragma unroll
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         GAT_STAMP(8)
     }
     // ---------------- tail: LN -> GELU -> feat ; lifter Linear(128J -> 3J)  (GAT.py:148-152)
+    const int tok = lane & 31;
     {
         f32x16 x[4];
 #pragma unroll
@@ -415,7 +427,6 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) mine[r] = gelu_f(mine[r]);      // each wave finishes only its own channel block
         store_block(R + wave * kTile, lane, mine);
-        const int tok = lane & 31;
         if (tok < J) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -426,6 +437,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             }
         }
     }
+    float* XO = R + 6 * kTile;            // x_out of this sample (3J floats), for the joint-token epilogue
     f32x16 wl[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) wl[kb] = load_block(a.lifter_p + ((size_t)wave * 4 + kb) * kTile, lane);
@@ -448,9 +460,58 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             s += p;
         }
         for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
-        if (lane == 0) a.x_out[(size_t)b * 3 * J + o] = s + a.lifter_b[o];
+        if (lane == 0) {
+            const float xo = s + a.lifter_b[o];
+            a.x_out[(size_t)b * 3 * J + o] = xo;
+            XO[o] = xo;
+        }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) wl[kb] = nx[kb];
+    }
+    if (a.jkv) {
+        // ---------------- MDR joint tokens: jf = Linear(133->64)(cat(pose2d, pose3d/1000, feat)) + pos_j ; per LBF layer
+        // k = wk(LN1(jf)), v = wv(LN1(jf)) written as MFMA operand tiles (same layout as k_mdr_joint)
+        __syncthreads();                                            // XO complete
+        float* JF = R + 4 * kTile;                                  // 2 tiles
+        if (wave < 2) {
+            f32x16 acc = load_chanvec_S(a.jf_b, 32 * wave, h) + load_block(a.posj_T + (size_t)wave * kTile, lane), ac1 = zero16();
+            const int tk = tok < J ? tok : 0;
+            const float* p2 = a.pose2d + ((size_t)b * J + tk) * 2;
+            const float pin[5] = {p2[0], p2[1], XO[tk * 3] / 1000.f, XO[tk * 3 + 1] / 1000.f, XO[tk * 3 + 2] / 1000.f};   // GATOR.py:19
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc += load_chanvec_S(a.jf5 + i * 64, 32 * wave, h) * pin[i];
+            mma2_T(load_wtile(a.jf_p, wave * 4 + 0, lane), ft[0], acc, load_wtile(a.jf_p, wave * 4 + 1, lane), ft[1], ac1);
+            mma2_T(load_wtile(a.jf_p, wave * 4 + 2, lane), ft[2], acc, load_wtile(a.jf_p, wave * 4 + 3, lane), ft[3], ac1);
+            store_block(JF + wave * kTile, lane, acc + ac1);
+        }
+        __syncthreads();
+        f32x16 jf[2];
+        jf[0] = load_block(JF, lane);
+        jf[1] = load_block(JF + kTile, lane);
+        const float mean = (row_sum32x2(jf[0], jf[1])) * (1.0f / 64.0f);
+        const f32x16 d0 = jf[0] - mean, d1 = jf[1] - mean;
+        const float rstd = 1.0f / sqrtf(row_sum32x2(d0 * d0, d1 * d1) * (1.0f / 64.0f) + 1e-5f);
+        // 12 jobs (layer, k|v, channel block) over the 4 waves
+#pragma unroll 1
+        for (int job = wave * 3; job < wave * 3 + 3; ++job) {
+            const int li = job >> 2, kv = (job >> 1) & 1, nb = job & 1;
+            f32x16 fz[2];
+            fz[0] = d0 * rstd * load_chanvec_S(a.j_n1w[li], 0, h) + load_chanvec_S(a.j_n1b[li], 0, h);
+            fz[1] = d1 * rstd * load_chanvec_S(a.j_n1w[li], 32, h) + load_chanvec_S(a.j_n1b[li], 32, h);
+            float* out = a.jkv + (((size_t)b * 3 + li) * 4 + kv * 2 + nb) * kTile;
+            f32x16 r0 = zero16(), r1 = zero16();
+            if (kv == 0) {
+                mma2_T(load_wtile(a.j_wk_p[li], nb * 2 + 0, lane), fz[0], r0, load_wtile(a.j_wk_p[li], nb * 2 + 1, lane), fz[1], r1);
+                r0 += r1;
+                if (tok >= J) r0 = zero16();                       // joints >= J: zero rows (masked in the softmax anyway)
+            } else {
+                mma2_C(load_wtile(a.j_wv_p[li], nb * 2 + 0, lane), fz[0], r0, load_wtile(a.j_wv_p[li], nb * 2 + 1, lane), fz[1], r1);
+                r0 += r1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) r0[r] = (kap(r) + 4 * h < J) ? r0[r] : 0.f;
+            }
+            store_block(out, lane, r0);
+        }
     }
     GAT_STAMP(9)
     if (a.stamps && b == 0 && t == 0)
@@ -459,7 +520,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
 
 }  // namespace
 
-int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream) {
+int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue) {
     GatArgs a;
     const Weights& w = c->w;
     a.B = B; a.J = c->J; a.pose2d = pose2d;
@@ -476,6 +537,11 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         (void)r;
     }
     a.x_out = x_out; a.feat = feat;
+    a.jkv = nullptr;
+    if (joint_epilogue) {
+        a.jkv = f->jkv; a.jf5 = f->jfeat5; a.jf_p = f->jfeat128_p; a.jf_b = w.jfeat_b; a.posj_T = f->posj_T;
+        for (int i = 0; i < 3; ++i) { a.j_n1w[i] = w.lay[i].n1w; a.j_n1b[i] = w.lay[i].n1b; a.j_wk_p[i] = f->lay[i].wk; a.j_wv_p[i] = f->lay[i].wv; }
+    }
     a.stamps = nullptr;
     static const bool want_stamps = getenv("GATOR_GAT_STAMPS") != nullptr;
     unsigned long long* d_st = nullptr;

@@ -35,7 +35,8 @@ struct MdrArgs {
     const float *vf_in, *q_in, *k_in, *v_in;
     float *vf_out, *q_out, *k_out, *v_out;
     const float* jkv;        // [B][3][2][2][kTile]
-    const float* pc;         // [B][J][133]
+    const float* pc;         // [B][J][133]  (stand-alone MDR entry) or nullptr when x_out is given
+    const float* xout;       // [B][3J] pose3d in mm (full forward: pose_combine is never materialised)
     const int32_t* vj;       // [431]
     const float *tok_base, *tok_w3;
     const float *head_w, *head_b;
@@ -244,8 +245,14 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         B = ldw2(w.wq, 2, 3, lane);
         // verts tokens = Linear(6->64)([v431, pose3d[vj]/1000]) + pos_v   (MDR.py:126-137); the v431/bias/pos part is folded
         const int tk = token < kV ? token : kV - 1;
-        const float* p3 = a.pc + ((size_t)b * a.J + a.vj[tk]) * 133 + 2;
-        const float x0 = p3[0], x1 = p3[1], x2 = p3[2];
+        float x0, x1, x2;
+        if (a.xout) {             // pose3d / 1000 (GATOR.py:19), same fp32 division as the reference
+            const float* p3 = a.xout + ((size_t)b * a.J + a.vj[tk]) * 3;
+            x0 = p3[0] / 1000.f; x1 = p3[1] / 1000.f; x2 = p3[2] / 1000.f;
+        } else {
+            const float* p3 = a.pc + ((size_t)b * a.J + a.vj[tk]) * 133 + 2;
+            x0 = p3[0]; x1 = p3[1]; x2 = p3[2];
+        }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             f32x16 v = load_block(a.tok_base + ((size_t)t * 2 + nb) * kTile, lane);
@@ -554,17 +561,18 @@ LayerW make_layer(const FusedState* f, const gator_ctx* c, int li) {
 }  // namespace
 
 // pc [B,J,133] (reference layout) -> f->vc [B,431,3] (vert431) ; taps: f->lbf
-int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream) {
+int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream, const float* x_out, const float* pose2d) {
+    (void)pose2d;
     hipStream_t st = (hipStream_t)stream;
     const Weights& w = c->w;
     JointArgs ja;
     ja.pc = pc; ja.jw_p = f->jfeat_p; ja.jb = w.jfeat_b; ja.posj_T = f->posj_T; ja.jkv = f->jkv; ja.J = c->J;
     for (int i = 0; i < 3; ++i) { ja.n1w[i] = w.lay[i].n1w; ja.n1b[i] = w.lay[i].n1b; ja.wk_p[i] = f->lay[i].wk; ja.wv_p[i] = f->lay[i].wv; }
-    { StageTimer tm(c, "mdr_joint", stream); k_mdr_joint<<<B, 128, 0, st>>>(ja); }
+    if (pc) { StageTimer tm(c, "mdr_joint", stream); k_mdr_joint<<<B, 128, 0, st>>>(ja); }    // else: done by k_gat's epilogue
     const size_t per = (size_t)f->cap * kVT * 2 * kTile;      // one [B][14][2] tile set
     float* set[2][4] = {{f->vf, f->q, f->k, f->v}, {f->vf + per, f->q + per, f->k + per, f->v + per}};
     MdrArgs a{};
-    a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
+    a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.xout = pc ? nullptr : x_out; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
     a.head_w = f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = f->lbf;
     const int nwg = (B * kVT + 3) / 4;
     static const bool want_stamps = getenv("GATOR_MDR_STAMPS") != nullptr;
