@@ -32,7 +32,8 @@ int fused_ensure_ws(gator_ctx* c, int B) {
     const size_t o_vcp = take((size_t)MT * 3 * kCB * kTile), o_vc = take((size_t)cap * kV * 3), o_vf = take(2 * tiles),
                  o_q = take(2 * tiles), o_k = take(2 * tiles), o_v = take(2 * tiles), o_jkv = take((size_t)cap * 12 * kTile),
                  o_hf = take((size_t)cap * kV * 32), o_lbf = take((size_t)cap * kV * kE), o_feat = take((size_t)cap * J * kC),
-                 o_xout = take((size_t)cap * J * 3), o_pc = take((size_t)cap * J * 133);
+                 o_xout = take((size_t)cap * J * 3), o_pc = take((size_t)cap * J * 133),
+                 o_vcp3 = take(upsample_x3_vcp_elems(cap) / 2);
     GATOR_HIP_CHECK(hipMalloc(&f->ws, n * sizeof(float)));
     GATOR_HIP_CHECK(hipMemset(f->ws, 0, n * sizeof(float)));
     GATOR_HIP_CHECK(hipDeviceSynchronize());      // the memset runs on the null stream; a non-blocking stream would not wait for it
@@ -40,7 +41,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
     f->cap = cap;
     f->vcp = f->ws + o_vcp; f->vc = f->ws + o_vc; f->vf = f->ws + o_vf; f->q = f->ws + o_q; f->k = f->ws + o_k;
     f->v = f->ws + o_v; f->jkv = f->ws + o_jkv; f->hf = f->ws + o_hf; f->lbf = f->ws + o_lbf; f->feat = f->ws + o_feat;
-    f->xout = f->ws + o_xout; f->pc = f->ws + o_pc;
+    f->xout = f->ws + o_xout; f->pc = f->ws + o_pc; f->vcp3 = f->ws + o_vcp3;
     return GATOR_OK;
 }
 
@@ -174,7 +175,10 @@ int fused_create(gator_ctx* c, void* stream) {
         if (rc) return rc;
     }
     if (!(c->parts & GATOR_PART_MDR)) return GATOR_OK;
-    const size_t n_up = (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)64 * kTile;
+    // vertex regressor: split-precision bf16 planes by default; GATOR_UPSAMPLE_X3=0 keeps the fp32-input MFMA kernel (A/B runs)
+    const char* x3env = getenv("GATOR_UPSAMPLE_X3");
+    f->x3 = !(x3env && atoi(x3env) == 0);
+    const size_t n_up = f->x3 ? 0 : (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)64 * kTile;
     const size_t total = n_up + 3 * n_layer + 24 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
     GATOR_HIP_CHECK(hipMalloc(&f->wbuf, total * sizeof(float)));
     f->wbuf_floats = total;
@@ -182,11 +186,17 @@ int fused_create(gator_ctx* c, void* stream) {
     auto take = [&](size_t k) { float* r = p; p += k; return r; };
     // upsample_conv.weight [6890][431][3] -> one packed [216][14] tile grid per tap
     float* up = take(n_up);
-    for (int tap = 0; tap < 3; ++tap) {
-        int rc = fused_pack_linear(w.up_w + tap, (int64_t)kV * 3, 3, kNV, kV, up + (size_t)tap * kOB * kCB * kTile, stream);
+    if (f->x3) {
+        GATOR_HIP_CHECK(hipMalloc(&f->up_w3, upsample_x3_weight_elems() * 2));
+        int rc = pack_upsample_x3(w.up_w, f->up_w3, stream);
         if (rc) return rc;
+    } else {
+        for (int tap = 0; tap < 3; ++tap) {
+            int rc = fused_pack_linear(w.up_w + tap, (int64_t)kV * 3, 3, kNV, kV, up + (size_t)tap * kOB * kCB * kTile, stream);
+            if (rc) return rc;
+        }
+        f->up_w = up;
     }
-    f->up_w = up;
     for (int li = 0; li < 3; ++li) {
         const MdrLayerW& r = w.lay[li];
         MdrLayerP& q = f->lay[li];
@@ -292,6 +302,7 @@ void fused_destroy(gator_ctx* c) {
     if (c->fused->wbuf) (void)hipFree(c->fused->wbuf);
     if (c->fused->gbuf) (void)hipFree(c->fused->gbuf);
     if (c->fused->up_w16) (void)hipFree(c->fused->up_w16);
+    if (c->fused->up_w3) (void)hipFree(c->fused->up_w3);
     delete c->fused;
     c->fused = nullptr;
 }
@@ -305,10 +316,10 @@ static int fused_upsample_in(gator_ctx* c, const float* vert431, int B, float* v
     int rc = fused_ensure_ws(c, B);
     if (rc) return rc;
     FusedState* f = c->fused;
-    rc = launch_pack_vc(vert431, B, f->vcp, stream);
+    rc = f->x3 ? launch_pack_vc_x3(vert431, B, f->cap, f->vcp3, stream) : launch_pack_vc(vert431, B, f->vcp, stream);
     if (rc) return rc;
     StageTimer tm(c, "upsample", stream);
-    return launch_upsample(f, c, B, verts, stream);
+    return f->x3 ? launch_upsample_x3(f, c, B, verts, stream) : launch_upsample(f, c, B, verts, stream);
 }
 
 int fused_upsample(gator_ctx* c, const float* vert431, int B, float* verts, void* stream) {
@@ -348,11 +359,11 @@ static int fused_mdr_forward_impl(gator_ctx* c, const float* pc, int B, float* v
     int rc = fused_ensure_ws(c, B);
     if (rc) return rc;
     FusedState* f = c->fused;
-    rc = launch_mdr(c, f, pc, B, stream);        // also writes the packed vertex-GEMM operand f->vcp
+    rc = launch_mdr(c, f, pc, B, stream);        // also writes the packed vertex-GEMM operand f->vcp / f->vcp3
     if (rc) return rc;
     if (bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);
     StageTimer tm(c, "upsample", stream);
-    return launch_upsample(f, c, B, verts, stream);
+    return f->x3 ? launch_upsample_x3(f, c, B, verts, stream) : launch_upsample(f, c, B, verts, stream);
 }
 
 int fused_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* stream) {
@@ -412,7 +423,7 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
     if (rc) return rc;
     if (bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);
     StageTimer tm(c, "upsample", stream);
-    return launch_upsample(f, c, B, verts, stream);
+    return f->x3 ? launch_upsample_x3(f, c, B, verts, stream) : launch_upsample(f, c, B, verts, stream);
 }
 
 }  // namespace gator

@@ -25,7 +25,8 @@ struct FusedWs {
     float* ws = nullptr;
     size_t ws_floats = 0;
     int cap = 0;
-    float *vcp = nullptr;               // [MT][3][kCB][4][64][4]  packed vert431 (A operand of the upsample GEMM)
+    float *vcp = nullptr;               // [MT][3][kCB][4][64][4]  packed vert431 (A operand of the fp32-MFMA upsample GEMM)
+    void* vcp3 = nullptr;               // bf16 [plane 3][MT][3][28][64][8]  hi/mid/lo split of vert431 (split-precision GEMM)
     float *vc = nullptr;                // [B][431][3]
     float *vf = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;   // [B][14][2][kTile] each
     float *jkv = nullptr;               // [B][3 layers][2 (k,v)][2 heads][kTile]
@@ -44,6 +45,8 @@ struct FusedState : FusedWs {
     size_t wbuf_floats = 0;
     // upsample: Wp[tap][ob][cb][4][64][4]
     const float* up_w = nullptr;
+    void* up_w3 = nullptr;              // bf16 [plane 3][tap][ob][28][64][8]  hi/mid/lo split of upsample_conv.weight
+    bool x3 = true;                     // split-precision vertex regressor (GATOR_UPSAMPLE_X3=0: fp32-input MFMA kernel)
     void* up_w16 = nullptr;             // bf16 [tap][ob][28][64][8] (packed lazily on the first bf16 call)
     // MDR
     MdrLayerP lay[3];
@@ -74,6 +77,12 @@ size_t upsample_bf16_weight_elems();
 size_t upsample_bf16_vcp_elems(int B);
 int pack_upsample_bf16(const float* up_w, void* dst, void* stream);
 int launch_upsample_bf16(const FusedState* f, const gator_ctx* c, const float* vc, int B, float* verts, void* stream);
+// upsample_x3.hip
+size_t upsample_x3_weight_elems();
+size_t upsample_x3_vcp_elems(int B);
+int pack_upsample_x3(const float* up_w, void* dst, void* stream);
+int launch_pack_vc_x3(const float* vc, int B, int cap, void* vcp3, void* stream);
+int launch_upsample_x3(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream);
 // mdr_fused.hip
 int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream, const float* x_out = nullptr, const float* pose2d = nullptr);
 

@@ -464,6 +464,8 @@ __global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
 struct HeadArgs {
     const float *hf, *bn_w, *bn_b, *bn_mean, *bn_var, *bconv_w, *bconv_b;
     float *vc, *vcp;
+    __bf16* vcp3;           // non-null: write the hi/mid/lo bf16 planes of the split-precision vertex GEMM instead of vcp
+    size_t vcp3_plane;
     int alpha;
 };
 __global__ __launch_bounds__(256) void k_mdr_head(const HeadArgs a) {
@@ -542,7 +544,16 @@ __global__ __launch_bounds__(256) void k_mdr_head(const HeadArgs a) {
             for (int m = 0; m < 20; ++m) o += (p[m] * il) * bc[m][c];
             const float val = sc * o + cc[c];
             a.vc[((size_t)b * kV + v) * 3 + c] = val;
-            a.vcp[(((((size_t)mt * 3 + c) * kCB + cb) * 4 + g) * 64 + hh * 32 + sl) * 4 + j] = val;
+            if (a.vcp3) {       // exact three-way bf16 split, in k_upsample_x3's operand order [plane][mt][l'][v/16][lane][v%8]
+                const __bf16 hi = (__bf16)val;
+                const float r1 = val - (float)hi;
+                const __bf16 mid = (__bf16)r1;
+                const __bf16 lo = (__bf16)(r1 - (float)mid);
+                const size_t e = ((((size_t)mt * 3 + c) * 28 + (v >> 4)) * 64 + ((v >> 3) & 1) * 32 + sl) * 8 + (v & 7);
+                a.vcp3[e] = hi; a.vcp3[a.vcp3_plane + e] = mid; a.vcp3[2 * a.vcp3_plane + e] = lo;
+            } else {
+                a.vcp[(((((size_t)mt * 3 + c) * kCB + cb) * 4 + g) * 64 + hh * 32 + sl) * 4 + j] = val;
+            }
         }
     }
 }
@@ -609,7 +620,9 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     }
     HeadArgs ha;
     ha.hf = f->hf; ha.bn_w = w.bn_w; ha.bn_b = w.bn_b; ha.bn_mean = w.bn_mean; ha.bn_var = w.bn_var;
-    ha.bconv_w = w.bconv_w; ha.bconv_b = w.bconv_b; ha.vc = f->vc; ha.vcp = f->vcp; ha.alpha = c->alpha;
+    ha.bconv_w = w.bconv_w; ha.bconv_b = w.bconv_b; ha.vc = f->vc; ha.vcp = f->vcp;
+    ha.vcp3 = f->x3 ? (__bf16*)f->vcp3 : nullptr; ha.vcp3_plane = upsample_x3_vcp_elems(f->cap) / 3;     // plane stride fixed by the workspace capacity
+    ha.alpha = c->alpha;
     { StageTimer tm(c, "mdr_head", stream); k_mdr_head<<<B, 256, 0, st>>>(ha); }
     GATOR_HIP_CHECK(hipGetLastError());
     c->taps["mdr_lbf2"] = {f->lbf, (int64_t)B * kV * kE};
