@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "fused_state.h"
+#include "x3_common.h"
 
 namespace gator {
 namespace {
@@ -30,7 +31,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
     size_t n = 0;
     auto take = [&](size_t k) { size_t o = n; n += (k + 63) & ~(size_t)63; return o; };
     const size_t o_vcp = take((size_t)MT * 3 * kCB * kTile), o_vc = take((size_t)cap * kV * 3), o_vf = take(2 * tiles),
-                 o_q = take(2 * tiles), o_k = take(2 * tiles), o_v = take(2 * tiles), o_jkv = take((size_t)cap * 12 * kTile),
+                 o_q = take(3 * tiles), o_k = take(3 * tiles), o_v = take(3 * tiles) /* q/k/v sized for X3 tiles (1.5x) */, o_jkv = take((size_t)cap * 12 * kTile),
                  o_hf = take((size_t)cap * kV * 32), o_lbf = take((size_t)cap * kV * kE), o_feat = take((size_t)cap * J * kC),
                  o_xout = take((size_t)cap * J * 3), o_pc = take((size_t)cap * J * 133),
                  o_vcp3 = take(upsample_x3_vcp_elems(cap) / 2);
@@ -114,6 +115,16 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
         });
         q.f1b = upload(t2);
     }
+    {   // split-precision image of every block's weight grids (the tables mc/md/aoffT/f1b in between are converted too, unused)
+        const char* e = getenv("GATOR_GAT_X3");
+        f->gat_x3 = e && atoi(e) != 0;      // off by default: measured no faster (the weight stream, not the MFMA, bounds k_gat)
+        if (f->gat_x3) {
+            const int64_t ntiles = (p - f->gblk[0].qkv) / kTile;
+            GATOR_HIP_CHECK(hipMalloc(&f->gxbuf, (size_t)ntiles * kTileX3 * sizeof(float)));
+            int rc = fused_repack_x3(f->gblk[0].qkv, f->gxbuf, ntiles, stream);
+            if (rc) return rc;
+        }
+    }
     std::vector<float> bt(8 * kTile), mt(kTile);
     for (int hd = 0; hd < kH; ++hd)
         fill_tile(bt.data() + (size_t)hd * kTile, [&](int t, int j) { return (t < J && j < J) ? hb[((size_t)hd * J + t) * J + j] : 0.f; });
@@ -178,6 +189,8 @@ int fused_create(gator_ctx* c, void* stream) {
     // vertex regressor: split-precision bf16 planes by default; GATOR_UPSAMPLE_X3=0 keeps the fp32-input MFMA kernel (A/B runs)
     const char* x3env = getenv("GATOR_UPSAMPLE_X3");
     f->x3 = !(x3env && atoi(x3env) == 0);
+    const char* mx3 = getenv("GATOR_MDR_X3");
+    f->mdr_x3 = !(mx3 && atoi(mx3) == 0);
     const size_t n_up = f->x3 ? 0 : (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)64 * kTile;
     const size_t total = n_up + 3 * n_layer + 24 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
     GATOR_HIP_CHECK(hipMalloc(&f->wbuf, total * sizeof(float)));
@@ -301,6 +314,7 @@ void fused_destroy(gator_ctx* c) {
     if (c->fused->ev_join) (void)hipEventDestroy((hipEvent_t)c->fused->ev_join);
     if (c->fused->wbuf) (void)hipFree(c->fused->wbuf);
     if (c->fused->gbuf) (void)hipFree(c->fused->gbuf);
+    if (c->fused->gxbuf) (void)hipFree(c->fused->gxbuf);
     if (c->fused->up_w16) (void)hipFree(c->fused->up_w16);
     if (c->fused->up_w3) (void)hipFree(c->fused->up_w3);
     delete c->fused;

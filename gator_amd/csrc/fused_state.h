@@ -46,6 +46,9 @@ struct FusedState : FusedWs {
     // upsample: Wp[tap][ob][cb][4][64][4]
     const float* up_w = nullptr;
     void* up_w3 = nullptr;              // bf16 [plane 3][tap][ob][28][64][8]  hi/mid/lo split of upsample_conv.weight
+    bool gat_x3 = false;                // GAT linears on split-precision bf16 MFMA (experiment, GATOR_GAT_X3=1)
+    float* gxbuf = nullptr;             // X3 tiles of the GAT block weights, tile-for-tile image of gbuf from gblk[0].qkv on
+    bool mdr_x3 = true;                 // MDR self-attention on split-precision bf16 MFMA (GATOR_MDR_X3=0: fp32-input MFMA)
     bool x3 = true;                     // split-precision vertex regressor (GATOR_UPSAMPLE_X3=0: fp32-input MFMA kernel)
     void* up_w16 = nullptr;             // bf16 [tap][ob][28][64][8] (packed lazily on the first bf16 call)
     // MDR

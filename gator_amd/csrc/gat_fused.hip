@@ -10,6 +10,7 @@
 // attention (modules.py:121-138) keeps scores, softmax and P.V in registers, two heads per wave.
 #include "fused_common.h"
 #include "fused_state.h"
+#include "x3_common.h"
 
 #include <cstdlib>
 
@@ -19,7 +20,8 @@ namespace {
 constexpr float kLog2eG = 1.4426950408889634f;
 
 struct GatBlockP {   // per-GATBlock packed tiles + reference-layout vectors
-    const float *qkv, *proj, *w0, *w1, *lin0, *lin1, *back, *fc1, *fc2;      // packed [NB][KB] tile grids
+    const float *qkv, *proj, *w0, *w1, *lin0, *lin1, *back, *fc1, *fc2;      // packed [NB][KB] tile grids (fp32 tiles, or X3 tiles)
+    const float* back32;                                                       // linearback always also as fp32 tiles (its 16-wide k tail)
     const float *mc, *md, *aoffT, *f1b;                                        // packed tables (see GatTables)
     const float* vecs;                                                         // V_TOTAL floats, order above
 };
@@ -114,16 +116,38 @@ __device__ __forceinline__ f32x16 dot16_C(const WTile& w, const f32x16& x) {
     return e + o;
 }
 
-struct WG4 { WTile t[4]; };     // one 4-tile weight group = 16 float4 per lane (64 VGPRs)
-__device__ __forceinline__ WG4 ldg4(const float* __restrict__ Wp, int tile0, int lane) {
-    WG4 g;
+// ---- operand abstraction: X = false -> fp32-input MFMA on packed fp32 tiles; X = true -> split-precision bf16 MFMA on X3 tiles
+template <bool X> struct Op;
+template <> struct Op<false> { typedef f32x16 T; typedef WTile W; static constexpr int kT = kTile; };
+template <> struct Op<true> { typedef X3 T; typedef X3 W; static constexpr int kT = kTileX3; };
+
+template <bool X> __device__ __forceinline__ typename Op<X>::T mkop(const f32x16& v);
+template <> __device__ __forceinline__ f32x16 mkop<false>(const f32x16& v) { return v; }
+template <> __device__ __forceinline__ X3 mkop<true>(const f32x16& v) { return x3_split(v); }
+template <bool X> __device__ __forceinline__ typename Op<X>::T ldop(const float* p, int lane);
+template <> __device__ __forceinline__ f32x16 ldop<false>(const float* p, int lane) { return load_block(p, lane); }
+template <> __device__ __forceinline__ X3 ldop<true>(const float* p, int lane) { return x3_load(p, lane); }
+template <bool X> __device__ __forceinline__ void stop(float* p, int lane, const f32x16& v) {
+    if constexpr (X) x3_store(p, lane, x3_split(v)); else store_block(p, lane, v);
+}
+template <bool X> __device__ __forceinline__ typename Op<X>::W ldw1(const float* __restrict__ Wp, int tile, int lane);
+template <> __device__ __forceinline__ WTile ldw1<false>(const float* __restrict__ Wp, int tile, int lane) { return load_wtile(Wp, tile, lane); }
+template <> __device__ __forceinline__ X3 ldw1<true>(const float* __restrict__ Wp, int tile, int lane) { return x3_load(Wp + (size_t)tile * kTileX3, lane); }
+__device__ __forceinline__ f32x16 dotC(const WTile& w, const f32x16& x) { return dot16_C(w, x); }
+__device__ __forceinline__ f32x16 dotC(const X3& w, const X3& x) { return x3_mma(x, w, zero16()); }
+
+// one 4-tile weight group (K = 128 of one 32-wide output block): 64 VGPRs fp32, 96 VGPRs X3
+template <bool X> struct Grp { typename Op<X>::W t[4]; };
+template <bool X> __device__ __forceinline__ Grp<X> ldg4(const float* __restrict__ Wp, int tile0, int lane) {
+    Grp<X> g;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g.t[i] = load_wtile(Wp, tile0 + i, lane);
+    for (int i = 0; i < 4; ++i) g.t[i] = ldw1<X>(Wp, tile0 + i, lane);
     return g;
 }
-// sum over 4 k-blocks with two independent 64-term chains (fp32 accuracy); operands in registers, T- or C-layout output
+// sum over 4 k-blocks, operands in registers, T- or C-layout output.  fp32: two independent 64-term chains; X3: one chain
+// (the bf16 MFMA sums 16 products internally, and a dependent chain of it issues back to back)
 template <bool CL>
-__device__ __forceinline__ f32x16 lin4r(const WG4& g, const f32x16 (&xs)[4], f32x16 init) {
+__device__ __forceinline__ f32x16 lin4r(const Grp<false>& g, const f32x16 (&xs)[4], f32x16 init) {
     f32x16 a0 = init, a1 = zero16();
     if (CL) {
         mma2_C(g.t[0], xs[0], a0, g.t[1], xs[1], a1);
@@ -134,20 +158,33 @@ __device__ __forceinline__ f32x16 lin4r(const WG4& g, const f32x16 (&xs)[4], f32
     }
     return a0 + a1;
 }
+template <bool CL>
+__device__ __forceinline__ f32x16 lin4r(const Grp<true>& g, const X3 (&xs)[4], f32x16 init) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) init = CL ? x3_mma(xs[i], g.t[i], init) : x3_mma(g.t[i], xs[i], init);
+    return init;
+}
 // same with the 4 operand tiles read from LDS (consecutive tiles at T)
-__device__ __forceinline__ f32x16 lin4l(const WG4& g, const float* T, int lane, f32x16 init) {
+__device__ __forceinline__ f32x16 lin4l(const Grp<false>& g, const float* T, int lane, f32x16 init) {
     f32x16 a0 = init, a1 = zero16();
     mma2_T(g.t[0], load_block(T + 0 * kTile, lane), a0, g.t[1], load_block(T + 1 * kTile, lane), a1);
     mma2_T(g.t[2], load_block(T + 2 * kTile, lane), a0, g.t[3], load_block(T + 3 * kTile, lane), a1);
     return a0 + a1;
 }
+__device__ __forceinline__ f32x16 lin4l(const Grp<true>& g, const float* T, int lane, f32x16 init) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) init = x3_mma(g.t[i], x3_load(T + i * kTileX3, lane), init);
+    return init;
+}
 
+template <bool X3K>
 __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* X = lds;                       // residual stream, 4 tiles (T-layout)
-    float* R = lds + 4 * kTile;           // 16 tiles of phase-local scratch
-    float *AT = R, *SB = R + 4 * kTile, *FB = R + 8 * kTile, *F1P = R + 12 * kTile, *HB = R;
-    float* V = lds + 20 * kTile;          // per-block vectors (V_TOTAL floats)
+    constexpr int TA = Op<X3K>::kT;       // floats per operand tile in LDS (fp32 block, or X3 planes)
+    float* R = lds + 4 * kTile;           // phase-local scratch: AT | SB | FB (4 operand tiles each) | F1P (4 fp32 tiles), aliased by HB (16)
+    float *AT = R, *SB = R + 4 * TA, *FB = R + 8 * TA, *F1P = R + 12 * TA, *HB = R;
+    float* V = R + 16 * TA;               // per-block vectors (V_TOTAL floats)
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // provably wave-uniform (scalar loads, scalar addressing)
     unsigned long long st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = a.stamps ? clock64() : 0;
@@ -212,8 +249,8 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
     // 4-tile weight group (16 x 1 KiB wave loads) is always in flight while the current one feeds the MFMAs: two group
     // buffers G0/G1 alternate through the fixed per-block order q,k,v,W0,W1,proj,lin0,back,fc1[4],fc2[4].  GATOR_PIN keeps
     // the compiler from sinking a prefetch back down to its first use.
-    WG4 G0 = ldg4(a.blk[0].qkv, wave * 4, lane);
-    WG4 G1 = ldg4(a.blk[0].qkv, (4 + wave) * 4, lane);
+    Grp<X3K> G0 = ldg4<X3K>(a.blk[0].qkv, wave * 4, lane);
+    Grp<X3K> G1 = ldg4<X3K>(a.blk[0].qkv, (4 + wave) * 4, lane);
     GATOR_PIN();
 
     for (int bi = 0; bi < kDepth; ++bi) {
@@ -228,22 +265,27 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             GATOR_PIN();
             const f32x16 bq = load_chanvec_L(V, V_QKVB + 32 * wave, h), bk = load_chanvec_L(V, V_QKVB + 128 + 32 * wave, h);
             const float vb = V[V_QKVB + 256 + 32 * wave + (lane & 31)];
-            f32x16 y[4];
-            layernorm128<false>(X, V + V_N1W, V + V_N1B, lane, y);
+            typename Op<X3K>::T y[4];
+            {
+                f32x16 yf[4];
+                layernorm128<false>(X, V + V_N1W, V + V_N1B, lane, yf);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) y[kb] = mkop<X3K>(yf[kb]);
+            }
             GAT_STAMP(10)
             // ---- Attention (modules.py:121-138): wave owns heads 2*wave, 2*wave+1 ----
             const f32x16 q = lin4r<false>(G0, y, bq);
-            G0 = ldg4(w.qkv, (8 + wave) * 4, lane);
+            G0 = ldg4<X3K>(w.qkv, (8 + wave) * 4, lane);
             GATOR_PIN();
             GAT_STAMP(11)
             const f32x16 k = lin4r<false>(G1, y, bk);
-            G1 = ldg4(w.w0, wave * 4, lane);
+            G1 = ldg4<X3K>(w.w0, wave * 4, lane);
             const f32x16 ba = load_block(a.biasT + (size_t)(2 * wave) * kTile, lane);
             const f32x16 bb = load_block(a.biasT + (size_t)(2 * wave + 1) * kTile, lane);
             GATOR_PIN();
             GAT_STAMP(12)
             const f32x16 v = lin4r<true>(G0, y, zero16());
-            G0 = ldg4(w.w1, wave * 4, lane);
+            G0 = ldg4<X3K>(w.w1, wave * 4, lane);
             GATOR_PIN();
             GAT_STAMP(13)
             {
@@ -283,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
                     O = GATOR_MFMA(lo ? vv : 0.f, sa[r] * ia, O);                          // rows (channels) 0..15  <- head 2w
                     Ob = GATOR_MFMA(lo ? 0.f : vv, sb[r] * ib, Ob);                        // rows 16..31            <- head 2w+1
                 }
-                store_block(AT + wave * kTile, lane, O + Ob);
+                stop<X3K>(AT + wave * TA, lane, O + Ob);
             }
             GAT_STAMP(14)
             // ---- MGCN (modules.py:243-255): h_k = y @ W[k]; out = diag(A)(M.h0) + offdiag(A)(M.h1) + bias ----
@@ -292,11 +334,11 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             const f32x16 bg = load_chanvec_L(V, V_GCNB + 32 * wave, h), bp = load_chanvec_L(V, V_PROJB + 32 * wave, h);
             GATOR_PIN();
             f32x16 h0 = lin4r<true>(G1, y, zero16());
-            G1 = ldg4(w.proj, wave * 4, lane);
+            G1 = ldg4<X3K>(w.proj, wave * 4, lane);
             GATOR_PIN();
             GAT_STAMP(15)
             f32x16 h1 = lin4r<true>(G0, y, zero16());
-            G0 = ldg4(w.lin0, wave * 4, lane);
+            G0 = ldg4<X3K>(w.lin0, wave * 4, lane);
             GATOR_PIN();
             GAT_STAMP(16)
             h0 = h0 * mdt;                                                                  // diag(A)[t] * M[t][n] * h0[t][n]
@@ -313,12 +355,13 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             GAT_STAMP(2)
             // proj + (attention + MGCN) sum  -> SB
             const f32x16 acc = lin4l(G1, AT, lane, bp);
-            G1 = ldg4(w.back, wave * 5, lane);
+            G1 = ldg4<X3K>(w.back, wave * 5, lane);
             GATOR_PIN();
-            store_block(SB + wave * kTile, lane, acc + g_out);
+            stop<X3K>(SB + wave * TA, lane, acc + g_out);
         }
         // small operands of the X_Feat phase, requested before the barrier
-        const WTile wl1 = load_wtile(w.lin1, wave, lane), wb4 = load_wtile(w.back, wave * 5 + 4, lane);
+        const typename Op<X3K>::W wl1 = ldw1<X3K>(w.lin1, wave, lane);
+        const WTile wb4 = load_wtile(w.back32, wave * 5 + 4, lane);
         const f32x16 m1 = load_block(a.m1T, lane), m2 = load_block(a.m2T, lane), f1bias = load_block(w.f1b, lane);
         const float b0 = V[V_LIN0B + 32 * wave + (lane & 31)];
         const f32x16 bback = load_chanvec_L(V, V_BACKB + 32 * wave, h);
@@ -326,24 +369,24 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         __syncthreads();
         GAT_STAMP(3)
         {   // ---- X_Feat (modules.py:158-177) ----
-            f32x16 s[4];
+            typename Op<X3K>::T s[4];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) s[kb] = load_block(SB + kb * kTile, lane);
+            for (int kb = 0; kb < 4; ++kb) s[kb] = ldop<X3K>(SB + kb * TA, lane);
             const f32x16 u0 = lin4r<true>(G0, s, zero16());
-            G0 = ldg4(w.fc1, (4 * wave + 0) * 4, lane);
+            G0 = ldg4<X3K>(w.fc1, (4 * wave + 0) * 4, lane);
             GATOR_PIN();
             // linears[1] (128->16): this wave contributes k-block `wave`; partial hop-2 aggregation, summed by the reader
-            const f32x16 u1 = dot16_C(wl1, load_block(SB + wave * kTile, lane));            // (s[wave] would index registers dynamically)
+            const f32x16 u1 = dotC(wl1, ldop<X3K>(SB + wave * TA, lane));                    // (s[wave] would index registers dynamically)
             f32x16 f0 = zero16(), f1 = zero16();
             dot16x2(u0 + b0, m1, f0, u1, m2, f1);                                           // hop<=1 and hop==2 aggregations
-            store_block(FB + wave * kTile, lane, f0);
+            stop<X3K>(FB + wave * TA, lane, f0);
             store_block(F1P + wave * kTile, lane, f1);
         }
         __syncthreads();
         GAT_STAMP(4)
         {   // linearback(144->128) + residual
             f32x16 acc = lin4l(G1, FB, lane, bback);
-            G1 = ldg4(w.fc1, (4 * wave + 1) * 4, lane);
+            G1 = ldg4<X3K>(w.fc1, (4 * wave + 1) * 4, lane);
             GATOR_PIN();
             f32x16 f1 = f1bias;                                                             // rowsum(m2)[t] * linears[1].bias[n]
 #pragma unroll
@@ -360,32 +403,37 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         __syncthreads();
         GAT_STAMP(5)
         {   // ---- MLP (modules.py:188-196): fc1 + GELU -> HB (16 tiles), fc2 + residual ----
-            f32x16 y2[4];
-            layernorm128<false>(X, V + V_N2W, V + V_N2B, lane, y2);
+            typename Op<X3K>::T y2[4];
+            {
+                f32x16 yf[4];
+                layernorm128<false>(X, V + V_N2W, V + V_N2B, lane, yf);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) y2[kb] = mkop<X3K>(yf[kb]);
+            }
             f32x16 hd = lin4r<false>(G0, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 0), h));
-            G0 = ldg4(w.fc1, (4 * wave + 2) * 4, lane);
+            G0 = ldg4<X3K>(w.fc1, (4 * wave + 2) * 4, lane);
             GATOR_PIN();
 #pragma unroll
             for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
-            store_block(HB + (4 * wave + 0) * kTile, lane, hd);
+            stop<X3K>(HB + (4 * wave + 0) * TA, lane, hd);
             hd = lin4r<false>(G1, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 1), h));
-            G1 = ldg4(w.fc1, (4 * wave + 3) * 4, lane);
+            G1 = ldg4<X3K>(w.fc1, (4 * wave + 3) * 4, lane);
             GATOR_PIN();
 #pragma unroll
             for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
-            store_block(HB + (4 * wave + 1) * kTile, lane, hd);
+            stop<X3K>(HB + (4 * wave + 1) * TA, lane, hd);
             hd = lin4r<false>(G0, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 2), h));
-            G0 = ldg4(w.fc2, wave * 16 + 0, lane);
+            G0 = ldg4<X3K>(w.fc2, wave * 16 + 0, lane);
             GATOR_PIN();
 #pragma unroll
             for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
-            store_block(HB + (4 * wave + 2) * kTile, lane, hd);
+            stop<X3K>(HB + (4 * wave + 2) * TA, lane, hd);
             hd = lin4r<false>(G1, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 3), h));
-            G1 = ldg4(w.fc2, wave * 16 + 4, lane);
+            G1 = ldg4<X3K>(w.fc2, wave * 16 + 4, lane);
             GATOR_PIN();
 #pragma unroll
             for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
-            store_block(HB + (4 * wave + 3) * kTile, lane, hd);
+            stop<X3K>(HB + (4 * wave + 3) * TA, lane, hd);
         }
         const f32x16 bfc2 = load_chanvec_L(V, V_FC2B + 32 * wave, h);
         GAT_STAMP(6)
@@ -394,17 +442,17 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         reinterpret_cast<f32x4*>(V)[t] = vn0;          // every read of this block's vectors happened before the barrier above
         reinterpret_cast<f32x4*>(V)[256 + t] = vn1;
         {   // fc2: four independent 128-product chains (one per group of 4 hidden blocks)
-            const f32x16 c0 = lin4l(G0, HB + 0 * kTile, lane, bfc2);
-            G0 = ldg4(w.fc2, wave * 16 + 8, lane);
+            const f32x16 c0 = lin4l(G0, HB + 0 * TA, lane, bfc2);
+            G0 = ldg4<X3K>(w.fc2, wave * 16 + 8, lane);
             GATOR_PIN();
-            const f32x16 c1 = lin4l(G1, HB + 4 * kTile, lane, zero16());
-            G1 = ldg4(w.fc2, wave * 16 + 12, lane);
+            const f32x16 c1 = lin4l(G1, HB + 4 * TA, lane, zero16());
+            G1 = ldg4<X3K>(w.fc2, wave * 16 + 12, lane);
             GATOR_PIN();
-            const f32x16 c2 = lin4l(G0, HB + 8 * kTile, lane, zero16());
-            G0 = ldg4(wn.qkv, wave * 4, lane);                      // next block's q / k groups
+            const f32x16 c2 = lin4l(G0, HB + 8 * TA, lane, zero16());
+            G0 = ldg4<X3K>(wn.qkv, wave * 4, lane);                      // next block's q / k groups
             GATOR_PIN();
-            const f32x16 c3 = lin4l(G1, HB + 12 * kTile, lane, zero16());
-            G1 = ldg4(wn.qkv, (4 + wave) * 4, lane);
+            const f32x16 c3 = lin4l(G1, HB + 12 * TA, lane, zero16());
+            G1 = ldg4<X3K>(wn.qkv, (4 + wave) * 4, lane);
             GATOR_PIN();
             xw += (c0 + c1) + (c2 + c3);
             store_block(X + wave * kTile, lane, xw);     // every wave finished reading X (LN2) before the HB barrier
@@ -531,7 +579,11 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         const GatBlockW& r = w.blk[i];
         const GatBlockPk& p = f->gblk[i];
         GatBlockP& q = a.blk[i];
-        q.qkv = p.qkv; q.proj = p.proj; q.w0 = p.w0; q.w1 = p.w1; q.lin0 = p.lin0; q.lin1 = p.lin1; q.back = p.back; q.fc1 = p.fc1; q.fc2 = p.fc2;
+        // X3 tile grids mirror the fp32 ones tile for tile (fused_create_gat): same tile index, 1.5x the tile size
+        auto sel = [&](const float* t) { return f->gat_x3 ? f->gxbuf + (size_t)(t - f->gblk[0].qkv) / kTile * kTileX3 : t; };
+        q.qkv = sel(p.qkv); q.proj = sel(p.proj); q.w0 = sel(p.w0); q.w1 = sel(p.w1); q.lin0 = sel(p.lin0); q.lin1 = sel(p.lin1);
+        q.back = sel(p.back); q.fc1 = sel(p.fc1); q.fc2 = sel(p.fc2);
+        q.back32 = p.back;
         q.mc = p.mc; q.md = p.md; q.aoffT = p.aoffT; q.f1b = p.f1b;
         q.vecs = f->g_vecs + (size_t)i * 2048;
         (void)r;
@@ -549,13 +601,16 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         GATOR_HIP_CHECK(hipMalloc(&d_st, 20 * sizeof(unsigned long long)));
         a.stamps = d_st;
     }
-    constexpr size_t kLds = (20 * kTile + 2048) * sizeof(float);     // 88 KB
+    constexpr size_t kLds = (20 * kTile + 2048) * sizeof(float);                 // 88 KB
+    constexpr size_t kLdsX3 = (4 * kTile + 16 * kTileX3 + 2048) * sizeof(float);   // 120 KB
     static bool attr = false;
     if (!attr) {
-        GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsX3));
         attr = true;
     }
-    k_gat<<<B, 256, kLds, (hipStream_t)stream>>>(a);
+    if (f->gat_x3) k_gat<true><<<B, 256, kLdsX3, (hipStream_t)stream>>>(a);
+    else k_gat<false><<<B, 256, kLds, (hipStream_t)stream>>>(a);
     GATOR_HIP_CHECK(hipGetLastError());
     if (d_st) {     // diagnostic build path: synchronous read-back, never used in timed runs
         unsigned long long hst[20];

@@ -17,6 +17,7 @@
 // coalesced float4 wave loads from L2), so no LDS staging or barrier is needed.
 #include "fused_common.h"
 #include "fused_state.h"
+#include "x3_common.h"
 
 #include <cstdlib>
 
@@ -170,6 +171,58 @@ __device__ __forceinline__ f32x16 self_attention_head(const float* __restrict__ 
     return ((O + O2) + (O3 + O4)) * (1.0f / l);
 }
 
+// ---- the same on split-precision operands (x3_common.h): Q, K, V arrive as X3 tiles, S^T = K Q^T and O^T += V^T P^T are 12
+// bf16 MFMAs each (768 cycles per key tile against 2048), the probabilities are split in registers.  The bf16 MFMA sums
+// 16 products internally and its dependent chain issues back to back, so two accumulators (even / odd key tiles) suffice.
+#define ATTN_TILE_X3(KT, KB, VB, OACC)                                                                      \
+    {                                                                                                       \
+        f32x16 S = x3_mma(KB, qx, zero16());  /* S^T[key][query] */                                         \
+        float bm = -1e30f;                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+            float sc = S[r] * c;                                                                            \
+            if ((KT) == kVT - 1 && kap(r) + 4 * h >= kV - 32 * (kVT - 1)) sc = -1e30f;                      \
+            S[r] = sc;                                                                                      \
+            bm = fmaxf(bm, sc);                                                                             \
+        }                                                                                                   \
+        bm = fmaxf(bm, xhalf(bm));                                                                          \
+        if (!__all(bm <= m + 8.0f)) {                                                                       \
+            const float mn = fmaxf(m, bm);                                                                  \
+            const float al = __builtin_amdgcn_exp2f(m - mn);                                                \
+            O = O * al;                                                                                     \
+            O2 = O2 * al;                                                                                   \
+            l *= al;                                                                                        \
+            m = mn;                                                                                         \
+        }                                                                                                   \
+        float ps = 0.f;                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+            const float pe = __builtin_amdgcn_exp2f(S[r] - m);                                              \
+            S[r] = pe;                                                                                      \
+            ps += pe;                                                                                       \
+        }                                                                                                   \
+        l += ps;                                                                                            \
+        OACC = x3_mma(VB, x3_split(S), OACC);   /* O^T[d][query] += V^T[d][key] P^T[key][query] */          \
+    }
+__device__ __forceinline__ f32x16 self_attention_head_x3(const float* __restrict__ qt, const float* __restrict__ kbase,
+                                                         const float* __restrict__ vbase, int lane) {
+    const int h = lane >> 5;
+    const X3 qx = x3_load(qt, lane);
+    f32x16 O = zero16(), O2 = zero16();
+    float m = -1e30f, l = 0.f;
+    const float c = kLog2e * 0.17677669529663688110f;
+    X3 kb = x3_load(kbase, lane), vb = x3_load(vbase, lane);
+#pragma unroll 1
+    for (int kt = 0; kt < kVT; kt += 2) {                   // tiles kt (-> O) and kt + 1 (-> O2); the next tile's K/V in flight
+        X3 kn = x3_load(kbase + (size_t)(kt + 1) * 2 * kTileX3, lane), vn = x3_load(vbase + (size_t)(kt + 1) * 2 * kTileX3, lane);
+        ATTN_TILE_X3(kt, kb, vb, O)
+        const int k2 = kt + 2 < kVT ? kt + 2 : kt;
+        kb = x3_load(kbase + (size_t)k2 * 2 * kTileX3, lane);
+        vb = x3_load(vbase + (size_t)k2 * 2 * kTileX3, lane);
+        ATTN_TILE_X3(kt + 1, kn, vn, O2)
+    }
+    l += xhalf(l);
+    return (O + O2) * (1.0f / l);
+}
+
 // ---- cross-attention over the J joint tokens (keys/values precomputed per sample by k_mdr_joint) -------------------------
 __device__ __forceinline__ f32x16 cross_attention_head(const float* __restrict__ kj, const float* __restrict__ vjp,
                                                        const f32x16& qh, int J, int lane) {
@@ -201,6 +254,9 @@ __device__ __forceinline__ f32x16 cross_attention_head(const float* __restrict__
 // ---- weight stream of the tokenwise part: two buffers of one tile pair each (2 x 32 VGPRs).  The pair for the NEXT
 // product is requested right after the current product's MFMAs are queued, so its L2 latency hides behind them and
 // behind the co-resident wave.  MDR_PIN keeps the order (memory ops and scheduler).
+template <bool X> __device__ __forceinline__ void st_op(float* p, int lane, const f32x16& v) {
+    if constexpr (X) x3_store(p, lane, x3_split(v)); else store_block(p, lane, v);
+}
 struct W2 { WTile t[2]; };
 __device__ __forceinline__ W2 ldw2(const float* __restrict__ Wp, int i0, int i1, int lane) {
     W2 w;
@@ -220,8 +276,10 @@ __device__ __forceinline__ f32x16 lin2_C(const W2& w, const f32x16 (&x)[2]) {
     return a0 + a1;
 }
 
-template <int MODE>   // 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
+// X: self-attention on split-precision operands (q/k/v tiles are X3 tiles, 1.5x the size, same tile indices)
+template <int MODE, bool X>   // 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
 __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) {
+    constexpr int TQ = X ? kTileX3 : kTile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int id = xcd_remap(blockIdx.x, nwg) * 4 + wave;
     if (id >= a.B * kVT) return;
@@ -263,10 +321,17 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         }
     } else {
         f32x16 att[2];
-        att[0] = self_attention_head(a.q_in + (tile + 0) * kTile, a.k_in + ((size_t)b * kVT * 2 + 0) * kTile,
-                                     a.v_in + ((size_t)b * kVT * 2 + 0) * kTile, lane);
-        att[1] = self_attention_head(a.q_in + (tile + 1) * kTile, a.k_in + ((size_t)b * kVT * 2 + 1) * kTile,
-                                     a.v_in + ((size_t)b * kVT * 2 + 1) * kTile, lane);
+        if constexpr (X) {
+            att[0] = self_attention_head_x3(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
+                                            a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
+            att[1] = self_attention_head_x3(a.q_in + (tile + 1) * TQ, a.k_in + ((size_t)b * kVT * 2 + 1) * TQ,
+                                            a.v_in + ((size_t)b * kVT * 2 + 1) * TQ, lane);
+        } else {
+            att[0] = self_attention_head(a.q_in + (tile + 0) * kTile, a.k_in + ((size_t)b * kVT * 2 + 0) * kTile,
+                                         a.v_in + ((size_t)b * kVT * 2 + 0) * kTile, lane);
+            att[1] = self_attention_head(a.q_in + (tile + 1) * kTile, a.k_in + ((size_t)b * kVT * 2 + 1) * kTile,
+                                         a.v_in + ((size_t)b * kVT * 2 + 1) * kTile, lane);
+        }
         A = ldw2(a.prev.sa3, 0, 1, lane);
         B = ldw2(a.prev.sa3, 2, 3, lane);
         vf[0] = load_block(a.vf_in + (tile + 0) * kTile, lane);
@@ -364,8 +429,8 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         f32x16 y1 = lin2_T(B, vf, load_chanvec_S(w.sa0_b, 32, h));
         B = ldw2(w.sa1, 2, 3, lane);
         MDR_PIN();
-        store_block(a.q_out + (tile + 0) * kTile, lane, y0);
-        store_block(a.q_out + (tile + 1) * kTile, lane, y1);
+        st_op<X>(a.q_out + (tile + 0) * TQ, lane, y0);
+        st_op<X>(a.q_out + (tile + 1) * TQ, lane, y1);
         y0 = lin2_T(A, vf, load_chanvec_S(w.sa1_b, 0, h));
         A = ldw2(w.sa2, 0, 1, lane);
         MDR_PIN();
@@ -374,8 +439,8 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         const float bv0 = w.sa2_b[lane & 31], bv1 = w.sa2_b[32 + (lane & 31)];
         MDR_PIN();
         if (token >= kV) { y0 = zero16(); y1 = zero16(); }                   // pad keys: finite (they are masked anyway)
-        store_block(a.k_out + (tile + 0) * kTile, lane, y0);
-        store_block(a.k_out + (tile + 1) * kTile, lane, y1);
+        st_op<X>(a.k_out + (tile + 0) * TQ, lane, y0);
+        st_op<X>(a.k_out + (tile + 1) * TQ, lane, y1);
         y0 = lin2_C(A, vf);                                                   // V in C-layout: channel on the lane
         y1 = lin2_C(B, vf);
 #pragma unroll
@@ -384,8 +449,8 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
             y0[r] = ok ? y0[r] + bv0 : 0.f;
             y1[r] = ok ? y1[r] + bv1 : 0.f;
         }
-        store_block(a.v_out + (tile + 0) * kTile, lane, y0);
-        store_block(a.v_out + (tile + 1) * kTile, lane, y1);
+        st_op<X>(a.v_out + (tile + 0) * TQ, lane, y0);
+        st_op<X>(a.v_out + (tile + 1) * TQ, lane, y1);
     }
     MDR_STAMP(4)
     if (a.stamps && id == 0 && lane == 0)
@@ -581,7 +646,8 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     for (int i = 0; i < 3; ++i) { ja.n1w[i] = w.lay[i].n1w; ja.n1b[i] = w.lay[i].n1b; ja.wk_p[i] = f->lay[i].wk; ja.wv_p[i] = f->lay[i].wv; }
     if (pc) { StageTimer tm(c, "mdr_joint", stream); k_mdr_joint<<<B, 128, 0, st>>>(ja); }    // else: done by k_gat's epilogue
     const size_t per = (size_t)f->cap * kVT * 2 * kTile;      // one [B][14][2] tile set
-    float* set[2][4] = {{f->vf, f->q, f->k, f->v}, {f->vf + per, f->q + per, f->k + per, f->v + per}};
+    const size_t perq = (size_t)f->cap * kVT * 2 * (f->mdr_x3 ? kTileX3 : kTile);      // q/k/v tile sets: X3 tiles when split-precision
+    float* set[2][4] = {{f->vf, f->q, f->k, f->v}, {f->vf + per, f->q + perq, f->k + perq, f->v + perq}};
     MdrArgs a{};
     a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.xout = pc ? nullptr : x_out; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
     a.head_w = f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = f->lbf;
@@ -599,9 +665,15 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         if (li > 0) a.prev = make_layer(f, c, li - 1);
         if (li < 3) a.cur = make_layer(f, c, li);
         StageTimer tm(c, li == 0 ? "mdr_layer0" : (li < 3 ? "mdr_layer" : "mdr_attn_head"), stream);
-        if (li == 0) k_mdr_layer<0><<<nwg, 256, 0, st>>>(a, nwg);
-        else if (li < 3) k_mdr_layer<1><<<nwg, 256, 0, st>>>(a, nwg);
-        else k_mdr_layer<2><<<nwg, 256, 0, st>>>(a, nwg);
+        if (f->mdr_x3) {
+            if (li == 0) k_mdr_layer<0, true><<<nwg, 256, 0, st>>>(a, nwg);
+            else if (li < 3) k_mdr_layer<1, true><<<nwg, 256, 0, st>>>(a, nwg);
+            else k_mdr_layer<2, true><<<nwg, 256, 0, st>>>(a, nwg);
+        } else {
+            if (li == 0) k_mdr_layer<0, false><<<nwg, 256, 0, st>>>(a, nwg);
+            else if (li < 3) k_mdr_layer<1, false><<<nwg, 256, 0, st>>>(a, nwg);
+            else k_mdr_layer<2, false><<<nwg, 256, 0, st>>>(a, nwg);
+        }
     }
     if (d_st) {     // diagnostic path only
         unsigned long long hst[512];

@@ -1,0 +1,77 @@
+// Split-precision ("x3") operands: fp32-accurate products on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, 32 cycles for a 16-deep
+// k-step against 8 x 64 cycles on the fp32-input MFMA).
+//
+// Every fp32 value is split EXACTLY into three bf16 planes, x = hi + mid + lo (8+8+8 significand bits; each remainder is
+// exactly representable in fp32, so nothing is lost).  A product a*w is the sum of nine exact partial products; the six
+// largest -- hi*hi | hi*mid, mid*hi | mid*mid, hi*lo, lo*hi -- go through the MFMA (fp32 accumulate), the three dropped
+// ones are below 2^-24 of the product, i.e. under the rounding of the fp32 accumulation itself.  A 32x32 (K=32) tile
+// product is 12 bf16 MFMAs (384 cycles) instead of 16 fp32-input MFMAs (1024 cycles).
+//
+// Operand tile ("X3 tile", 6 KiB = kTileX3 floats): [plane 3][k-step 2][lane 64][8 bf16].  Element j of lane l (i = l&31,
+// h = l>>5) of k-step s is k index 16s + 8(j>>2) + 4h + (j&3): exactly registers 8s..8s+7 of a fused_common.h T/C-layout
+// block, so an accumulator tile becomes the next product's operand by converting its registers pairwise, with no lane
+// movement, and a packed fp32 weight tile [g][lane][j] maps to it by g = 2s + (j>>2).
+#pragma once
+#include "fused_common.h"
+
+namespace gator {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define GATOR_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int kTileX3 = 1536;       // floats-equivalent of one X3 operand tile
+
+struct X3 { bf16x8 p[3][2]; };      // [plane hi/mid/lo][k-step]: 24 VGPRs
+
+__device__ __forceinline__ X3 x3_split(const f32x16& v) {
+    X3 o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = v[8 * s + j];
+            const __bf16 h = (__bf16)x;
+            const float r = x - (float)h;
+            const __bf16 m = (__bf16)r;
+            o.p[0][s][j] = h;
+            o.p[1][s][j] = m;
+            o.p[2][s][j] = (__bf16)(r - (float)m);
+        }
+    return o;
+}
+
+__device__ __forceinline__ X3 x3_load(const float* __restrict__ tile, int lane) {
+    const bf16x8* q = reinterpret_cast<const bf16x8*>(tile) + lane;
+    X3 o;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) o.p[pl][s] = q[(pl * 2 + s) * 64];
+    return o;
+}
+__device__ __forceinline__ void x3_store(float* __restrict__ tile, int lane, const X3& v) {
+    bf16x8* q = reinterpret_cast<bf16x8*>(tile) + lane;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) q[(pl * 2 + s) * 64] = v.p[pl][s];
+}
+
+// acc += A . B over the tile's 32-deep k (rows of the result = A's lane index, columns = B's lane index); small terms first
+__device__ __forceinline__ f32x16 x3_mma(const X3& A, const X3& B, f32x16 acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        acc = GATOR_MFMA_BF16(A.p[2][s], B.p[0][s], acc);      // lo*hi
+        acc = GATOR_MFMA_BF16(A.p[0][s], B.p[2][s], acc);      // hi*lo
+        acc = GATOR_MFMA_BF16(A.p[1][s], B.p[1][s], acc);      // mid*mid
+        acc = GATOR_MFMA_BF16(A.p[1][s], B.p[0][s], acc);      // mid*hi
+        acc = GATOR_MFMA_BF16(A.p[0][s], B.p[1][s], acc);      // hi*mid
+        acc = GATOR_MFMA_BF16(A.p[0][s], B.p[0][s], acc);      // hi*hi
+    }
+    return acc;
+}
+
+// fused_pack.hip: fp32 packed tiles [g][lane][4] -> X3 tiles, same tile indices
+int fused_repack_x3(const float* src_tiles, float* dst_tiles, int64_t ntiles, void* stream);
+
+}  // namespace gator
