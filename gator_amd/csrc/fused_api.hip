@@ -247,6 +247,12 @@ int fused_create(gator_ctx* c, void* stream) {
         GATOR_HIP_CHECK(hipFree(tmp));
         if (rc) return rc;
         f->head_w = dst;
+        if (f->mdr_x3) {     // split-precision image of the three layers' tile grids and the head tiles (contiguous in wbuf)
+            const int64_t ntiles = (dst + 2 * kTile - f->lay[0].wq) / kTile;
+            GATOR_HIP_CHECK(hipMalloc(&f->wxbuf, (size_t)ntiles * kTileX3 * sizeof(float)));
+            rc = fused_repack_x3(f->lay[0].wq, f->wxbuf, ntiles, stream);
+            if (rc) return rc;
+        }
         float* hbd = take(64);
         GATOR_HIP_CHECK(hipMemcpy(hbd, hb.data(), 32 * sizeof(float), hipMemcpyHostToDevice));
         f->head_b = hbd;
@@ -315,6 +321,7 @@ void fused_destroy(gator_ctx* c) {
     if (c->fused->wbuf) (void)hipFree(c->fused->wbuf);
     if (c->fused->gbuf) (void)hipFree(c->fused->gbuf);
     if (c->fused->gxbuf) (void)hipFree(c->fused->gxbuf);
+    if (c->fused->wxbuf) (void)hipFree(c->fused->wxbuf);
     if (c->fused->up_w16) (void)hipFree(c->fused->up_w16);
     if (c->fused->up_w3) (void)hipFree(c->fused->up_w3);
     delete c->fused;

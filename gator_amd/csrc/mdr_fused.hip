@@ -277,9 +277,47 @@ __device__ __forceinline__ f32x16 lin2_C(const W2& w, const f32x16 (&x)[2]) {
 }
 
 // X: self-attention on split-precision operands (q/k/v tiles are X3 tiles, 1.5x the size, same tile indices)
+// split-precision forms: the weight pair is two X3 tiles (48 VGPRs), activations are split once per linear input, one chain
+struct W2X { X3 t[2]; };
+__device__ __forceinline__ W2X ldw2x(const float* __restrict__ Wx, int i0, int i1, int lane) {
+    W2X w;
+    w.t[0] = x3_load(Wx + (size_t)i0 * kTileX3, lane);
+    w.t[1] = x3_load(Wx + (size_t)i1 * kTileX3, lane);
+    return w;
+}
+__device__ __forceinline__ f32x16 lin2_T(const W2X& w, const X3 (&x)[2], f32x16 init) { return x3_mma(w.t[1], x[1], x3_mma(w.t[0], x[0], init)); }
+__device__ __forceinline__ f32x16 lin2_C(const W2X& w, const X3 (&x)[2]) { return x3_mma(x[1], w.t[1], x3_mma(x[0], w.t[0], zero16())); }
+template <bool X> struct TokOp;
+template <> struct TokOp<false> { typedef W2 W; typedef f32x16 A; };
+template <> struct TokOp<true> { typedef W2X W; typedef X3 A; };
+template <bool X> __device__ __forceinline__ typename TokOp<X>::W ldw(const float* __restrict__ Wp, int i0, int i1, int lane) {
+    if constexpr (X) return ldw2x(Wp, i0, i1, lane); else return ldw2(Wp, i0, i1, lane);
+}
+template <bool X> __device__ __forceinline__ typename TokOp<X>::A mk(const f32x16& v) {
+    if constexpr (X) return x3_split(v); else return v;
+}
+
 template <int MODE, bool X>   // 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
 __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) {
     constexpr int TQ = X ? kTileX3 : kTile;
+    __shared__ f32x4 park[X ? 8 : 1][X ? 256 : 1];
+    auto park_vf = [&](const f32x16 (&v)[2]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x4 t4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t4[j] = v[i >> 2][4 * (i & 3) + j];
+            park[i][threadIdx.x] = t4;
+        }
+    };
+    auto unpark_vf = [&](f32x16 (&v)[2]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 t4 = park[i][threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i >> 2][4 * (i & 3) + j] = t4[j];
+        }
+    };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int id = xcd_remap(blockIdx.x, nwg) * 4 + wave;
     if (id >= a.B * kVT) return;
@@ -297,10 +335,11 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
     const int token = 32 * t + (lane & 31);
     const LayerW& w = a.cur;
     f32x16 vf[2];
-    W2 A, B;
+    typename TokOp<X>::W A, B;
+    typedef typename TokOp<X>::A Act;
     if (MODE == 0) {
-        A = ldw2(w.wq, 0, 1, lane);
-        B = ldw2(w.wq, 2, 3, lane);
+        A = ldw<X>(w.wq, 0, 1, lane);
+        B = ldw<X>(w.wq, 2, 3, lane);
         // verts tokens = Linear(6->64)([v431, pose3d[vj]/1000]) + pos_v   (MDR.py:126-137); the v431/bias/pos part is folded
         const int tk = token < kV ? token : kV - 1;
         float x0, x1, x2;
@@ -332,18 +371,19 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
             att[1] = self_attention_head(a.q_in + (tile + 1) * kTile, a.k_in + ((size_t)b * kVT * 2 + 1) * kTile,
                                          a.v_in + ((size_t)b * kVT * 2 + 1) * kTile, lane);
         }
-        A = ldw2(a.prev.sa3, 0, 1, lane);
-        B = ldw2(a.prev.sa3, 2, 3, lane);
+        A = ldw<X>(a.prev.sa3, 0, 1, lane);
+        B = ldw<X>(a.prev.sa3, 2, 3, lane);
         vf[0] = load_block(a.vf_in + (tile + 0) * kTile, lane);
         vf[1] = load_block(a.vf_in + (tile + 1) * kTile, lane);
         MDR_PIN();
         MDR_STAMP(0)
         // linears[-1] + residual (vanilla_transformer_encoder.py:94, MDR.py:143)
-        const f32x16 y0 = lin2_T(A, att, load_chanvec_S(a.prev.sa3_b, 0, h));
-        if (MODE == 1) A = ldw2(w.wq, 0, 1, lane); else A = ldw2(a.head_w, 0, 1, lane);
+        const Act attx[2] = {mk<X>(att[0]), mk<X>(att[1])};
+        const f32x16 y0 = lin2_T(A, attx, load_chanvec_S(a.prev.sa3_b, 0, h));
+        if (MODE == 1) A = ldw<X>(w.wq, 0, 1, lane); else A = ldw<X>(a.head_w, 0, 1, lane);
         MDR_PIN();
-        const f32x16 y1 = lin2_T(B, att, load_chanvec_S(a.prev.sa3_b, 32, h));
-        if (MODE == 1) B = ldw2(w.wq, 2, 3, lane);
+        const f32x16 y1 = lin2_T(B, attx, load_chanvec_S(a.prev.sa3_b, 32, h));
+        if (MODE == 1) B = ldw<X>(w.wq, 2, 3, lane);
         MDR_PIN();
         vf[0] += y0;
         vf[1] += y1;
@@ -360,7 +400,8 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
                     *reinterpret_cast<f32x4*>(a.lbf + ((size_t)b * kV + token) * kE + 32 * nb + 8 * g + 4 * h) = v4;
                 }
         }
-        const f32x16 acc = lin2_T(A, vf, load_chanvec_S(a.head_b, 0, h));
+        const Act vfx[2] = {mk<X>(vf[0]), mk<X>(vf[1])};
+        const f32x16 acc = lin2_T(A, vfx, load_chanvec_S(a.head_b, 0, h));
         if (token < kV) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -375,30 +416,46 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
     MDR_STAMP(1)
     // ---- CrossAttentionBlock (MDR.py:64-69) ----
     {
-        f32x16 fz[2], q[2], o[2];
-        layernorm64(vf, w.n1w, w.n1b, h, fz);
+        f32x16 q[2], o[2];
+        Act fz[2];
+        {
+            f32x16 fzf[2];
+            layernorm64(vf, w.n1w, w.n1b, h, fzf);
+            fz[0] = mk<X>(fzf[0]);
+            fz[1] = mk<X>(fzf[1]);
+        }
         const float* jb = a.jkv + (((size_t)b * 3 + a.layer) * 4) * kTile;       // [k/v][head] tiles
         q[0] = lin2_T(A, fz, zero16());
-        A = ldw2(w.proj, 0, 1, lane);
+        A = ldw<X>(w.proj, 0, 1, lane);
         MDR_PIN();
         q[1] = lin2_T(B, fz, zero16());
-        B = ldw2(w.proj, 2, 3, lane);
+        B = ldw<X>(w.proj, 2, 3, lane);
         MDR_PIN();
 #pragma unroll
         for (int hd = 0; hd < 2; ++hd) o[hd] = cross_attention_head(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], a.J, lane);
-        const f32x16 y0 = lin2_T(A, o, load_chanvec_S(w.proj_b, 0, h));
-        A = ldw2(w.fc1, 0, 1, lane);                                            // MLP chunk 0: fc1 rows 0..31
+        const Act ox[2] = {mk<X>(o[0]), mk<X>(o[1])};
+        const f32x16 y0 = lin2_T(A, ox, load_chanvec_S(w.proj_b, 0, h));
+        A = ldw<X>(w.fc1, 0, 1, lane);                                            // MLP chunk 0: fc1 rows 0..31
         MDR_PIN();
-        const f32x16 y1 = lin2_T(B, o, load_chanvec_S(w.proj_b, 32, h));
-        B = ldw2(w.fc2, 0, 8, lane);                                            //              fc2 columns 0..31, both row blocks
+        const f32x16 y1 = lin2_T(B, ox, load_chanvec_S(w.proj_b, 32, h));
+        B = ldw<X>(w.fc2, 0, 8, lane);                                            //              fc2 columns 0..31, both row blocks
         MDR_PIN();
         vf[0] += y0;
         vf[1] += y1;
     }
     MDR_STAMP(2)
     {
-        f32x16 y2[2], acc2[2][2];
-        layernorm64(vf, w.n2w, w.n2b, h, y2);
+        f32x16 acc2[2][2];
+        Act y2[2];
+        {
+            f32x16 y2f[2];
+            layernorm64(vf, w.n2w, w.n2b, h, y2f);
+            y2[0] = mk<X>(y2f[0]);
+            y2[1] = mk<X>(y2f[1]);
+        }
+        if constexpr (X) {      // the residual stream waits in LDS while the MLP needs the registers
+            park_vf(vf);
+        }
         acc2[0][0] = load_chanvec_S(w.fc2_b, 0, h);
         acc2[1][0] = load_chanvec_S(w.fc2_b, 32, h);
         acc2[0][1] = zero16();
@@ -406,16 +463,28 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
 #pragma unroll
         for (int c = 0; c < 8; ++c) {           // 256 hidden units in 8 chunks of 32: fc1 -> GELU -> fc2 partial
             f32x16 hdn = lin2_T(A, y2, load_chanvec_S(w.fc1_b, 32 * c, h));
-            if (c < 7) A = ldw2(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw2(w.sa0, 0, 1, lane);
+            if (c < 7) A = ldw<X>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<X>(w.sa0, 0, 1, lane);
             MDR_PIN();
 #pragma unroll
             for (int r = 0; r < 16; ++r) hdn[r] = gelu_f(hdn[r]);
-            mma2_T(B.t[0], hdn, acc2[0][c & 1], B.t[1], hdn, acc2[1][c & 1]);   // even / odd chunks: 2 chains of 128 products each
-            if (c < 7) B = ldw2(w.fc2, c + 1, 8 + c + 1, lane); else B = ldw2(w.sa0, 2, 3, lane);
+            if constexpr (X) {
+                const X3 hx = x3_split(hdn);
+                acc2[0][0] = x3_mma(B.t[0], hx, acc2[0][0]);
+                acc2[1][0] = x3_mma(B.t[1], hx, acc2[1][0]);
+            } else {
+                mma2_T(B.t[0], hdn, acc2[0][c & 1], B.t[1], hdn, acc2[1][c & 1]);   // even / odd chunks: 2 chains of 128 products each
+            }
+            if (c < 7) B = ldw<X>(w.fc2, c + 1, 8 + c + 1, lane); else B = ldw<X>(w.sa0, 2, 3, lane);
             MDR_PIN();
         }
-        vf[0] += acc2[0][0] + acc2[0][1];
-        vf[1] += acc2[1][0] + acc2[1][1];
+        if constexpr (X) {
+            unpark_vf(vf);
+            vf[0] += acc2[0][0];
+            vf[1] += acc2[1][0];
+        } else {
+            vf[0] += acc2[0][0] + acc2[0][1];
+            vf[1] += acc2[1][0] + acc2[1][1];
+        }
     }
     MDR_STAMP(3)
     custom_ln64(vf, w.a2, w.b2, h);                                           // MDR.py:142 self.norm
@@ -423,26 +492,27 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
     store_block(a.vf_out + (tile + 1) * kTile, lane, vf[1]);
     // ---- in-projections of the self-attention (vanilla_transformer_encoder.py:87-89) in the consumer's operand order ----
     {
-        f32x16 y0 = lin2_T(A, vf, load_chanvec_S(w.sa0_b, 0, h));
-        A = ldw2(w.sa1, 0, 1, lane);
+        const Act vfx[2] = {mk<X>(vf[0]), mk<X>(vf[1])};
+        f32x16 y0 = lin2_T(A, vfx, load_chanvec_S(w.sa0_b, 0, h));
+        A = ldw<X>(w.sa1, 0, 1, lane);
         MDR_PIN();
-        f32x16 y1 = lin2_T(B, vf, load_chanvec_S(w.sa0_b, 32, h));
-        B = ldw2(w.sa1, 2, 3, lane);
+        f32x16 y1 = lin2_T(B, vfx, load_chanvec_S(w.sa0_b, 32, h));
+        B = ldw<X>(w.sa1, 2, 3, lane);
         MDR_PIN();
         st_op<X>(a.q_out + (tile + 0) * TQ, lane, y0);
         st_op<X>(a.q_out + (tile + 1) * TQ, lane, y1);
-        y0 = lin2_T(A, vf, load_chanvec_S(w.sa1_b, 0, h));
-        A = ldw2(w.sa2, 0, 1, lane);
+        y0 = lin2_T(A, vfx, load_chanvec_S(w.sa1_b, 0, h));
+        A = ldw<X>(w.sa2, 0, 1, lane);
         MDR_PIN();
-        y1 = lin2_T(B, vf, load_chanvec_S(w.sa1_b, 32, h));
-        B = ldw2(w.sa2, 2, 3, lane);
+        y1 = lin2_T(B, vfx, load_chanvec_S(w.sa1_b, 32, h));
+        B = ldw<X>(w.sa2, 2, 3, lane);
         const float bv0 = w.sa2_b[lane & 31], bv1 = w.sa2_b[32 + (lane & 31)];
         MDR_PIN();
         if (token >= kV) { y0 = zero16(); y1 = zero16(); }                   // pad keys: finite (they are masked anyway)
         st_op<X>(a.k_out + (tile + 0) * TQ, lane, y0);
         st_op<X>(a.k_out + (tile + 1) * TQ, lane, y1);
-        y0 = lin2_C(A, vf);                                                   // V in C-layout: channel on the lane
-        y1 = lin2_C(B, vf);
+        y0 = lin2_C(A, vfx);                                                  // V in C-layout: channel on the lane
+        y1 = lin2_C(B, vfx);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool ok = 32 * t + kap(r) + 4 * h < kV;
@@ -627,8 +697,10 @@ LayerW make_layer(const FusedState* f, const gator_ctx* c, int li) {
     const MdrLayerP& p = f->lay[li];
     const MdrLayerW& r = c->w.lay[li];
     LayerW w;
-    w.wq = p.wq; w.proj = p.proj; w.fc1 = p.fc1; w.fc2 = p.fc2;
-    w.sa0 = p.sa[0]; w.sa1 = p.sa[1]; w.sa2 = p.sa[2]; w.sa3 = p.sa[3];
+    // X3 images mirror the fp32 tile grids tile for tile (fused_create)
+    auto sel = [&](const float* t) { return f->mdr_x3 ? f->wxbuf + (size_t)(t - f->lay[0].wq) / kTile * kTileX3 : t; };
+    w.wq = sel(p.wq); w.proj = sel(p.proj); w.fc1 = sel(p.fc1); w.fc2 = sel(p.fc2);
+    w.sa0 = sel(p.sa[0]); w.sa1 = sel(p.sa[1]); w.sa2 = sel(p.sa[2]); w.sa3 = sel(p.sa[3]);
     w.n1w = r.n1w; w.n1b = r.n1b; w.proj_b = r.proj_b; w.n2w = r.n2w; w.n2b = r.n2b; w.fc1_b = r.fc1_b; w.fc2_b = r.fc2_b;
     w.a2 = r.a2; w.b2 = r.b2; w.sa0_b = r.sa_b[0]; w.sa1_b = r.sa_b[1]; w.sa2_b = r.sa_b[2]; w.sa3_b = r.sa_b[3];
     return w;
@@ -650,7 +722,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     float* set[2][4] = {{f->vf, f->q, f->k, f->v}, {f->vf + per, f->q + perq, f->k + perq, f->v + perq}};
     MdrArgs a{};
     a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.xout = pc ? nullptr : x_out; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
-    a.head_w = f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = f->lbf;
+    a.head_w = f->mdr_x3 ? f->wxbuf + (size_t)(f->head_w - f->lay[0].wq) / kTile * kTileX3 : f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = f->lbf;
     const int nwg = (B * kVT + 3) / 4;
     static const bool want_stamps = getenv("GATOR_MDR_STAMPS") != nullptr;
     unsigned long long* d_st = nullptr;
