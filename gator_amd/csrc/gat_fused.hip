@@ -89,8 +89,7 @@ __device__ __forceinline__ void layernorm128(const float* X, const float* w, con
     for (int kb = 0; kb < 4; ++kb) {
         y[kb] = x[kb] * rstd * load_chanvec_L(w, 32 * kb, h) + load_chanvec_L(b, 32 * kb, h);
         if (GELU) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) y[kb][r] = gelu_f(y[kb][r]);
+            gelu_tile(y[kb]);
         }
     }
 }
@@ -413,26 +412,22 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             f32x16 hd = lin4r<false>(G0, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 0), h));
             G0 = ldg4<X3K>(w.fc1, (4 * wave + 2) * 4, lane);
             GATOR_PIN();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
+            gelu_tile(hd);
             stop<X3K>(HB + (4 * wave + 0) * TA, lane, hd);
             hd = lin4r<false>(G1, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 1), h));
             G1 = ldg4<X3K>(w.fc1, (4 * wave + 3) * 4, lane);
             GATOR_PIN();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
+            gelu_tile(hd);
             stop<X3K>(HB + (4 * wave + 1) * TA, lane, hd);
             hd = lin4r<false>(G0, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 2), h));
             G0 = ldg4<X3K>(w.fc2, wave * 16 + 0, lane);
             GATOR_PIN();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
+            gelu_tile(hd);
             stop<X3K>(HB + (4 * wave + 2) * TA, lane, hd);
             hd = lin4r<false>(G1, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 3), h));
             G1 = ldg4<X3K>(w.fc2, wave * 16 + 4, lane);
             GATOR_PIN();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hd[r] = gelu_f(hd[r]);
+            gelu_tile(hd);
             stop<X3K>(HB + (4 * wave + 3) * TA, lane, hd);
         }
         const f32x16 bfc2 = load_chanvec_L(V, V_FC2B + 32 * wave, h);
@@ -472,8 +467,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         for (int kb = 0; kb < 4; ++kb) { x[kb] = x[kb] - mean; sq[kb] = x[kb] * x[kb]; }
         const float rstd = 1.0f / sqrtf(row_sum128(sq) * (1.0f / 128.0f) + 1e-5f);
         f32x16 mine = (xw - mean) * rstd * load_chanvec_S(a.norm_w, 32 * wave, h) + load_chanvec_S(a.norm_b, 32 * wave, h);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mine[r] = gelu_f(mine[r]);      // each wave finishes only its own channel block
+        gelu_tile(mine);      // each wave finishes only its own channel block
         store_block(R + wave * kTile, lane, mine);
         if (tok < J) {
 #pragma unroll

@@ -465,8 +465,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
             f32x16 hdn = lin2_T(A, y2, load_chanvec_S(w.fc1_b, 32 * c, h));
             if (c < 7) A = ldw<X>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<X>(w.sa0, 0, 1, lane);
             MDR_PIN();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hdn[r] = gelu_f(hdn[r]);
+            gelu_tile(hdn);
             if constexpr (X) {
                 const X3 hx = x3_split(hdn);
                 acc2[0][0] = x3_mma(B.t[0], hx, acc2[0][0]);
