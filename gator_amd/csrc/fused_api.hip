@@ -117,7 +117,7 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
     }
     {   // split-precision image of every block's weight grids (the tables mc/md/aoffT/f1b in between are converted too, unused)
         const char* e = getenv("GATOR_GAT_X3");
-        f->gat_x3 = e && atoi(e) != 0;      // off by default: measured no faster (the weight stream, not the MFMA, bounds k_gat)
+        f->gat_x3 = !(e && atoi(e) == 0);
         if (f->gat_x3) {
             const int64_t ntiles = (p - f->gblk[0].qkv) / kTile;
             GATOR_HIP_CHECK(hipMalloc(&f->gxbuf, (size_t)ntiles * kTileX3 * sizeof(float)));

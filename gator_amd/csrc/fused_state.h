@@ -46,7 +46,7 @@ struct FusedState : FusedWs {
     // upsample: Wp[tap][ob][cb][4][64][4]
     const float* up_w = nullptr;
     void* up_w3 = nullptr;              // bf16 [plane 3][tap][ob][28][64][8]  hi/mid/lo split of upsample_conv.weight
-    bool gat_x3 = false;                // GAT linears on split-precision bf16 MFMA (experiment, GATOR_GAT_X3=1)
+    bool gat_x3 = true;                 // GAT linears on split-precision bf16 MFMA (GATOR_GAT_X3=0: fp32-input MFMA)
     float* gxbuf = nullptr;             // X3 tiles of the GAT block weights, tile-for-tile image of gbuf from gblk[0].qkv on
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
     bool mdr_x3 = true;                 // MDR self-attention on split-precision bf16 MFMA (GATOR_MDR_X3=0: fp32-input MFMA)

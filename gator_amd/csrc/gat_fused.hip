@@ -143,36 +143,47 @@ template <bool X> __device__ __forceinline__ Grp<X> ldg4(const float* __restrict
     for (int i = 0; i < 4; ++i) g.t[i] = ldw1<X>(Wp, tile0 + i, lane);
     return g;
 }
-// sum over 4 k-blocks, operands in registers, T- or C-layout output.  fp32: two independent 64-term chains; X3: one chain
-// (the bf16 MFMA sums 16 products internally, and a dependent chain of it issues back to back)
+// Rolling weight buffer.  The wave holds ONE 4-tile group; each tile slot is refilled with the matching tile of the NEXT group
+// in the fixed order q,k,v,W0,W1,proj,lin0,back,fc1[4],fc2[4] right after the MFMAs that read it are queued, so a load is
+// always one group-time ahead of its use (the same distance as two alternating buffers, at half the registers).
+// fp32: two independent 64-term chains; X3: one chain (the bf16 MFMA sums 16 products internally, dependent issue is back to back).
 template <bool CL>
-__device__ __forceinline__ f32x16 lin4r(const Grp<false>& g, const f32x16 (&xs)[4], f32x16 init) {
+__device__ __forceinline__ f32x16 lin4r(Grp<false>& g, const f32x16 (&xs)[4], f32x16 init, const float* __restrict__ nW, int nt, int lane) {
     f32x16 a0 = init, a1 = zero16();
-    if (CL) {
-        mma2_C(g.t[0], xs[0], a0, g.t[1], xs[1], a1);
-        mma2_C(g.t[2], xs[2], a0, g.t[3], xs[3], a1);
-    } else {
-        mma2_T(g.t[0], xs[0], a0, g.t[1], xs[1], a1);
-        mma2_T(g.t[2], xs[2], a0, g.t[3], xs[3], a1);
-    }
+    if (CL) mma2_C(g.t[0], xs[0], a0, g.t[1], xs[1], a1); else mma2_T(g.t[0], xs[0], a0, g.t[1], xs[1], a1);
+    g.t[0] = load_wtile(nW, nt + 0, lane);
+    g.t[1] = load_wtile(nW, nt + 1, lane);
+    if (CL) mma2_C(g.t[2], xs[2], a0, g.t[3], xs[3], a1); else mma2_T(g.t[2], xs[2], a0, g.t[3], xs[3], a1);
+    g.t[2] = load_wtile(nW, nt + 2, lane);
+    g.t[3] = load_wtile(nW, nt + 3, lane);
     return a0 + a1;
 }
 template <bool CL>
-__device__ __forceinline__ f32x16 lin4r(const Grp<true>& g, const X3 (&xs)[4], f32x16 init) {
+__device__ __forceinline__ f32x16 lin4r(Grp<true>& g, const X3 (&xs)[4], f32x16 init, const float* __restrict__ nW, int nt, int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) init = CL ? x3_mma(xs[i], g.t[i], init) : x3_mma(g.t[i], xs[i], init);
+    for (int i = 0; i < 4; ++i) {
+        init = CL ? x3_mma(xs[i], g.t[i], init) : x3_mma(g.t[i], xs[i], init);
+        g.t[i] = x3_load(nW + (size_t)(nt + i) * kTileX3, lane);
+    }
     return init;
 }
 // same with the 4 operand tiles read from LDS (consecutive tiles at T)
-__device__ __forceinline__ f32x16 lin4l(const Grp<false>& g, const float* T, int lane, f32x16 init) {
+__device__ __forceinline__ f32x16 lin4l(Grp<false>& g, const float* T, int lane, f32x16 init, const float* __restrict__ nW, int nt) {
     f32x16 a0 = init, a1 = zero16();
     mma2_T(g.t[0], load_block(T + 0 * kTile, lane), a0, g.t[1], load_block(T + 1 * kTile, lane), a1);
+    g.t[0] = load_wtile(nW, nt + 0, lane);
+    g.t[1] = load_wtile(nW, nt + 1, lane);
     mma2_T(g.t[2], load_block(T + 2 * kTile, lane), a0, g.t[3], load_block(T + 3 * kTile, lane), a1);
+    g.t[2] = load_wtile(nW, nt + 2, lane);
+    g.t[3] = load_wtile(nW, nt + 3, lane);
     return a0 + a1;
 }
-__device__ __forceinline__ f32x16 lin4l(const Grp<true>& g, const float* T, int lane, f32x16 init) {
+__device__ __forceinline__ f32x16 lin4l(Grp<true>& g, const float* T, int lane, f32x16 init, const float* __restrict__ nW, int nt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) init = x3_mma(g.t[i], x3_load(T + i * kTileX3, lane), init);
+    for (int i = 0; i < 4; ++i) {
+        init = x3_mma(g.t[i], x3_load(T + i * kTileX3, lane), init);
+        g.t[i] = x3_load(nW + (size_t)(nt + i) * kTileX3, lane);
+    }
     return init;
 }
 
@@ -245,11 +256,9 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
     for (int r = 0; r < 16; ++r) ident[r] = (kap(r) + 4 * h == (lane & 31)) ? 1.f : 0.f;
 
     // Software pipeline of the weight stream.  One wave per SIMD means nobody hides this wave's L2 latency, so the next
-    // 4-tile weight group (16 x 1 KiB wave loads) is always in flight while the current one feeds the MFMAs: two group
-    // buffers G0/G1 alternate through the fixed per-block order q,k,v,W0,W1,proj,lin0,back,fc1[4],fc2[4].  GATOR_PIN keeps
-    // the compiler from sinking a prefetch back down to its first use.
-    Grp<X3K> G0 = ldg4<X3K>(a.blk[0].qkv, wave * 4, lane);
-    Grp<X3K> G1 = ldg4<X3K>(a.blk[0].qkv, (4 + wave) * 4, lane);
+    // 4-tile weight group is always in flight while the current one feeds the MFMAs (rolling buffer G, see lin4r).
+    // GATOR_PIN keeps the compiler from sinking a prefetch back down to its first use.
+    Grp<X3K> G = ldg4<X3K>(a.blk[0].qkv, wave * 4, lane);
     GATOR_PIN();
 
     for (int bi = 0; bi < kDepth; ++bi) {
@@ -273,18 +282,15 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             }
             GAT_STAMP(10)
             // ---- Attention (modules.py:121-138): wave owns heads 2*wave, 2*wave+1 ----
-            const f32x16 q = lin4r<false>(G0, y, bq);
-            G0 = ldg4<X3K>(w.qkv, (8 + wave) * 4, lane);
+            const f32x16 q = lin4r<false>(G, y, bq, w.qkv, (4 + wave) * 4, lane);
             GATOR_PIN();
             GAT_STAMP(11)
-            const f32x16 k = lin4r<false>(G1, y, bk);
-            G1 = ldg4<X3K>(w.w0, wave * 4, lane);
+            const f32x16 k = lin4r<false>(G, y, bk, w.qkv, (8 + wave) * 4, lane);
             const f32x16 ba = load_block(a.biasT + (size_t)(2 * wave) * kTile, lane);
             const f32x16 bb = load_block(a.biasT + (size_t)(2 * wave + 1) * kTile, lane);
             GATOR_PIN();
             GAT_STAMP(12)
-            const f32x16 v = lin4r<true>(G0, y, zero16());
-            G0 = ldg4<X3K>(w.w1, wave * 4, lane);
+            const f32x16 v = lin4r<true>(G, y, zero16(), w.w0, wave * 4, lane);
             GATOR_PIN();
             GAT_STAMP(13)
             {
@@ -332,12 +338,10 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             const f32x16 aoff = load_block(w.aoffT, lane);
             const f32x16 bg = load_chanvec_L(V, V_GCNB + 32 * wave, h), bp = load_chanvec_L(V, V_PROJB + 32 * wave, h);
             GATOR_PIN();
-            f32x16 h0 = lin4r<true>(G1, y, zero16());
-            G1 = ldg4<X3K>(w.proj, wave * 4, lane);
+            f32x16 h0 = lin4r<true>(G, y, zero16(), w.w1, wave * 4, lane);
             GATOR_PIN();
             GAT_STAMP(15)
-            f32x16 h1 = lin4r<true>(G0, y, zero16());
-            G0 = ldg4<X3K>(w.lin0, wave * 4, lane);
+            f32x16 h1 = lin4r<true>(G, y, zero16(), w.proj, wave * 4, lane);
             GATOR_PIN();
             GAT_STAMP(16)
             h0 = h0 * mdt;                                                                  // diag(A)[t] * M[t][n] * h0[t][n]
@@ -353,8 +357,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             __syncthreads();
             GAT_STAMP(2)
             // proj + (attention + MGCN) sum  -> SB
-            const f32x16 acc = lin4l(G1, AT, lane, bp);
-            G1 = ldg4<X3K>(w.back, wave * 5, lane);
+            const f32x16 acc = lin4l(G, AT, lane, bp, w.lin0, wave * 4);
             GATOR_PIN();
             stop<X3K>(SB + wave * TA, lane, acc + g_out);
         }
@@ -371,8 +374,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             typename Op<X3K>::T s[4];
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) s[kb] = ldop<X3K>(SB + kb * TA, lane);
-            const f32x16 u0 = lin4r<true>(G0, s, zero16());
-            G0 = ldg4<X3K>(w.fc1, (4 * wave + 0) * 4, lane);
+            const f32x16 u0 = lin4r<true>(G, s, zero16(), w.back, wave * 5, lane);
             GATOR_PIN();
             // linears[1] (128->16): this wave contributes k-block `wave`; partial hop-2 aggregation, summed by the reader
             const f32x16 u1 = dotC(wl1, ldop<X3K>(SB + wave * TA, lane));                    // (s[wave] would index registers dynamically)
@@ -384,8 +386,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         __syncthreads();
         GAT_STAMP(4)
         {   // linearback(144->128) + residual
-            f32x16 acc = lin4l(G1, FB, lane, bback);
-            G1 = ldg4<X3K>(w.fc1, (4 * wave + 1) * 4, lane);
+            f32x16 acc = lin4l(G, FB, lane, bback, w.fc1, (4 * wave + 0) * 4);
             GATOR_PIN();
             f32x16 f1 = f1bias;                                                             // rowsum(m2)[t] * linears[1].bias[n]
 #pragma unroll
@@ -409,23 +410,19 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) y2[kb] = mkop<X3K>(yf[kb]);
             }
-            f32x16 hd = lin4r<false>(G0, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 0), h));
-            G0 = ldg4<X3K>(w.fc1, (4 * wave + 2) * 4, lane);
+            f32x16 hd = lin4r<false>(G, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 0), h), w.fc1, (4 * wave + 1) * 4, lane);
             GATOR_PIN();
             gelu_tile(hd);
             stop<X3K>(HB + (4 * wave + 0) * TA, lane, hd);
-            hd = lin4r<false>(G1, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 1), h));
-            G1 = ldg4<X3K>(w.fc1, (4 * wave + 3) * 4, lane);
+            hd = lin4r<false>(G, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 1), h), w.fc1, (4 * wave + 2) * 4, lane);
             GATOR_PIN();
             gelu_tile(hd);
             stop<X3K>(HB + (4 * wave + 1) * TA, lane, hd);
-            hd = lin4r<false>(G0, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 2), h));
-            G0 = ldg4<X3K>(w.fc2, wave * 16 + 0, lane);
+            hd = lin4r<false>(G, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 2), h), w.fc1, (4 * wave + 3) * 4, lane);
             GATOR_PIN();
             gelu_tile(hd);
             stop<X3K>(HB + (4 * wave + 2) * TA, lane, hd);
-            hd = lin4r<false>(G1, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 3), h));
-            G1 = ldg4<X3K>(w.fc2, wave * 16 + 4, lane);
+            hd = lin4r<false>(G, y2, load_chanvec_L(V, V_FC1B + 32 * (4 * wave + 3), h), w.fc2, wave * 16 + 0, lane);
             GATOR_PIN();
             gelu_tile(hd);
             stop<X3K>(HB + (4 * wave + 3) * TA, lane, hd);
@@ -437,17 +434,13 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         reinterpret_cast<f32x4*>(V)[t] = vn0;          // every read of this block's vectors happened before the barrier above
         reinterpret_cast<f32x4*>(V)[256 + t] = vn1;
         {   // fc2: four independent 128-product chains (one per group of 4 hidden blocks)
-            const f32x16 c0 = lin4l(G0, HB + 0 * TA, lane, bfc2);
-            G0 = ldg4<X3K>(w.fc2, wave * 16 + 8, lane);
+            const f32x16 c0 = lin4l(G, HB + 0 * TA, lane, bfc2, w.fc2, wave * 16 + 4);
             GATOR_PIN();
-            const f32x16 c1 = lin4l(G1, HB + 4 * TA, lane, zero16());
-            G1 = ldg4<X3K>(w.fc2, wave * 16 + 12, lane);
+            const f32x16 c1 = lin4l(G, HB + 4 * TA, lane, zero16(), w.fc2, wave * 16 + 8);
             GATOR_PIN();
-            const f32x16 c2 = lin4l(G0, HB + 8 * TA, lane, zero16());
-            G0 = ldg4<X3K>(wn.qkv, wave * 4, lane);                      // next block's q / k groups
+            const f32x16 c2 = lin4l(G, HB + 8 * TA, lane, zero16(), w.fc2, wave * 16 + 12);
             GATOR_PIN();
-            const f32x16 c3 = lin4l(G1, HB + 12 * TA, lane, zero16());
-            G1 = ldg4<X3K>(wn.qkv, (4 + wave) * 4, lane);
+            const f32x16 c3 = lin4l(G, HB + 12 * TA, lane, zero16(), wn.qkv, wave * 4);               // next block's q group
             GATOR_PIN();
             xw += (c0 + c1) + (c2 + c3);
             store_block(X + wave * kTile, lane, xw);     // every wave finished reading X (LN2) before the HB barrier

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64 * (kX3Waves + 1), 1) void k_upsample_x3(const __
                                                                        float* __restrict__ out, int B, int MT, int nwg, int64_t a_plane,
                                                                        int64_t w_plane) {
     __shared__ bf16x8 wl[2][9][64];
+    __shared__ f32x4 tot[kX3Waves][12][64];       // running totals of the hi*hi chains, see the flush below (96 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wg = xcd_remap(blockIdx.x, nwg);
     const int mgroups = (MT + kX3Waves - 1) / kX3Waves;
@@ -145,8 +146,33 @@ __global__ __launch_bounds__(64 * (kX3Waves + 1), 1) void k_upsample_x3(const __
         for (int l = 0; l < 3; ++l)
 #pragma unroll
             for (int p = 0; p < 3; ++p) x[l][p] = xn[l][p];
+        // Every 7 k-steps the hi*hi chain is flushed into an LDS-resident total and restarted from zero: the chain's
+        // partial sums stay small (their roundings scale with their magnitude) and only 4 additions happen at full
+        // magnitude -- the two-level summation of the fp32 kernel, with LDS instead of 48 more accumulator registers.
+        if (s % 7 == 6 && s != kS16 - 1) {
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = big[l][4 * g + j];
+                    if (s != 6) v4 += tot[wave][l * 4 + g][lane];
+                    tot[wave][l * 4 + g][lane] = v4;
+                }
+#pragma unroll
+            for (int l = 0; l < 3; ++l) big[l] = zero16();
+        }
         __syncthreads();
     }
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v4 = tot[wave][l * 4 + g][lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) big[l][4 * g + j] += v4[j];
+        }
     const int ov = 32 * ob + (lane & 31), h = lane >> 5;
     if (ov >= kNV || !live) return;
     const float bo = bias[ov];
