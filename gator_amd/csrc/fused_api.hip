@@ -64,7 +64,7 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
     const Weights& w = c->w;
     const int J = c->J;
     const size_t blk_tiles = 48 + 16 + 16 + 16 + 16 + 4 + 20 + 64 + 64 + 4 + 4 + 1 + 1;     // 274
-    const size_t total = (kDepth * blk_tiles + 8 + 2 + 8 + 4 + 12 + (size_t)3 * J * 4) * kTile;
+    const size_t total = (kDepth * blk_tiles + 8 + 2 + 8 + 4 + 12) * kTile;
     GATOR_HIP_CHECK(hipMalloc(&f->gbuf, total * sizeof(float)));
     float* p = f->gbuf;
     auto take = [&](size_t tiles) { float* r = p; p += tiles * kTile; return r; };
@@ -159,16 +159,7 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
             fill_tile(pt.data() + (size_t)kb * kTile, [&](int t, int ch) { return t < J ? pe[(size_t)t * kC + 32 * kb + ch] : 0.f; });
         f->g_posT = upload(pt);
     }
-    // lifter [3J][128J] -> per output o, 4 T-layout tiles: tile[kb][g][lane][j] = Wl[o][(lane&31)*128 + 32kb + 8g + 4h + j]
-    {
-        const std::vector<float> wl = d2h(w.lifter_w, (size_t)3 * J * kC * J);
-        std::vector<float> lp((size_t)3 * J * 4 * kTile, 0.f);
-        for (int o = 0; o < 3 * J; ++o)
-            for (int kb = 0; kb < 4; ++kb)
-                fill_tile(lp.data() + ((size_t)o * 4 + kb) * kTile,
-                          [&](int t, int ch) { return t < J ? wl[(size_t)o * kC * J + (size_t)t * kC + 32 * kb + ch] : 0.f; });
-        f->g_lifter = upload(lp);
-    }
+    // (the lifter reads the reference weight [3J][128J] as it is, gat_fused.hip)
     GATOR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;

@@ -41,7 +41,7 @@ struct FusedState : FusedWs {
     float* wbuf = nullptr;              // all packed weights
     float* gbuf = nullptr;              // packed GAT weights + tables
     GatBlockPk gblk[kDepth];
-    const float *g_biasT = nullptr, *g_m1T = nullptr, *g_m2T = nullptr, *g_lifter = nullptr, *g_gl3 = nullptr, *g_posT = nullptr, *g_vecs = nullptr;
+    const float *g_biasT = nullptr, *g_m1T = nullptr, *g_m2T = nullptr, *g_gl3 = nullptr, *g_posT = nullptr, *g_vecs = nullptr;
     size_t wbuf_floats = 0;
     // upsample: Wp[tap][ob][cb][4][64][4]
     const float* up_w = nullptr;

@@ -31,7 +31,7 @@ struct GatArgs {
     const float* pose2d;
     const float *gl0_W, *gl0_b, *gn_w, *gn_b, *gl3_p, *gl3_b, *posT;           // embed: gl3_p packed [4][2]; posT = 4 folded T-layout tiles
     const float *biasT, *m1T, *m2T;                                            // [8] tiles, 1 tile, 1 tile
-    const float *norm_w, *norm_b, *lifter_p, *lifter_b;                        // lifter_p: [3J][4 kb] tiles
+    const float *norm_w, *norm_b, *lifter_w, *lifter_b;                        // lifter_w: the reference weight [3J][128J], row-major
     GatBlockP blk[kDepth];
     float *x_out, *feat;
     // optional epilogue (full forward): the MDR joint tokens and their per-layer cross-attention K/V (MDR.py:130-134,37-38,65),
@@ -473,50 +473,98 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         }
     }
     float* XO = R + 6 * kTile;            // x_out of this sample (3J floats), for the joint-token epilogue
-    f32x16 wl[4];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) wl[kb] = load_block(a.lifter_p + ((size_t)wave * 4 + kb) * kTile, lane);
+    GAT_STAMP(18)
+    // lifter (GAT.py:151-152): x_out[o] = <feat flattened [J*128], W[o]> + b[o].  The weight rows are read as the reference
+    // stores them ([3J][128J] row-major; one float2 per lane = 512 B per wave load, no padding to 32 tokens); each lane
+    // gathers the 2J feat values that face its weight elements from LDS once and keeps them for all of the wave's outputs.
+    constexpr int kJmax = 19;
+    const float* Wl = a.lifter_w + (size_t)lane * 2;
+    const size_t wrow = (size_t)kC * J;
     __syncthreads();
     f32x16 ft[4];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) ft[kb] = load_block(R + kb * kTile, lane);
-    for (int o = wave; o < 3 * J; o += 4) {
-        const int on = o + 4 < 3 * J ? o + 4 : o;                     // prefetch the next output's weight tiles
-        f32x16 nx[4];
+    for (int kb = 0; kb < 4; ++kb) ft[kb] = load_block(R + kb * kTile, lane);      // T-layout blocks for the joint-token epilogue
+    f32x2 fv[kJmax];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) nx[kb] = load_block(a.lifter_p + ((size_t)on * 4 + kb) * kTile, lane);
-        GATOR_PIN();
-        float s = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            float p = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p += ft[kb][r] * wl[kb][r];
-            s += p;
-        }
-        for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
-        if (lane == 0) {
-            const float xo = s + a.lifter_b[o];
-            a.x_out[(size_t)b * 3 * J + o] = xo;
-            XO[o] = xo;
-        }
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) wl[kb] = nx[kb];
+    for (int k = 0; k < kJmax; ++k) {
+        const int i = (k * 64 + lane) * 2, tk = i >> 7, ch = i & 127, cb = ch & 31;        // flat index -> (token, channel)
+        fv[k] = *reinterpret_cast<const f32x2*>(R + (ch >> 5) * kTile + (((cb >> 3) * 64 + tk + 32 * ((cb >> 2) & 1)) * 4 + (cb & 3)));
+        if (k >= J) fv[k] = f32x2(0.f);
     }
+    // Operands of the joint-token epilogue are requested here: one wave per SIMD means nothing else hides their latency,
+    // and vmcnt retires in order, so they are complete for free once the lifter loop's own loads have been waited for.
+    const int tkj = tok < J ? tok : 0;
+    WTile jw[4], kw[2];
+    f32x16 posj;
+    float p2x = 0.f, p2y = 0.f;
+    auto job_tile = [&](int job, int i) {
+        const int li = job >> 2, kv = (job >> 1) & 1, nb = job & 1;
+        return load_wtile(kv ? a.j_wv_p[li] : a.j_wk_p[li], nb * 2 + i, lane);
+    };
+    if (a.jkv) {
+        if (wave < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) jw[i] = load_wtile(a.jf_p, wave * 4 + i, lane);
+            posj = load_block(a.posj_T + (size_t)wave * kTile, lane);
+            p2x = a.pose2d[((size_t)b * J + tkj) * 2];
+            p2y = a.pose2d[((size_t)b * J + tkj) * 2 + 1];
+        }
+        kw[0] = job_tile(wave * 3, 0);
+        kw[1] = job_tile(wave * 3, 1);
+    }
+    GATOR_PIN();
+    // four outputs of the wave per trip (o = wave + 4i): all 4 x J row loads are in flight together, so the L2 latency is paid
+    // once per trip instead of once per output (one wave per SIMD: nobody else hides it)
+    for (int o0 = wave; o0 < 3 * J; o0 += 16) {
+        f32x2 wr[4][kJmax];
+        float bo[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int o = o0 + 4 * u < 3 * J ? o0 + 4 * u : o0;
+            bo[u] = a.lifter_b[o];
+#pragma unroll
+            for (int k = 0; k < kJmax; ++k)      // unconditional (a load under a runtime condition is branched around and waited for singly)
+                wr[u][k] = *reinterpret_cast<const f32x2*>(Wl + (size_t)o * wrow + (k < J ? k : 0) * 128);
+        }
+        float sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < kJmax; ++k) {    // fv[k] = 0 for k >= J
+                s0 += fv[k][0] * wr[u][k][0];
+                s1 += fv[k][1] * wr[u][k][1];
+            }
+            sv[u] = s0 + s1;
+        }
+        for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sv[u] += __shfl_xor(sv[u], d);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (o0 + 4 * u < 3 * J) {
+                    const float xo = sv[u] + bo[u];
+                    a.x_out[(size_t)b * 3 * J + o0 + 4 * u] = xo;
+                    XO[o0 + 4 * u] = xo;
+                }
+        }
+    }
+    GAT_STAMP(19)
     if (a.jkv) {
         // ---------------- MDR joint tokens: jf = Linear(133->64)(cat(pose2d, pose3d/1000, feat)) + pos_j ; per LBF layer
         // k = wk(LN1(jf)), v = wv(LN1(jf)) written as MFMA operand tiles (same layout as k_mdr_joint)
         __syncthreads();                                            // XO complete
         float* JF = R + 4 * kTile;                                  // 2 tiles
         if (wave < 2) {
-            f32x16 acc = load_chanvec_S(a.jf_b, 32 * wave, h) + load_block(a.posj_T + (size_t)wave * kTile, lane), ac1 = zero16();
-            const int tk = tok < J ? tok : 0;
-            const float* p2 = a.pose2d + ((size_t)b * J + tk) * 2;
-            const float pin[5] = {p2[0], p2[1], XO[tk * 3] / 1000.f, XO[tk * 3 + 1] / 1000.f, XO[tk * 3 + 2] / 1000.f};   // GATOR.py:19
+            f32x16 acc = load_chanvec_S(a.jf_b, 32 * wave, h) + posj, ac1 = zero16();
+            const int tk = tkj;
+            const float pin[5] = {p2x, p2y, XO[tk * 3] / 1000.f, XO[tk * 3 + 1] / 1000.f, XO[tk * 3 + 2] / 1000.f};   // GATOR.py:19
 #pragma unroll
             for (int i = 0; i < 5; ++i) acc += load_chanvec_S(a.jf5 + i * 64, 32 * wave, h) * pin[i];
-            mma2_T(load_wtile(a.jf_p, wave * 4 + 0, lane), ft[0], acc, load_wtile(a.jf_p, wave * 4 + 1, lane), ft[1], ac1);
-            mma2_T(load_wtile(a.jf_p, wave * 4 + 2, lane), ft[2], acc, load_wtile(a.jf_p, wave * 4 + 3, lane), ft[3], ac1);
+            mma2_T(jw[0], ft[0], acc, jw[1], ft[1], ac1);
+            mma2_T(jw[2], ft[2], acc, jw[3], ft[3], ac1);
             store_block(JF + wave * kTile, lane, acc + ac1);
         }
         __syncthreads();
@@ -530,22 +578,27 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
 #pragma unroll 1
         for (int job = wave * 3; job < wave * 3 + 3; ++job) {
             const int li = job >> 2, kv = (job >> 1) & 1, nb = job & 1;
+            const int jn = job + 1 < wave * 3 + 3 ? job + 1 : job;       // next job's weight tiles in flight during this one
+            const WTile nw0 = job_tile(jn, 0), nw1 = job_tile(jn, 1);
+            GATOR_PIN();
             f32x16 fz[2];
             fz[0] = d0 * rstd * load_chanvec_S(a.j_n1w[li], 0, h) + load_chanvec_S(a.j_n1b[li], 0, h);
             fz[1] = d1 * rstd * load_chanvec_S(a.j_n1w[li], 32, h) + load_chanvec_S(a.j_n1b[li], 32, h);
             float* out = a.jkv + (((size_t)b * 3 + li) * 4 + kv * 2 + nb) * kTile;
             f32x16 r0 = zero16(), r1 = zero16();
             if (kv == 0) {
-                mma2_T(load_wtile(a.j_wk_p[li], nb * 2 + 0, lane), fz[0], r0, load_wtile(a.j_wk_p[li], nb * 2 + 1, lane), fz[1], r1);
+                mma2_T(kw[0], fz[0], r0, kw[1], fz[1], r1);
                 r0 += r1;
                 if (tok >= J) r0 = zero16();                       // joints >= J: zero rows (masked in the softmax anyway)
             } else {
-                mma2_C(load_wtile(a.j_wv_p[li], nb * 2 + 0, lane), fz[0], r0, load_wtile(a.j_wv_p[li], nb * 2 + 1, lane), fz[1], r1);
+                mma2_C(kw[0], fz[0], r0, kw[1], fz[1], r1);
                 r0 += r1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) r0[r] = (kap(r) + 4 * h < J) ? r0[r] : 0.f;
             }
             store_block(out, lane, r0);
+            kw[0] = nw0;
+            kw[1] = nw1;
         }
     }
     GAT_STAMP(9)
@@ -561,7 +614,7 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
     a.B = B; a.J = c->J; a.pose2d = pose2d;
     a.gl0_W = w.gl0_W; a.gl0_b = w.gl0_b; a.gn_w = w.gn_w; a.gn_b = w.gn_b; a.gl3_p = f->g_gl3; a.gl3_b = w.gl3_b; a.posT = f->g_posT;
     a.biasT = f->g_biasT; a.m1T = f->g_m1T; a.m2T = f->g_m2T;
-    a.norm_w = w.norm_w; a.norm_b = w.norm_b; a.lifter_p = f->g_lifter; a.lifter_b = w.lifter_b;
+    a.norm_w = w.norm_w; a.norm_b = w.norm_b; a.lifter_w = w.lifter_w; a.lifter_b = w.lifter_b;
     for (int i = 0; i < kDepth; ++i) {
         const GatBlockW& r = w.blk[i];
         const GatBlockPk& p = f->gblk[i];
@@ -606,11 +659,13 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         static const char* nm[10] = {"embed", "ln1+qkv+attn+mgcn", "barrier1", "proj+prefetch+barrier2", "xfeat+barrier3",
                                      "back+barrier4", "ln2+fc1+gelu", "barrier5", "fc2+barrier6", "tail"};
         unsigned long long tot = 0;
-        for (int i = 0; i < 10; ++i) tot += hst[i];
+        hst[9] += 0; for (int i = 0; i < 10; ++i) tot += hst[i];
+        tot += hst[18] + hst[19];
         hst[1] += hst[10] + hst[11] + hst[12] + hst[13] + hst[14] + hst[15] + hst[16] + hst[17];
         fprintf(stderr, "[k_gat stamps, wg0 wave0, B=%d] total %llu cycles:", B, tot);
         for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%llu", nm[i], hst[i]);
         fprintf(stderr, " | phase1 detail: ln1=%llu q=%llu k=%llu v=%llu attn=%llu h0=%llu h1=%llu mgcn=%llu", hst[10], hst[11], hst[12], hst[13], hst[14], hst[15], hst[16], hst[17]);
+        fprintf(stderr, " | tail detail: ln+gelu+feat=%llu lifter=%llu joint tokens=%llu", hst[18], hst[19], hst[9]);
         fprintf(stderr, "\n");
     }
     return GATOR_OK;
