@@ -8,8 +8,11 @@ weak scaling: every rank owns its own 256 samples), inputs resident in HBM, foll
 of the predicted vertices [N*256, 6890, 3] over xGMI.  Rank 0 prints ONE JSON line.
 
 roofline  : the dominant kernel of the forward (largest share of device time), timed live with HIP events recorded by the
-            library on the launch stream (gator_profile_*), against the fp32 MFMA peak (157.3 TFLOP/s); algorithmic
-            FLOPs per stage from SURVEY Appendix D.
+            library on the launch stream (gator_profile_*); algorithmic (fp32) FLOPs per stage from SURVEY Appendix D.
+            `peak` is the MFMA peak of the pipe that kernel computes on: the fused kernels run their products on the bf16
+            MFMA with every fp32 operand split exactly into three bf16 planes and six partial products per fp32 product
+            (x3_common.h), so their ceiling is the dense bf16 peak / 6 = 416.7 TFLOP/s of fp32-equivalent work; a stage
+            switched back to the fp32-input MFMA (GATOR_*_X3=0) is priced against 157.3 TFLOP/s.
 cpu_baseline: the oracle (torch-CPU restatement of the reference forward, kind "port") timed on this box's host cores on a
             bounded sample (rank 0, N=1 only).
 """
@@ -26,6 +29,22 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
+PEAK_BF16_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak
+X3_PRODUCTS = 6                  # bf16 MFMA partial products per fp32 product on the split-precision path (x3_common.h)
+PEAK_X3_TFLOPS = round(PEAK_BF16_TFLOPS / X3_PRODUCTS, 1)
+# which switch moves a stage back to the fp32-input MFMA kernels (read by the library when the context is created)
+STAGE_X3_SWITCH = {'gat': 'GATOR_GAT_X3', 'mdr_layer0': 'GATOR_MDR_X3', 'mdr_layer': 'GATOR_MDR_X3', 'mdr_attn_head': 'GATOR_MDR_X3',
+                   'upsample': 'GATOR_UPSAMPLE_X3'}
+
+
+def stage_pipe(stage, impl):
+    """-> (pipe name, peak TFLOP/s of fp32-equivalent work) for a profiled stage."""
+    sw = STAGE_X3_SWITCH.get(stage)
+    if impl == 'fused' and sw is not None and os.environ.get(sw, '1') != '0':
+        return 'bf16 MFMA, split precision (3 planes, %d partial products per fp32 product)' % X3_PRODUCTS, PEAK_X3_TFLOPS
+    if stage == 'upsample_bf16':
+        return 'bf16 MFMA', PEAK_BF16_TFLOPS
+    return 'fp32-input MFMA', PEAK_F32_TFLOPS
 FLOPS_PER_MESH = {17: 4.10e8, 19: 4.18e8}      # SURVEY 8(d): dense algorithmic count
 # algorithmic MFLOP per mesh per stage, J=17 (SURVEY Appendix D)
 # mdr_layer  = one middle LBF launch: 431x431 attention core of layer l-1 (47.6) + its out-proj (3.5) + cross-attn/Mlp of
@@ -70,8 +89,8 @@ def build_model(J, impl, device):
     return m.to(device).eval(), base, alpha
 
 
-STAGE_KERNEL = {'gat': 'k_gat', 'mdr_layer0': 'k_mdr_layer<0>', 'mdr_layer': 'k_mdr_layer<1>', 'mdr_attn_head': 'k_mdr_layer<2>',
-                'upsample': 'k_upsample'}
+STAGE_KERNEL = {'gat': 'k_gat<true>', 'mdr_layer0': 'k_mdr_layer<0, true>', 'mdr_layer': 'k_mdr_layer<1, true>',
+                'mdr_attn_head': 'k_mdr_layer<2, true>', 'upsample': 'k_upsample_x3'}
 
 
 def pmc_traffic(stage, B):
@@ -175,8 +194,9 @@ def main():
             if mflop is not None and avg_s > 0:
                 ach = mflop * 1e6 * B / avg_s / 1e12
                 traffic = pmc_traffic(name, B)
-                roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(ach / PEAK_F32_TFLOPS, 4), 'traffic': traffic, 'avg_launch_ms': round(avg_s * 1e3, 4),
+                pipe, peak = stage_pipe(name.split(':')[0], a.impl)
+                roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                        'frac': round(ach / peak, 4), 'traffic': traffic, 'avg_launch_ms': round(avg_s * 1e3, 4), 'pipe': pipe,
                         'stages_ms': {k: round(v[0] / v[1], 4) for k, v in prof.items()}}
         if roof is None:   # no per-kernel events available (bring-up path): price the whole forward
             ach = FLOPS_PER_MESH[J] * value / world / 1e12
