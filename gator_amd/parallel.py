@@ -12,9 +12,10 @@ import torch
 
 
 class ShardedForward:
-    def __init__(self, model, world_size=1, rank=0, dist=None, micro_batch=None):
+    def __init__(self, model, world_size=1, rank=0, dist=None, micro_batch=None, always_gather=False):
         self.model, self.world, self.rank, self.dist = model, world_size, rank, dist
         self.micro = micro_batch
+        self.always_gather = always_gather      # run the collective even for one rank (exercises RCCL on a 1-GPU box)
         self._bufs = {}
         self._comm_stream = None
         self._flip = 0
@@ -36,7 +37,7 @@ class ShardedForward:
     def step(self, pose2d_shard):
         """pose2d_shard [B_local, J, 2] on this rank's GPU -> (verts [world*B_local,6890,3], pose3d [world*B_local,J,3])
         replicated on every rank (rank r's samples at rows r*B_local ...)."""
-        if self.world == 1 or self.dist is None:
+        if self.dist is None or (self.world == 1 and not self.always_gather):
             return self.model(pose2d_shard)
         B, J = pose2d_shard.shape[0], pose2d_shard.shape[1]
         dev = pose2d_shard.device
