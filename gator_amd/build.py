@@ -12,6 +12,12 @@ SOURCES = ['api.hip', 'basic_kernels.hip', 'fused_api.hip', 'fused_pack.hip', 'u
 HEADERS = ['internal.h', os.path.join(ROOT, 'include', 'gator_hip.h')]
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
          '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+# Measured on gfx950 (tools/microbench/coissue.hip): up to six plain VALU instructions (v_fma_f32, v_cvt_pk_bf16_f32, v_cndmask
+# ...) issue in the shadow of one bf16 MFMA for ~0.6 cycles each, while a v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 never hides
+# and adds 6-8 cycles.  Building the MFMA kernels without the packed forms (the flags below) was tried and is NOT used: the
+# VALU-bound parts (exact GELU, operand splits) lose more than the MFMA-adjacent parts gain (1.00 -> 1.03 ms per step).
+NO_PK = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+NO_PK_SOURCES = ()
 
 
 def _stale(target, deps):
@@ -34,7 +40,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, s.rsplit('.', 1)[0] + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + (['-x', 'hip'] if s.endswith('.hip') else []) + ['-c', src, '-o', obj]
+            cmd = [hipcc] + FLAGS + (NO_PK if s in NO_PK_SOURCES else []) + (['-x', 'hip'] if s.endswith('.hip') else []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))

@@ -220,6 +220,28 @@ __device__ __forceinline__ f32x16 load_chanvec_S(const float* vec, int base, int
     return v;
 }
 
+// The same in two steps, so that the scalar loads can be ISSUED ahead of a block of MFMAs and CONSUMED after it: an s_load
+// waited for at its point of use costs its whole latency (1-2k cycles under load when the wave is alone on its SIMD).
+struct SVec { float lo[16], hi[16]; };
+__device__ __forceinline__ SVec chanvec_issue(const float* vec, int base) {
+    const gator_cfloat* cv = (const gator_cfloat*)(unsigned long long)(vec + base);
+    SVec s;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s.lo[4 * g + j] = cv[8 * g + j];
+            s.hi[4 * g + j] = cv[8 * g + 4 + j];
+        }
+    return s;
+}
+__device__ __forceinline__ f32x16 chanvec_select(const SVec& s, int h) {
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = h ? s.hi[r] : s.lo[r];
+    return v;
+}
+
 // XCD-aware bijective remap of a 1-D grid: blocks that share an XCD (equal blockIdx % 8) get CONTIGUOUS logical ids,
 // so the workgroups of one sample hit one L2.  Speed only -- never correctness (cdna_hip_programming.md T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

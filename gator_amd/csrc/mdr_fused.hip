@@ -178,8 +178,8 @@ __device__ __forceinline__ f32x16 self_attention_head(const float* __restrict__ 
     {                                                                                                       \
         f32x16 S = x3_mma(KB, qx, zero16());  /* S^T[key][query] */                                         \
         float bm = -1e30f;                                                                                  \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
-            float sc = S[r] * c;                                                                            \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {   /* Q arrives pre-scaled by log2(e)/sqrt(d_k) */ \
+            float sc = S[r];                                                                                \
             if ((KT) == kVT - 1 && kap(r) + 4 * h >= kV - 32 * (kVT - 1)) sc = -1e30f;                      \
             S[r] = sc;                                                                                      \
             bm = fmaxf(bm, sc);                                                                             \
@@ -208,7 +208,6 @@ __device__ __forceinline__ f32x16 self_attention_head_x3(const float* __restrict
     const X3 qx = x3_load(qt, lane);
     f32x16 O = zero16(), O2 = zero16();
     float m = -1e30f, l = 0.f;
-    const float c = kLog2e * 0.17677669529663688110f;
     X3 kb = x3_load(kbase, lane), vb = x3_load(vbase, lane);
 #pragma unroll 1
     for (int kt = 0; kt < kVT; kt += 2) {                   // tiles kt (-> O) and kt + 1 (-> O2); the next tile's K/V in flight
@@ -460,11 +459,20 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         acc2[1][0] = load_chanvec_S(w.fc2_b, 32, h);
         acc2[0][1] = zero16();
         acc2[1][1] = zero16();
-#pragma unroll
+#pragma unroll 1
         for (int c = 0; c < 8; ++c) {           // 256 hidden units in 8 chunks of 32: fc1 -> GELU -> fc2 partial
-            f32x16 hdn = lin2_T(A, y2, load_chanvec_S(w.fc1_b, 32 * c, h));
-            if (c < 7) A = ldw<X>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<X>(w.sa0, 0, 1, lane);
-            MDR_PIN();
+            f32x16 hdn;
+            if constexpr (X) {      // bias after the products: its scalar loads fly during the MFMAs instead of in front of them
+                const SVec b1 = chanvec_issue(w.fc1_b, 32 * c);
+                hdn = lin2_T(A, y2, zero16());
+                if (c < 7) A = ldw<X>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<X>(w.sa0, 0, 1, lane);
+                MDR_PIN();
+                hdn += chanvec_select(b1, h);
+            } else {
+                hdn = lin2_T(A, y2, load_chanvec_S(w.fc1_b, 32 * c, h));
+                if (c < 7) A = ldw<X>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<X>(w.sa0, 0, 1, lane);
+                MDR_PIN();
+            }
             gelu_tile(hdn);
             if constexpr (X) {
                 const X3 hx = x3_split(hdn);
@@ -498,6 +506,10 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         f32x16 y1 = lin2_T(B, vfx, load_chanvec_S(w.sa0_b, 32, h));
         B = ldw<X>(w.sa1, 2, 3, lane);
         MDR_PIN();
+        if constexpr (X) {      // the consumer's softmax works in the exp2 domain: fold log2(e) / sqrt(d_k) into Q once, here
+            y0 = y0 * (kLog2e * 0.17677669529663688110f);
+            y1 = y1 * (kLog2e * 0.17677669529663688110f);
+        }
         st_op<X>(a.q_out + (tile + 0) * TQ, lane, y0);
         st_op<X>(a.q_out + (tile + 1) * TQ, lane, y1);
         y0 = lin2_T(A, vfx, load_chanvec_S(w.sa1_b, 0, h));
@@ -736,9 +748,10 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         if (li > 0) a.prev = make_layer(f, c, li - 1);
         if (li < 3) a.cur = make_layer(f, c, li);
         StageTimer tm(c, li == 0 ? "mdr_layer0" : (li < 3 ? "mdr_layer" : "mdr_attn_head"), stream);
+        static const size_t solo = getenv("GATOR_MDR_SOLO") ? 60 * 1024 : 0;      // diagnostic: 1 workgroup per CU (1 wave/SIMD)
         if (f->mdr_x3) {
-            if (li == 0) k_mdr_layer<0, true><<<nwg, 256, 0, st>>>(a, nwg);
-            else if (li < 3) k_mdr_layer<1, true><<<nwg, 256, 0, st>>>(a, nwg);
+            if (li == 0) k_mdr_layer<0, true><<<nwg, 256, solo, st>>>(a, nwg);
+            else if (li < 3) k_mdr_layer<1, true><<<nwg, 256, solo, st>>>(a, nwg);
             else k_mdr_layer<2, true><<<nwg, 256, 0, st>>>(a, nwg);
         } else {
             if (li == 0) k_mdr_layer<0, false><<<nwg, 256, 0, st>>>(a, nwg);
