@@ -614,13 +614,14 @@ struct HeadArgs {
     size_t vcp3_plane;
     int alpha;
 };
-__global__ __launch_bounds__(256) void k_mdr_head(const HeadArgs a) {
+template <int NT>
+__global__ __launch_bounds__(NT) void k_mdr_head(const HeadArgs a) {
     __shared__ float bn[kV][3];
-    __shared__ float part[4][60];
+    __shared__ float part[NT / 64][60];
     __shared__ float bc[20][3];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* hf = a.hf + (size_t)b * kV * 32;
-    for (int v = t; v < kV; v += 256) {
+    for (int v = t; v < kV; v += NT) {
         const f32x4 q = *reinterpret_cast<const f32x4*>(hf + v * 32 + 24);
         float x[3] = {q[0], q[1], q[2]};
         if (a.alpha) {      // LayerNorm(3)
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(256) void k_mdr_head(const HeadArgs a) {
         float acc[20][3];
 #pragma unroll
         for (int m = 0; m < 20; ++m) acc[m][0] = acc[m][1] = acc[m][2] = 0.f;
-        for (int e = t; e < kV * 3; e += 256) {
+        for (int e = t; e < kV * 3; e += NT) {
             const int c = e / 3, k = e - 3 * c;
             // tap k of channel c meets input position ll = l + k - 1 (zero padding outside 0..2)
             const float in0 = (k >= 1) ? bn[c][k - 1] : 0.f;        // l=0: ll = k-1
@@ -663,10 +664,15 @@ __global__ __launch_bounds__(256) void k_mdr_head(const HeadArgs a) {
             }
     }
     __syncthreads();
-    if (t < 60) bc[t / 3][t % 3] = (float)(((double)part[0][t] + (double)part[1][t]) + ((double)part[2][t] + (double)part[3][t]) + (double)a.bconv_b[t / 3]);
+    if (t < 60) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) sacc += (double)part[w][t];
+        bc[t / 3][t % 3] = (float)(sacc + (double)a.bconv_b[t / 3]);
+    }
     __syncthreads();
     const int mt = b >> 5, sl = b & 31;
-    for (int v = t; v < kV; v += 256) {
+    for (int v = t; v < kV; v += NT) {
         const float* r = hf + v * 32;
         float av[20];
 #pragma unroll
@@ -779,7 +785,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     ha.bconv_w = w.bconv_w; ha.bconv_b = w.bconv_b; ha.vc = f->vc; ha.vcp = f->vcp;
     ha.vcp3 = f->x3 ? (__bf16*)f->vcp3 : nullptr; ha.vcp3_plane = upsample_x3_vcp_elems(f->cap) / 3;     // plane stride fixed by the workspace capacity
     ha.alpha = c->alpha;
-    { StageTimer tm(c, "mdr_head", stream); k_mdr_head<<<B, 256, 0, st>>>(ha); }
+    { StageTimer tm(c, "mdr_head", stream); k_mdr_head<512><<<B, 512, 0, st>>>(ha); }
     GATOR_HIP_CHECK(hipGetLastError());
     c->taps["mdr_lbf2"] = {f->lbf, (int64_t)B * kV * kE};
     c->taps["vert431"] = {f->vc, (int64_t)B * kV * 3};
