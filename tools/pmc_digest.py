@@ -16,8 +16,8 @@ def short(name):
 
 
 def find(pattern):
-    r = glob.glob(os.path.join(src, pattern), recursive=True)
-    return r[0] if r else None
+    r = glob.glob(os.path.join(src, pattern), recursive=True)      # gpurun MERGES into gpurun_out/: keep the newest run
+    return max(r, key=os.path.getmtime) if r else None
 
 
 def pmc_rows(path):
