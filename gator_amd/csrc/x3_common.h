@@ -23,17 +23,6 @@ constexpr int kTileX3 = 1536;       // floats-equivalent of one X3 operand tile
 
 struct X3 { bf16x8 p[3][2]; };      // [plane hi/mid/lo][k-step]: 24 VGPRs
 
-// a - b as a plain v_sub_f32: hipcc would pair two of these into a v_pk_add_f32, and packed fp32 instructions do not issue in
-// the shadow of an MFMA (tools/microbench/coissue.hip: +6..8 cycles each, against ~0.6 for a plain VALU instruction)
-__device__ __forceinline__ float x3_sub(float a, float b) {
-#ifdef GATOR_X3_SCALAR_SUB
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return a - b;
-#endif
-}
 __device__ __forceinline__ X3 x3_split(const f32x16& v) {
     X3 o;
 #pragma unroll
@@ -42,11 +31,11 @@ __device__ __forceinline__ X3 x3_split(const f32x16& v) {
         for (int j = 0; j < 8; ++j) {
             const float x = v[8 * s + j];
             const __bf16 h = (__bf16)x;
-            const float r = x3_sub(x, (float)h);
+            const float r = x - (float)h;
             const __bf16 m = (__bf16)r;
             o.p[0][s][j] = h;
             o.p[1][s][j] = m;
-            o.p[2][s][j] = (__bf16)x3_sub(r, (float)m);
+            o.p[2][s][j] = (__bf16)(r - (float)m);
         }
     return o;
 }
