@@ -49,6 +49,9 @@ typedef struct {
     int32_t reserved;
 } gator_tensor;
 
+/* GATOR_IMPL_FUSED computes its large products on the bf16 MFMA from an exact three-way bf16 split of every fp32 operand
+ * (fp32-accurate; csrc/x3_common.h).  The environment variables GATOR_GAT_X3, GATOR_MDR_X3, GATOR_UPSAMPLE_X3 (= 0), read by
+ * gator_create, select the fp32-input-MFMA form of a stage instead (same accuracy class, slower; A/B runs and tests). */
 typedef enum { GATOR_IMPL_FUSED = 0,   /* MFMA / register-resident fused kernels (default) */
                GATOR_IMPL_BASIC = 1    /* bring-up kernels: one simple HIP kernel per reference op; used as an
                                           on-device cross-check of the fused path */
