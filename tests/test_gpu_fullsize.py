@@ -71,3 +71,19 @@ def test_large_batch_b2048_j19():
     assert torch.equal(vs, v[idx]) and torch.equal(ps, p[idx])
     ref, _ = go.gator_forward(sd, c, x[idx].cpu(), torch.float64)
     assert np.abs(vs.cpu().numpy() - ref.numpy()).max() * 1e3 <= 1e-3
+
+
+def test_subbatch_streams_bitwise(setup):
+    """gator_config.subbatch_streams = 2 (two half-batches on two internal streams, forked from / joined to the caller's
+    stream by events) returns exactly the single-stream result, for even and odd splits and when called repeatedly."""
+    m, x, v, p = setup
+    z, m2 = build_model('h36m17_bn', 'fused')
+    m2.subbatch_streams = 2
+    for _ in range(2):
+        v2, p2 = m2(x)
+        assert torch.equal(v2, v) and torch.equal(p2, p)
+    for n in (255, 129, 128):
+        vs, ps = m2(x[:n].contiguous())
+        assert torch.equal(vs, v[:n]) and torch.equal(ps, p[:n]), n
+    vs, ps = m2(x[:64].contiguous())            # below the threshold: plain path, same context
+    assert torch.equal(vs, v[:64]) and torch.equal(ps, p[:64])
