@@ -2,7 +2,7 @@
 
   joints  = J_regressor @ (verts * 1000)          lib/core/base.py:219-221, demo/run.py:142   -> gator_regress_joints_f32
   MPJPE   = mean || root-aligned pred - target ||  data/PW3D/dataset.py:273-286, data/Human36M/dataset.py:466-478
-  PA-MPJPE via the rigid (Procrustes) alignment    lib/coord_utils.py:127-149
+  PA-MPJPE via the rigid (Procrustes) alignment    lib/coord_utils.py:127-149                  -> gator_rigid_align_f32
 
 so that evaluation needs [B,17,3] + a few scalars on the host instead of a D2H copy of every 82 kB mesh
 (lib/core/base.py:223,232-237 copy each mesh to the host twice)."""
@@ -61,20 +61,18 @@ def mpvpe(pred_mesh, target_mesh, pred_joint, target_joint, root=0):
 
 def rigid_align(a, b):
     """Batched similarity (Procrustes) alignment of a onto b, [B,N,3] device tensors (lib/coord_utils.py:127-149:
-    rotation by SVD of the covariance with the reflection fix, scale = trace(S)/var(a), translation of the centroids)."""
-    ca, cb = a.mean(1, keepdim=True), b.mean(1, keepdim=True)
-    a0, b0 = a - ca, b - cb
-    H = a0.transpose(1, 2) @ b0
-    U, S, Vt = torch.linalg.svd(H.double())
-    R = Vt.transpose(1, 2) @ U.transpose(1, 2)
-    neg = torch.linalg.det(R) < 0
-    Vt = torch.where(neg[:, None, None], torch.cat([Vt[:, :2], -Vt[:, 2:]], 1), Vt)
-    S = torch.where(neg[:, None], torch.cat([S[:, :2], -S[:, 2:]], 1), S)
-    R = Vt.transpose(1, 2) @ U.transpose(1, 2)
-    var_a = (a0.double() ** 2).sum((1, 2)) / a.shape[1]
-    c = (S.sum(1) / a.shape[1]) / var_a
-    t = cb.double().transpose(1, 2) - c[:, None, None] * (R @ ca.double().transpose(1, 2))
-    return (c[:, None, None] * (R @ a.double().transpose(1, 2)) + t).transpose(1, 2).to(a.dtype)
+    rotation by SVD of the covariance with the reflection fix, scale = trace(S)/var(a), translation of the centroids):
+    gator_rigid_align_f32, one 3x3 one-sided-Jacobi SVD per sample in fp64."""
+    if not (a.is_cuda and b.is_cuda):
+        raise RuntimeError('rigid_align: inputs must live on a HIP device')
+    if a.shape != b.shape or a.dim() != 3 or a.shape[2] != 3:
+        raise ValueError('rigid_align: expected two [B,N,3] tensors, got %s and %s' % (tuple(a.shape), tuple(b.shape)))
+    a32, b32 = a.contiguous().float(), b.contiguous().float()
+    out = torch.empty_like(a32)
+    st = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+    _lib.check(_lib.load().gator_rigid_align_f32(a32.data_ptr(), b32.data_ptr(), a32.shape[0], a32.shape[1], out.data_ptr(), st),
+               'gator_rigid_align_f32')
+    return out.to(a.dtype)
 
 
 def pa_mpjpe(pred_joint, target_joint, eval_joints=H36M_EVAL_JOINTS):

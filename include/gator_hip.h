@@ -110,6 +110,19 @@ int gator_profile_read(gator_ctx* ctx, char* names, int64_t names_capacity, floa
 int gator_regress_joints_f32(const float* verts, int32_t batch, const int32_t* coo_row, const int32_t* coo_col,
                              const float* coo_val, int32_t nnz, int32_t n_joint, float* joints, void* stream);
 
+/* "Next" row 8(f)-3: the input contract in front of the path (demo/run.py:103-121,127-134, data/PW3D/dataset.py:168-183,241-250):
+ *   joints [batch, num_joint_in, comps] raw 2D joints in pixels (comps >= 2: x, y[, score]); add_pelvis_neck != 0 appends
+ *   pelvis = (joint 11 + joint 12)/2 and neck = (joint 5 + joint 6)/2 (COCO order); pose2d [batch, num_joint_out, 2] =
+ *   per-sample per-axis (xy - mean) / std over the joints (population std) -- what the bbox/affine/normalise chain reduces
+ *   to for rot = 0, flip = 0. */
+int gator_preprocess_pose2d_f32(const float* joints, int32_t batch, int32_t num_joint_in, int32_t comps,
+                                int32_t add_pelvis_neck, float* pose2d, void* stream);
+
+/* "Next" row 8(f)-2: per-sample similarity (Procrustes) alignment of a onto b, [batch, n_points, 3] each
+ * (rigid_transform_3D / rigid_align, lib/coord_utils.py:127-149: 3x3 SVD with the reflection fix, scale, translation);
+ * the kernel under PA-MPJPE (data/PW3D/dataset.py:337-375). */
+int gator_rigid_align_f32(const float* a, const float* b, int32_t batch, int32_t n_points, float* aligned, void* stream);
+
 /* Host-side graph constants (no GPU needed).  Replace the absent Cython algos.pyx
  * (lib/models/backbones/setup.py:1-6) and lib/models/backbones/modules.py:6-29, lib/graph_utils.py:71-89. */
 int gator_floyd_warshall(const float* adj, int32_t n, int64_t* dist, int64_t* path);
