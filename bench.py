@@ -1,11 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- meshes/sec of the GATOR forward (GAT encoder + MDR head -> 6890 vertices) on N MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" = one GATOR.forward over a batch of B=256 synthetic Human3.6M 17-joint poses per GPU (BASELINE.json configs[1];
-weak scaling: every rank owns its own 256 samples), inputs resident in HBM, followed -- for N>1 -- by the RCCL all-gather
-of the predicted vertices [N*256, 6890, 3] over xGMI.  Rank 0 prints ONE JSON line.
+N = 1 runs in this process.  N > 1: one rank per GPU over RCCL.  When the script is started directly (no RANK in the
+environment) it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process -- before
+anything in this process has touched the GPU -- relays rank 0's JSON line and exits with the child's code; when it is
+started by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE set) it is one of the ranks, and --gpus must equal WORLD_SIZE.
+
+A "step" = one GATOR.forward over a batch of B synthetic poses per GPU (default: B=256 Human3.6M 17-joint, BASELINE.json
+configs[1]; weak scaling: every rank owns its own B samples), inputs resident in HBM, followed -- for N>1 -- by the RCCL
+all-gather of the predicted vertices [N*B, 6890, 3] over xGMI.  Rank 0 prints ONE JSON line.
+
+Timing: W warm-up steps, then R blocks (default 11) of EXACTLY K steps, each block bracketed by barrier + synchronize on
+both sides and reduced with MAX over ranks; the line reports the MEDIAN block (`ms_per_step` x `steps` = that block).
 
 roofline  : the dominant kernel of the forward (largest share of device time), timed live with HIP events recorded by the
             library on the launch stream (gator_profile_*); algorithmic (fp32) FLOPs per stage from SURVEY Appendix D.
@@ -13,28 +21,91 @@ roofline  : the dominant kernel of the forward (largest share of device time), t
             MFMA with every fp32 operand split exactly into three bf16 planes and six partial products per fp32 product
             (x3_common.h), so their ceiling is the dense bf16 peak / 6 = 416.7 TFLOP/s of fp32-equivalent work; a stage
             switched back to the fp32-input MFMA (GATOR_*_X3=0) is priced against 157.3 TFLOP/s.
-cpu_baseline: the oracle (torch-CPU restatement of the reference forward, kind "port") timed on this box's host cores on a
-            bounded sample (rank 0, N=1 only).
+cpu_baseline: the oracle (torch-CPU restatement of the reference forward, kind "port") timed on this box's host cores with
+            BASELINE.md section 3's protocol (B in {16,64,256}, 3 warm-up + 10 timed, median per B, best B), rank 0, N=1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 PEAK_BF16_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak
 X3_PRODUCTS = 6                  # bf16 MFMA partial products per fp32 product on the split-precision path (x3_common.h)
 PEAK_X3_TFLOPS = round(PEAK_BF16_TFLOPS / X3_PRODUCTS, 1)
 # which switch moves a stage back to the fp32-input MFMA kernels (read by the library when the context is created)
-STAGE_X3_SWITCH = {'gat': 'GATOR_GAT_X3', 'mdr_layer0': 'GATOR_MDR_X3', 'mdr_layer': 'GATOR_MDR_X3', 'mdr_attn_head': 'GATOR_MDR_X3',
-                   'upsample': 'GATOR_UPSAMPLE_X3'}
+STAGE_X3_SWITCH = {'gat': 'GATOR_GAT_X3', 'gat_tail': None, 'mdr_layer0': 'GATOR_MDR_X3', 'mdr_layer': 'GATOR_MDR_X3',
+                   'mdr_attn_head': 'GATOR_MDR_X3', 'upsample': 'GATOR_UPSAMPLE_X3'}
+FLOPS_PER_MESH = {17: 4.10e8, 19: 4.18e8}      # SURVEY 8(d): dense algorithmic count
+BYTES_PER_MESH = {17: 83020, 19: 83060}        # SURVEY 8(d): compulsory HBM bytes (pose2d in, vertices + pose3d out)
+# algorithmic MFLOP per mesh per stage, J=17 (SURVEY Appendix D)
+# mdr_layer  = one middle LBF launch: 431x431 attention core of layer l-1 (47.6) + its out-proj (3.5) + cross-attn/Mlp of
+#              layer l (37.5) + q/k/v in-proj of layer l (10.6) = 99.2 ; mdr_layer0 = tokenise + the last two items
+STAGE_MFLOP = {'upsample_bf16': 53.45, 'gat': 56.66, 'mdr_layer0': 48.7, 'mdr_layer': 99.2, 'mdr_attn_head': 51.4, 'mdr_head': 1.3,
+               'upsample': 53.45}
+# inter-kernel operand bytes per mesh the dominant kernels are DESIGNED to move (DESIGN.md section 3): the residual tile set
+# vf (14 tiles x 2 blocks x 4 KiB) and the Q/K/V tile sets as split-precision planes (x 1.5), read and/or written once
+_VF, _QKV = 14 * 2 * 4096, 3 * 14 * 2 * 6144
+STAGE_BYTES = {'mdr_layer0': _VF + _QKV, 'mdr_layer': 2 * (_VF + _QKV), 'mdr_attn_head': _VF + _QKV + 431 * 32 * 4 + 431 * 64 * 4,
+               'upsample': 3 * 431 * 2 * 3 + 6890 * 3 * 4, 'gat': 136 + 17 * 128 * 4 + 204 + 12 * 4096}
+STAGE_KERNEL = {'gat': 'k_gat', 'mdr_layer0': 'k_mdr_layer<0, true>', 'mdr_layer': 'k_mdr_layer<1, true>',
+                'mdr_attn_head': 'k_mdr_layer<2, true>', 'upsample': 'k_upsample_x3'}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--blocks', type=int, default=11, help='timed blocks of --steps steps each; the median block is reported')
+    ap.add_argument('--batch', type=int, default=256, help='samples per GPU per step')
+    ap.add_argument('--joints', type=int, default=17)
+    ap.add_argument('--impl', default=os.environ.get('GATOR_AMD_IMPL', 'fused'))
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'], help='bf16: vertex regressor on bf16 MFMA (config 3)')
+    ap.add_argument('--mode', default='gather', choices=['gather', 'eval'],
+                    help='N>1: all-gather the vertices (config 4) or the all-reduce-only evaluation mode (config 5)')
+    ap.add_argument('--subbatch-variant', action='store_true', help='also time the sub-batch-streams=2 mode (extra key)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a):
+    """Started directly with --gpus N > 1: run the N ranks as a child torch.distributed.run (this process never initialises
+    the GPU, and nothing is exec'd over a GPU-touched process), relay its output, return its exit code."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:
+        s = ln.strip()
+        if s.startswith('{') and '"metric"' in s:
+            line = s
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write('bench.py: the ranks exited without printing a result line\n')
+        rc = 1
+    return rc
 
 
 def stage_pipe(stage, impl):
@@ -45,30 +116,12 @@ def stage_pipe(stage, impl):
     if stage == 'upsample_bf16':
         return 'bf16 MFMA', PEAK_BF16_TFLOPS
     return 'fp32-input MFMA', PEAK_F32_TFLOPS
-FLOPS_PER_MESH = {17: 4.10e8, 19: 4.18e8}      # dense algorithmic count
-# algorithmic MFLOP per mesh per stage, J=17
-# mdr_layer  = one middle LBF launch: 431x431 attention core of layer l-1 (47.6) + its out-proj (3.5) + cross-attn/Mlp of
-#              layer l (37.5) + q/k/v in-proj of layer l (10.6) = 99.2 ; mdr_layer0 = tokenise + the last two items
-STAGE_MFLOP = {'upsample_bf16': 53.45, 'gat': 56.66, 'mdr_layer0': 48.7, 'mdr_layer': 99.2, 'mdr_attn_head': 51.4, 'mdr_head': 1.3, 'upsample': 53.45}
-
-
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=256, help='samples per GPU per step')
-    ap.add_argument('--joints', type=int, default=17)
-    ap.add_argument('--impl', default=os.environ.get('GATOR_AMD_IMPL', 'fused'))
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'], help='bf16: vertex regressor on bf16 MFMA (config 3)')
-    ap.add_argument('--subbatch-variant', action='store_true', help='also time the sub-batch-streams=2 mode (extra key)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0)
-    return ap.parse_args()
 
 
 def build_model(J, impl, device):
+    import numpy as np
     import scipy.sparse as sps
+    import torch
     from gator_amd import models, synthetic
     alpha = J == 19
     base = synthetic.make_base_data(0)
@@ -77,8 +130,8 @@ def build_model(J, impl, device):
     sk19 = ((1, 2), (0, 1), (0, 2), (2, 4), (1, 3), (6, 8), (8, 10), (5, 7), (7, 9), (12, 14), (14, 16), (11, 13), (13, 15),
             (17, 11), (17, 12), (17, 18), (18, 5), (18, 6), (18, 0), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12), (13, 14), (15, 16))
     adj = np.eye(J)
-    for a, b in (sk17 if J == 17 else sk19):
-        adj[a, b] = adj[b, a] = 1
+    for p, q in (sk17 if J == 17 else sk19):
+        adj[p, q] = adj[q, p] = 1
     m = models.GATOR.get_model(J, 128, 6, [None, sps.csr_matrix(adj)], 1, torch.Tensor(synthetic.model_j_regressor(J)),
                                base_data=base, alpha=alpha)
     sd = m.state_dict()
@@ -89,25 +142,29 @@ def build_model(J, impl, device):
     return m.to(device).eval(), base, alpha
 
 
-STAGE_KERNEL = {'gat': 'k_gat<true>', 'mdr_layer0': 'k_mdr_layer<0, true>', 'mdr_layer': 'k_mdr_layer<1, true>',
-                'mdr_attn_head': 'k_mdr_layer<2, true>', 'upsample': 'k_upsample_x3'}
-
-
 def pmc_traffic(stage, B):
     """HBM-side bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 as the gfx950
     guide prescribes, + WRITE_SIZE), collected with this same command at B=256; None for other batch sizes / kernels."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary_B256.json')
-    if B != 256 or not os.path.exists(path):
+    if B != 256:
         return None
-    for row in json.load(open(path)):
-        if row['kernel'] == STAGE_KERNEL.get(stage):
-            return int((row['fetch_MB_corrected'] + row['write_MB']) * 1048576)
+    for name in ('r02_pmc_summary_B256.json', 'r01_pmc_summary_B256.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(path):
+            continue
+        want = STAGE_KERNEL.get(stage, '')
+        for row in json.load(open(path)):
+            if row['kernel'].startswith(want) and want:
+                return int((row['fetch_MB_corrected'] + row['write_MB']) * 1048576)
     return None
 
 
-def cpu_baseline(model, base, alpha, J, seconds):
-    """Oracle fp32 on the host cores: bounded sample of the same workload (synthetic poses, same weights).  The thread count
-    is swept (all cores is pathological for these tiny tensors on a 100+-core host) and the best rate is reported."""
+def cpu_baseline(model, base, alpha, J):
+    """Oracle fp32 on the host cores, BASELINE.md section 3: B in {16, 64, 256}, 3 warm-up + 10 timed forwards each, median
+    meshes/s per B, best B reported.  Thread count: `torch.set_num_threads(os.cpu_count())` is pathological on the GPU box's
+    100+-thread host (1.2 meshes/s at 256 threads: these are tiny tensors), so the count is picked once by a short probe
+    (one B=64 forward each at 8/16/32 threads) and stated."""
+    import numpy as np
+    import torch
     from gator_amd import synthetic
     from oracle import gator_oracle as go
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -116,36 +173,51 @@ def cpu_baseline(model, base, alpha, J, seconds):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cands = sorted({n for n in (8, 16, 32, 64) if n <= avail}) or [avail]   # >64 threads: minutes per forward
-    best, sample, cores = 0.0, '', 1
-    t_end = time.time() + seconds
-    per = seconds / (len(cands) * 2)
-    for nt in cands:
+    cands = sorted({n for n in (8, 16, 32) if n <= avail}) or [avail]
+    xp = torch.from_numpy(synthetic.synthetic_pose2d(64, J, seed=1))
+    probe = {}
+    with torch.no_grad():
+        for nt in cands:
+            torch.set_num_threads(nt)
+            go.gator_forward(sd, c, xp, torch.float32)
+            t0 = time.perf_counter()
+            go.gator_forward(sd, c, xp, torch.float32)
+            probe[nt] = time.perf_counter() - t0
+        nt = min(probe, key=probe.get)
         torch.set_num_threads(nt)
-        for B in (64, 256):
+        per_b = {}
+        for B in (16, 64, 256):
             x = torch.from_numpy(synthetic.synthetic_pose2d(B, J, seed=1))
-            t_stop = time.time() + per
-            go.gator_forward(sd, c, x, torch.float32)                      # warm-up
+            for _ in range(3):
+                go.gator_forward(sd, c, x, torch.float32)
             ts = []
-            while len(ts) < 5 and (time.time() < t_stop or len(ts) < 1):
+            for _ in range(10):
                 t0 = time.perf_counter()
                 go.gator_forward(sd, c, x, torch.float32)
                 ts.append(time.perf_counter() - t0)
-            rate = B / float(np.median(ts))
-            if rate > best:
-                best, cores = rate, nt
-                sample = 'B=%d x %d timed forwards (median), fp32 torch-CPU, %d of %d host threads (best of sweep %s)' % (
-                    B, len(ts), nt, avail, cands)
-        if time.time() > t_end + seconds:
-            break
-    return {'value': round(best, 1), 'unit': 'meshes/sec', 'cores': int(cores), 'kind': 'port', 'sample': sample}
+            per_b[B] = B / float(np.median(ts))
+    bb = max(per_b, key=per_b.get)
+    return {'value': round(per_b[bb], 1), 'unit': 'meshes/sec', 'cores': int(nt), 'kind': 'port',
+            'sample': 'B in {16,64,256} x (3 warm-up + 10 timed forwards), median per B, best B=%d; fp32 torch-CPU oracle, %d of %d '
+                      'host threads (probe over %s)' % (bb, nt, avail, cands),
+            'per_batch': {str(k): round(v, 1) for k, v in per_b.items()}}
 
 
 def main():
     a = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    in_group = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    if a.gpus > 1 and not in_group:
+        sys.exit(launch_ranks(a))
+    world = int(os.environ.get('WORLD_SIZE', '1')) if in_group else 1
+    if world != a.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d; start it as `python bench.py --gpus N` or with '
+                         'torch.distributed.run --nproc-per-node N\n' % (a.gpus, world))
+        sys.exit(2)
+    rank = int(os.environ.get('RANK', '0')) if in_group else 0
+    local = int(os.environ.get('LOCAL_RANK', '0')) if in_group else 0
+
+    import numpy as np
+    import torch
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (there is no CPU path)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -159,56 +231,100 @@ def main():
     J, B = a.joints, a.batch
     model, base, alpha = build_model(J, a.impl, dev)
     model.precision = a.precision
-    runner = ShardedForward(model, world, rank, dist)
+    runner = ShardedForward(model, world, rank, dist, mode=a.mode)
     x = torch.from_numpy(synthetic.synthetic_pose2d(B, J, seed=1000 + rank)).to(dev)     # this rank's shard, resident in HBM
+    target = None
+    if a.mode == 'eval':      # config 5: synthetic ground-truth joints for the on-device MPJPE / PA-MPJPE sums
+        target = torch.from_numpy(np.random.RandomState(7 + rank).randn(B, 17, 3).astype(np.float32) * 200).to(dev)
+        runner.set_eval(synthetic.load_j_regressors()['h36m'], target)
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def block(fn, n):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
     for _ in range(a.warmup):
         out = runner.step(x)
     sync()
     model.profile(4)          # HIP-event brackets on every 4th timed step (the brackets themselves cost ~3 % of a step)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = runner.step(x)
-    sync()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(max(1, a.blocks)):
+        dt, out = block(lambda: runner.step(x), a.steps)
+        dts.append(dt)
     prof = model.profile_read()
     model.profile(0)
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert out[0].shape == (B * world, 6890, 3)
+    dt = float(np.median(dts))
+    if a.mode == 'gather':
+        assert out[0].shape == (B * world, 6890, 3)
+    comm = None
+    if world > 1:            # outside the timed region: what the collective costs alone, and how much of it the overlap hides
+        dt_c, _ = block(lambda: model(x), a.steps)
+        dt_g, _ = block(lambda: runner.comm_only(), a.steps)
+        c_ms, g_ms, t_ms = dt_c / a.steps * 1e3, dt_g / a.steps * 1e3, dt / a.steps * 1e3
+        hidden = max(0.0, c_ms + g_ms - t_ms)
+        comm = {'compute_ms': round(c_ms, 4), 'collective_ms': round(g_ms, 4), 'step_ms': round(t_ms, 4),
+                'overlap_frac': round(min(1.0, hidden / max(min(c_ms, g_ms), 1e-9)), 3),
+                'collective': 'all_gather [%d,6890,3]+[%d,%d,3] f32' % (B * world, B * world, J) if a.mode == 'gather'
+                else 'all_reduce of 4 error sums',
+                'bytes_per_rank': int(B * (6890 * 3 + J * 3) * 4) if a.mode == 'gather' else 32}
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = B * world * a.steps / dt
+        per_gpu_tf = FLOPS_PER_MESH.get(J, 4.10e8) * value / world / 1e12
         roof = None
         if prof:
             name, (tot_ms, calls) = max(prof.items(), key=lambda kv: kv[1][0])
             avg_s = tot_ms / calls * 1e-3
-            mflop = STAGE_MFLOP.get(name.split(':')[0], None)
+            stage = name.split(':')[0]
+            mflop = STAGE_MFLOP.get(stage, None)
             if mflop is not None and avg_s > 0:
                 ach = mflop * 1e6 * B / avg_s / 1e12
-                traffic = pmc_traffic(name, B)
-                pipe, peak = stage_pipe(name.split(':')[0], a.impl)
+                traffic = pmc_traffic(stage, B)
+                pipe, peak = stage_pipe(stage, a.impl)
+                alg = STAGE_BYTES.get(stage)
                 roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                        'frac': round(ach / peak, 4), 'traffic': traffic, 'avg_launch_ms': round(avg_s * 1e3, 4), 'pipe': pipe,
+                        'frac': round(ach / peak, 4), 'traffic': traffic,
+                        'algorithmic_bytes': int(alg * B) if alg else None,
+                        'traffic_ratio': round(traffic / (alg * B), 3) if (traffic and alg) else None,
+                        'avg_launch_ms': round(avg_s * 1e3, 4), 'pipe': pipe,
                         'stages_ms': {k: round(v[0] / v[1], 4) for k, v in prof.items()}}
         if roof is None:   # no per-kernel events available (bring-up path): price the whole forward
-            ach = FLOPS_PER_MESH[J] * value / world / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'whole forward', 'achieved': round(ach, 2), 'peak': PEAK_F32_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_TFLOPS, 4), 'traffic': None}
-        line = {'metric': 'meshes/sec (B=256, J=17) GATOR forward', 'value': round(value, 1), 'unit': 'meshes/sec',
+            roof = {'bound': 'mfma', 'kernel': 'whole forward', 'achieved': round(per_gpu_tf, 2), 'peak': PEAK_F32_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(per_gpu_tf / PEAK_F32_TFLOPS, 4), 'traffic': None}
+        jset = {17: 'Human3.6M 17-joint', 19: 'COCO 19-joint'}.get(J, '%d-joint' % J)
+        prec = 'fp32' if a.precision == 'f32' else 'fp32 encoder/head + bf16-MFMA vertex regressor'
+        tail = ''
+        if world > 1:
+            tail = (', RCCL all-gather of [%d,6890,3] vertices' % (B * world)) if a.mode == 'gather' else \
+                ', on-device joint regression + MPJPE/PA-MPJPE sums, RCCL all-reduce only'
+        line = {'metric': 'meshes/sec (B=%d, J=%d) GATOR forward' % (B, J), 'value': round(value, 1), 'unit': 'meshes/sec',
                 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic',
-                'config': {'workload': 'B=%d synthetic Human3.6M %d-joint poses per GPU, GAT+MDR forward fp32%s'
-                           % (B, J, ', RCCL all-gather of [%d,6890,3] vertices' % (B * world) if world > 1 else ''),
-                           'batch_per_gpu': B, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world},
+                'config': {'workload': 'B=%d synthetic %s poses per GPU, GAT+MDR forward %s%s' % (B, jset, prec, tail),
+                           'batch_per_gpu': B, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world, 'mode': a.mode},
+                'timing': {'blocks': len(dts), 'reported': 'median block',
+                           'block_ms': [round(d * 1e3, 3) for d in dts],
+                           'min_ms_per_step': round(min(dts) / a.steps * 1e3, 4), 'max_ms_per_step': round(max(dts) / a.steps * 1e3, 4)},
+                'whole_forward': {'flop_per_mesh': FLOPS_PER_MESH.get(J), 'achieved_tflops_per_gpu': round(per_gpu_tf, 2),
+                                  'frac_of_fp32_peak_157.3': round(per_gpu_tf / PEAK_F32_TFLOPS, 4),
+                                  'frac_of_split_precision_peak_416.7': round(per_gpu_tf / PEAK_X3_TFLOPS, 4),
+                                  'compulsory_bytes_per_mesh': BYTES_PER_MESH.get(J)},
                 'roofline': roof}
+        if comm is not None:
+            line['comm'] = comm
         if world == 1 and B >= 128 and a.subbatch_variant:
             # same workload with the library's sub-batch pipelining (two half-batches on two streams; bit-identical results).
             # Reported beside the headline, not as it: concurrent streams make per-kernel durations (and so `roofline`) ambiguous.
@@ -217,15 +333,10 @@ def main():
             m2.subbatch_streams = 2
             for _ in range(a.warmup):
                 m2(x)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(a.steps):
-                m2(x)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
-            line['subbatch_streams_2'] = {'value': round(B * a.steps / dt2, 1), 'ms_per_step': round(dt2 / a.steps * 1e3, 4)}
+            d2 = sorted(block(lambda: m2(x), a.steps)[0] for _ in range(5))[2]
+            line['subbatch_streams_2'] = {'value': round(B * a.steps / d2, 1), 'ms_per_step': round(d2 / a.steps * 1e3, 4)}
         if world == 1 and not a.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(model, base, alpha, J, a.cpu_seconds)
+            line['cpu_baseline'] = cpu_baseline(model, base, alpha, J)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,90 +1,186 @@
 """Multi-GPU execution of the path: samples are independent, so the batch is sharded contiguously across
-ranks (one process per GPU, weights replicated) and the ONLY collective is an all-gather of the predicted vertices
-[B/N, 6890, 3] (+ pose3d [B/N, J, 3]) over xGMI -- RCCL via torch.distributed's "nccl" backend.  The reference has no
-multi-GPU counterpart (no torch.distributed anywhere); correctness criterion: the gathered tensor equals the
-single-GPU output of the concatenated batch bit for bit (same kernels, per-sample arithmetic independent of B).
+ranks (one process per GPU, weights replicated) and the ONLY collective is
 
-Overlap: the gather runs on a side stream and the compute stream never waits for it, so step k's gather (xGMI is
-point-to-point, 7 links x ~153 GB/s per GPU: a ring all-gather of 21 MB/rank per 256 samples costs ~1 ms at 8 GPUs, the same
-order as the 1.5 ms of compute) hides behind step k+1's kernels.  Outputs are double-buffered; `step()` returns the buffers
-of THIS step together with an event the consumer must wait on (`wait()` does it for the current stream)."""
+  mode='gather' (BASELINE config 4): an all-gather of the predicted vertices [B/N, 6890, 3] (+ pose3d [B/N, J, 3]) over
+                xGMI -- RCCL via torch.distributed's "nccl" backend;
+  mode='eval'   (BASELINE config 5): joints are regressed and the MPJPE / PA-MPJPE sums formed on the device
+                (gator_amd.eval), and only those few scalars are all-reduced -- no rank ever holds another rank's meshes and no
+                mesh goes to the host (lib/core/base.py:219-237 copies every mesh to the host twice).
+
+The reference has no multi-GPU counterpart (no torch.distributed anywhere); correctness criterion: the
+gathered tensor equals the single-GPU output of the concatenated batch bit for bit (same kernels, per-sample arithmetic
+independent of B), resp. the reduced sums equal the single-process sums.
+
+One code path for every backend.  The chunk plan, the output-buffer rotation and the gather itself are the same Python for a
+HIP device ("nccl") and for host tensors ("gloo", the CPU tests); the only difference is that on a device the collective is
+issued on a side stream.
+
+Overlap and buffer ownership.  The collective of step k runs on the side stream and the compute stream does not wait for
+it, so it hides behind step k+1's kernels (xGMI is point-to-point, 7 links x ~153 GB/s per GPU: a ring all-gather of
+21 MB/rank per 256 samples costs ~1 ms at 8 GPUs, the same order as the compute).  Outputs rotate through `depth` buffers
+(default 2).  Ordering is by streams, never by host waits:
+  * `step()` returns the buffers of THIS step and sets `last_event`; the consumer calls `wait()` (current stream waits
+    for the gather) before reading them;
+  * the buffers returned by step k are overwritten by the gather of step k+depth, which the side stream starts only after
+    everything the CALLING stream had queued when step k+depth was called (wait_stream), i.e. after every read the consumer
+    queued on that stream in between.  A consumer on another stream must synchronise with the calling stream itself."""
+import contextlib
+
 import torch
 
 
 class ShardedForward:
-    def __init__(self, model, world_size=1, rank=0, dist=None, micro_batch=None, always_gather=False):
+    def __init__(self, model, world_size=1, rank=0, dist=None, micro_batch=None, always_gather=False, mode='gather', depth=2,
+                 metrics_fn=None):
+        if mode not in ('gather', 'eval'):
+            raise ValueError("mode must be 'gather' or 'eval'")
         self.model, self.world, self.rank, self.dist = model, world_size, rank, dist
         self.micro = micro_batch
         self.always_gather = always_gather      # run the collective even for one rank (exercises RCCL on a 1-GPU box)
+        self.mode = mode
+        self.depth = max(1, int(depth))
+        self.metrics_fn = metrics_fn            # eval mode: (verts, pose3d, target, sample slice) -> 1-D tensor of partial sums
         self._bufs = {}
+        self._stage = {}
         self._comm_stream = None
         self._flip = 0
+        self._target = None
+        self._regressor = None
+        self._regressor_dense = None
+        self._eval_joints = None
+        self._last = None                       # (kind, tensors) of the last collective, for comm_only()
         self.last_event = None
 
+    # ---- shared plan: chunks of the local batch, rotating output buffers ------------------------------------------------
+    def _plan(self, B):
+        mb = self.micro or B
+        return [(s, min(B, s + mb)) for s in range(0, B, mb)]
+
     def _buffers(self, B, J, device):
-        self._flip ^= 1
+        self._flip = (self._flip + 1) % self.depth
         key = (B, J, str(device), self._flip)
         if key not in self._bufs:
             self._bufs[key] = (torch.empty((self.world * B, 6890, 3), device=device, dtype=torch.float32),
                                torch.empty((self.world * B, J, 3), device=device, dtype=torch.float32))
         return self._bufs[key]
 
+    def _staging(self, n, J, device):
+        key = (n, J, str(device))
+        if key not in self._stage:
+            self._stage[key] = (torch.empty((self.world, n, 6890, 3), device=device, dtype=torch.float32),
+                                torch.empty((self.world, n, J, 3), device=device, dtype=torch.float32))
+        return self._stage[key]
+
+    def _side(self, device):
+        """Context in which collectives are issued: the side stream on a HIP device, nothing on the host."""
+        if device.type != 'cuda':
+            return contextlib.nullcontext(), None
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=device)
+        cur = torch.cuda.current_stream(device)
+        self._comm_stream.wait_stream(cur)      # after the producing kernels AND after every queued read of the buffer we reuse
+        return torch.cuda.stream(self._comm_stream), self._comm_stream
+
+    def _gather_chunk(self, verts, pose3d, s, e, B, gv, gp):
+        """All ranks' rows [s,e) of their local batches -> rows r*B+s .. r*B+e of the replicated outputs."""
+        dev, J = verts.device, pose3d.shape[1]
+        ctx, side = self._side(dev)
+        with ctx:
+            if s == 0 and e == B:               # whole local batch: rank-major concatenation IS the output layout
+                self.dist.all_gather_into_tensor(gv, verts)
+                self.dist.all_gather_into_tensor(gp, pose3d)
+            else:                               # micro-batch: one gather into a [world, n, ...] staging tile, one strided copy
+                sv, sp = self._staging(e - s, J, dev)
+                self.dist.all_gather_into_tensor(sv.view(-1, 6890, 3), verts)
+                self.dist.all_gather_into_tensor(sp.view(-1, J, 3), pose3d)
+                gv.view(self.world, B, 6890, 3)[:, s:e].copy_(sv)
+                gp.view(self.world, B, J, 3)[:, s:e].copy_(sp)
+        if side is not None:
+            verts.record_stream(side)
+            pose3d.record_stream(side)
+        return side
+
     def wait(self):
-        """Make the current stream wait for the gather of the last step (call before consuming its outputs)."""
+        """Make the current stream wait for the collective of the last step (call before consuming its outputs)."""
         if self.last_event is not None:
             torch.cuda.current_stream().wait_event(self.last_event)
 
+    # ---- mode 'gather' ---------------------------------------------------------------------------------------------------
     def step(self, pose2d_shard):
-        """pose2d_shard [B_local, J, 2] on this rank's GPU -> (verts [world*B_local,6890,3], pose3d [world*B_local,J,3])
-        replicated on every rank (rank r's samples at rows r*B_local ...)."""
+        """pose2d_shard [B_local, J, 2] on this rank's GPU.
+        gather: -> (verts [world*B_local,6890,3], pose3d [world*B_local,J,3]) replicated on every rank (rank r's samples at
+                rows r*B_local ...);
+        eval:   -> 1-D tensor of the globally reduced error sums (see set_eval)."""
+        if self.mode == 'eval':
+            return self._step_eval(pose2d_shard)
         if self.dist is None or (self.world == 1 and not self.always_gather):
             return self.model(pose2d_shard)
         B, J = pose2d_shard.shape[0], pose2d_shard.shape[1]
-        dev = pose2d_shard.device
-        gv, gp = self._buffers(B, J, dev)
-        mb = self.micro or B
-        if dev.type != 'cuda':            # host tensors (gloo): same sharding / gather logic, no streams
-            return self._step_host(pose2d_shard, gv, gp, mb)
-        if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=dev)
-        cur = torch.cuda.current_stream(dev)
-        # all_gather_into_tensor concatenates rank-major; to keep rank r's rows contiguous with micro-batching, each
-        # micro-batch gathers into a [world, mb, ...] staging view that aliases the right rows of the output.
-        gv_v = gv.view(self.world, B, 6890, 3)
-        gp_v = gp.view(self.world, B, J, 3)
-        for s in range(0, B, mb):
-            e = min(B, s + mb)
+        gv, gp = self._buffers(B, J, pose2d_shard.device)
+        side, chunks = None, []
+        for s, e in self._plan(B):
             verts, pose3d = self.model(pose2d_shard[s:e])
-            if mb == B:
-                self._comm_stream.wait_stream(cur)
-                with torch.cuda.stream(self._comm_stream):
-                    self.dist.all_gather_into_tensor(gv, verts)
-                    self.dist.all_gather_into_tensor(gp, pose3d)
-                verts.record_stream(self._comm_stream)
-                pose3d.record_stream(self._comm_stream)
-            else:
-                self._comm_stream.wait_stream(cur)
-                with torch.cuda.stream(self._comm_stream):
-                    outs_v = [gv_v[r, s:e] for r in range(self.world)]
-                    outs_p = [gp_v[r, s:e] for r in range(self.world)]
-                    self.dist.all_gather(outs_v, verts)
-                    self.dist.all_gather(outs_p, pose3d)
-                verts.record_stream(self._comm_stream)
-                pose3d.record_stream(self._comm_stream)
-        self.last_event = self._comm_stream.record_event()     # the compute stream does NOT wait: next step overlaps the gather
+            verts, pose3d = verts.contiguous(), pose3d.contiguous()
+            side = self._gather_chunk(verts, pose3d, s, e, B, gv, gp)
+            chunks.append((verts, pose3d, s, e))
+        self._last = ('gather', (chunks, B, gv, gp))
+        # the compute stream does NOT wait: the next step overlaps this gather
+        self.last_event = side.record_event() if side is not None else None
         return gv, gp
 
-    def _step_host(self, x, gv, gp, mb):
-        B, J = x.shape[0], x.shape[1]
-        gv_v, gp_v = gv.view(self.world, B, 6890, 3), gp.view(self.world, B, J, 3)
-        for s in range(0, B, mb):
-            e = min(B, s + mb)
-            verts, pose3d = self.model(x[s:e])
-            ov = [torch.empty_like(verts) for _ in range(self.world)]
-            op = [torch.empty_like(pose3d) for _ in range(self.world)]
-            self.dist.all_gather(ov, verts.contiguous())
-            self.dist.all_gather(op, pose3d.contiguous())
-            for r in range(self.world):
-                gv_v[r, s:e] = ov[r]
-                gp_v[r, s:e] = op[r]
-        return gv, gp
+    # ---- mode 'eval' -----------------------------------------------------------------------------------------------------
+    def set_eval(self, j_regressor, target_joints, eval_joints=None):
+        """j_regressor: dense [n_joint, 6890] (J_regressor_h36m, lib/core/base.py:221); target_joints: this rank's ground-truth
+        joints [B_local, n_joint, 3] in mm on the same device as the inputs."""
+        self._target = target_joints
+        self._eval_joints = eval_joints
+        self._regressor_dense = j_regressor
+        self._regressor = None
+
+    def _device_metrics(self, verts, pose3d, target, sl):
+        """[sum MPJPE, sum PA-MPJPE, samples] of the samples `sl` of the local batch, on the device (gator_amd.eval)."""
+        from . import eval as ev
+        if self._regressor is None:
+            self._regressor = ev.JointRegressor(self._regressor_dense, verts.device)
+        joints = self._regressor(verts) * 1000.0                        # metres -> mm (lib/core/base.py:219)
+        tgt = target[sl]
+        kw = {} if self._eval_joints is None else {'eval_joints': self._eval_joints}
+        n = joints.shape[0]
+        return torch.stack([ev.mpjpe(joints, tgt, **kw) * n, ev.pa_mpjpe(joints, tgt, **kw) * n,
+                            torch.tensor(float(n), device=verts.device)]).double()
+
+    def _step_eval(self, pose2d_shard):
+        fn = self.metrics_fn or self._device_metrics
+        B = pose2d_shard.shape[0]
+        acc = None
+        for s, e in self._plan(B):
+            verts, pose3d = self.model(pose2d_shard[s:e])
+            part = fn(verts, pose3d, self._target, slice(s, e))
+            acc = part if acc is None else acc + part
+        if self.dist is not None and (self.world > 1 or self.always_gather):
+            ctx, side = self._side(acc.device)
+            with ctx:
+                self.dist.all_reduce(acc)
+            if side is not None:
+                acc.record_stream(side)
+                self.last_event = side.record_event()
+            self._last = ('reduce', (acc,))
+        return acc
+
+    # ---- measurement helper ---------------------------------------------------------------------------------------------
+    def comm_only(self):
+        """Re-issue the last step's collective alone (bench.py: what the collective costs without compute to hide behind)."""
+        if self._last is None:
+            return None
+        kind, t = self._last
+        if kind == 'gather':
+            chunks, B, gv, gp = t
+            for verts, pose3d, s, e in chunks:
+                side = self._gather_chunk(verts, pose3d, s, e, B, gv, gp)
+        else:
+            ctx, side = self._side(t[0].device)
+            with ctx:
+                self.dist.all_reduce(t[0])
+        if side is not None:
+            self.last_event = side.record_event()
+        return None

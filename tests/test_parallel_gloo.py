@@ -1,6 +1,8 @@
-"""N>1 path on CPU: world_size-2 gloo run of the batch-sharding + vertex all-gather logic (gator_amd/parallel.py) with a
-deterministic stand-in for the per-rank forward.  Criterion: gathered == single-process output of the
-concatenated batch, bit for bit, with and without micro-batching."""
+"""N>1 path on CPU: world_size-2 gloo run of gator_amd.parallel.ShardedForward -- the SAME chunk plan, buffer rotation and
+collective calls the device path runs (only the side stream is absent on the host) -- with a deterministic stand-in for the
+per-rank forward.  Criterion: gathered == single-process output of the concatenated batch, bit for bit, with and
+without micro-batching (incl. a ragged last chunk), over several steps of the rotating output buffers; eval mode: the
+all-reduced error sums == the single-process sums."""
 import os
 import socket
 
@@ -16,6 +18,12 @@ def _fake_forward(x):                       # per-sample, batch-independent: lik
     return verts, x.repeat(1, 1, 2)[:, :, :3].contiguous()
 
 
+def _fake_metrics(verts, pose3d, target, sl):      # per-sample partial sums, like gator_amd.eval on the device
+    t = target[sl]
+    return torch.stack([(verts[:, :17].double() - t.double()).abs().sum(), pose3d.double().sum(),
+                        torch.tensor(float(verts.shape[0]), dtype=torch.float64)])
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -24,40 +32,66 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, micro, q):
+def _worker(rank, world, port, micro, mode, q):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from gator_amd.parallel import ShardedForward
-    torch.manual_seed(0)
-    full = torch.randn(world * 6, 17, 2)
-    shard = full[rank * 6:(rank + 1) * 6]
-    gv, gp = ShardedForward(_fake_forward, world, rank, dist, micro_batch=micro).step(shard)
-    rv, rp = _fake_forward(full)
-    q.put((rank, bool(torch.equal(gv, rv)), bool(torch.equal(gp, rp))))
+    n = 6
+    ok = True
+    if mode == 'gather':
+        run = ShardedForward(_fake_forward, world, rank, dist, micro_batch=micro)
+        kept = []
+        for step in range(3):                # three steps: the two output buffers rotate; step k's result survives step k+1
+            torch.manual_seed(step)
+            full = torch.randn(world * n, 17, 2)
+            gv, gp = run.step(full[rank * n:(rank + 1) * n])
+            rv, rp = _fake_forward(full)
+            ok = ok and bool(torch.equal(gv, rv)) and bool(torch.equal(gp, rp))
+            if kept:
+                ok = ok and bool(torch.equal(kept[-1][0], kept[-1][1]))       # previous step's buffer not overwritten yet
+                ok = ok and kept[-1][0].data_ptr() != gv.data_ptr()
+            kept.append((gv, rv))
+        run.comm_only()
+        ok = ok and bool(torch.equal(gv, rv))
+    else:
+        torch.manual_seed(0)
+        full = torch.randn(world * n, 17, 2)
+        tgt = torch.randn(world * n, 17, 3)
+        run = ShardedForward(_fake_forward, world, rank, dist, micro_batch=micro, mode='eval', metrics_fn=_fake_metrics)
+        run.set_eval(None, tgt[rank * n:(rank + 1) * n])
+        got = run.step(full[rank * n:(rank + 1) * n])
+        v, p = _fake_forward(full)
+        want = _fake_metrics(v, p, tgt, slice(0, world * n))
+        ok = bool(torch.allclose(got, want, rtol=1e-12, atol=0)) and float(got[2]) == world * n
+    q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(micro):
+def _run(micro, mode='gather'):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, micro, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, micro, mode, q)) for r in range(2)]
     for p in ps:
         p.start()
     res = [q.get(timeout=120) for _ in ps]
     for p in ps:
         p.join(60)
     assert sorted(r[0] for r in res) == [0, 1]
-    assert all(r[1] and r[2] for r in res), res
+    assert all(r[1] for r in res), res
 
 
 def test_allgather_full_batch():
     _run(None)
 
 
-def test_allgather_microbatched():
-    _run(4)
+def test_allgather_microbatched_ragged():
+    _run(4)                                  # 6 samples per rank in chunks of 4 + 2
+
+
+def test_eval_mode_allreduce_only():
+    _run(4, 'eval')
 
 
 def test_single_rank_passthrough():
