@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libgator_hip.so')
+# GATOR_AMD_LIB selects another build of the same ABI (the diagnostic library of `python -m gator_amd.build --diag`)
+LIB_PATH = os.environ.get('GATOR_AMD_LIB') or os.path.join(_HERE, 'lib', 'libgator_hip.so')
 
 GATOR_F32, GATOR_I64, GATOR_I32 = 0, 1, 2
 IMPL_FUSED, IMPL_BASIC = 0, 1
@@ -33,6 +34,7 @@ SIGNATURES = {
     'gator_mdr_forward_f32': (_I, [_P, _P, _I, _P, _P]),
     'gator_upsample_f32': (_I, [_P, _P, _I, _P, _P]),
     'gator_get_tap': (_I, [_P, ctypes.c_char_p, _P, _L, ctypes.POINTER(_L), _P]),
+    'gator_enable_block_taps': (_I, [_P, _I]),
     'gator_profile_enable': (_I, [_P, _I]),
     'gator_profile_read': (_I, [_P, ctypes.c_char_p, _L, _P, _P, _I, _P]),
     'gator_regress_joints_f32': (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P]),

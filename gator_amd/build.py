@@ -27,10 +27,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+DIAG_LIB = os.path.join(HERE, 'lib', 'libgator_hip_diag.so')
+
+
+def build(force=False, verbose=True, diag=False):
+    """Production library: no diagnostics compiled in, and a hot kernel that spills registers is a build error
+    (gator_amd/kernel_resources.py).  diag=True builds libgator_hip_diag.so instead (-DGATOR_DIAG: in-kernel cycle stamps read
+    through GATOR_GAT_STAMPS / GATOR_MDR_STAMPS; select it with GATOR_AMD_LIB=<path>, see tools/gat_stamps.py)."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     os.makedirs(os.path.join(HERE, 'lib'), exist_ok=True)
-    objdir = os.path.join(HERE, 'lib', 'obj')
+    objdir = os.path.join(HERE, 'lib', 'obj_diag' if diag else 'obj')
+    lib = DIAG_LIB if diag else LIB
     os.makedirs(objdir, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     hdrs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.hpp', '.cuh'))]
@@ -40,21 +47,40 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, s.rsplit('.', 1)[0] + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + (NO_PK if s in NO_PK_SOURCES else []) + (['-x', 'hip'] if s.endswith('.hip') else []) + ['-c', src, '-o', obj]
+            is_hip = s.endswith('.hip')
+            cmd = [hipcc] + FLAGS + (['-DGATOR_DIAG=1'] if diag else []) + (NO_PK if s in NO_PK_SOURCES else []) + \
+                (['-x', 'hip', '-Rpass-analysis=kernel-resource-usage'] if is_hip else []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
-        if p.wait() != 0:
+            procs.append((s, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+    from . import kernel_resources as kr
+    remarks = {}
+    for s, obj, p in procs:
+        err = p.communicate()[1]
+        if p.returncode != 0:
+            sys.stderr.write(err)
             raise RuntimeError('hipcc failed on %s' % s)
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs
+        noise = ('remark:', '-Rpass-analysis')
+        rest = [ln for ln in err.splitlines() if ln.strip() and not any(n in ln for n in noise)]
+        rest = [ln for ln in rest if not (ln.lstrip().startswith('|') or ln.lstrip()[:1].isdigit() and ' | ' in ln)]
+        if rest and verbose:
+            sys.stderr.write('\n'.join(rest) + '\n')
+        remarks[s] = (obj, kr.parse(err))
+    if not diag:
+        try:
+            kr.check({s: r for s, (_, r) in remarks.items()})
+        except RuntimeError:
+            for s, (obj, _) in remarks.items():      # do not leave objects of a rejected build behind
+                if os.path.exists(obj):
+                    os.remove(obj)
+            raise
+    if force or procs or _stale(lib, objs):
+        cmd = [hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', lib] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
-    print(LIB)
+    print(build(force='--force' in sys.argv, diag='--diag' in sys.argv))

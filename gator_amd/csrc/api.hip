@@ -258,7 +258,7 @@ extern "C" int gator_create(const gator_tensor* tensors, int32_t n, const gator_
     }
     int rc = resolve_weights(c);
     if (rc == GATOR_OK && (c->parts & GATOR_PART_GAT)) rc = basic_fold_constants(c, nullptr);
-    if (rc == GATOR_OK && cfg->max_batch > 0) rc = ensure_workspace(c, cfg->max_batch);
+    if (rc == GATOR_OK && cfg->max_batch > 0 && c->impl == GATOR_IMPL_BASIC) rc = ensure_workspace(c, cfg->max_batch);
     if (rc == GATOR_OK) rc = fused_create(c, nullptr);
     if (rc != GATOR_OK) { gator_destroy(c); return rc; }
     *out = c;
@@ -269,7 +269,8 @@ static int check_fwd(gator_ctx* c, const void* a, const void* b, int B, const ch
     if (!c || !a || !b || B <= 0) return fail(GATOR_EINVAL, "%s: null pointer or batch <= 0", fn);
     c->profiling = c->prof_stride > 0 && (c->prof_calls++ % c->prof_stride) == 0;
     GATOR_HIP_CHECK(hipSetDevice(c->device));
-    return ensure_workspace(c, B);
+    c->clear_taps();        // a tap never outlives the forward that produced it (workspaces may be re-allocated below)
+    return c->impl == GATOR_IMPL_BASIC ? ensure_workspace(c, B) : GATOR_OK;     // the fused entry points size their own workspace
 }
 
 extern "C" int gator_gat_forward_f32(gator_ctx* c, const float* pose2d, int32_t B, float* x_out, float* feat, void* stream) {
@@ -278,9 +279,9 @@ extern "C" int gator_gat_forward_f32(gator_ctx* c, const float* pose2d, int32_t 
     if (!feat) return fail(GATOR_EINVAL, "gator_gat_forward_f32: feat is null");
     if (!(c->parts & GATOR_PART_GAT)) return fail(GATOR_EUNSUPPORTED, "gator_gat_forward_f32: ctx was created without the GAT weights");
     c->last_batch = B;
-    c->taps.clear();
+    c->clear_taps();
     rc = c->impl == GATOR_IMPL_BASIC ? basic_gat_forward(c, pose2d, B, x_out, feat, stream) : fused_gat_forward(c, pose2d, B, x_out, feat, stream);
-    if (rc == GATOR_OK) c->taps["feat"] = {feat, (int64_t)B * c->J * kC};
+    if (rc == GATOR_OK) c->set_tap(TAP_FEAT, feat, (int64_t)B * c->J * kC);
     return rc;
 }
 
@@ -305,13 +306,13 @@ extern "C" int gator_forward_f32(gator_ctx* c, const float* pose2d, int32_t B, f
     if (!pose3d) return fail(GATOR_EINVAL, "gator_forward_f32: pose3d is null");
     if (c->parts != (GATOR_PART_GAT | GATOR_PART_MDR)) return fail(GATOR_EUNSUPPORTED, "gator_forward_f32: ctx needs both GAT and MDR weights");
     c->last_batch = B;
-    c->taps.clear();
+    c->clear_taps();
     if (c->impl != GATOR_IMPL_BASIC) return fused_forward(c, pose2d, B, verts, pose3d, stream);
     const BasicLayout L = basic_layout(c->J, c->cap_batch);
     float *feat = c->ws + L.feat, *xout = c->ws + L.xout, *pc = c->ws + L.pc;
     { StageTimer t(c, "gat", stream); rc = basic_gat_forward(c, pose2d, B, xout, feat, stream); }
     if (rc) return rc;
-    c->taps["feat"] = {feat, (int64_t)B * c->J * kC};
+    c->set_tap(TAP_FEAT, feat, (int64_t)B * c->J * kC);
     rc = basic_build_pc(c, pose2d, xout, feat, B, pc, pose3d, stream);
     if (rc) return rc;
     StageTimer t(c, "mdr+upsample", stream);
@@ -379,7 +380,7 @@ extern "C" int gator_forward_bf16(gator_ctx* c, const float* pose2d, int32_t B, 
     if (c->parts != (GATOR_PART_GAT | GATOR_PART_MDR) || c->impl != GATOR_IMPL_FUSED)
         return fail(GATOR_EUNSUPPORTED, "gator_forward_bf16: needs a fused ctx with both GAT and MDR weights");
     c->last_batch = B;
-    c->taps.clear();
+    c->clear_taps();
     return fused_forward(c, pose2d, B, verts, pose3d, stream, true);
 }
 
@@ -391,16 +392,29 @@ extern "C" int gator_upsample_bf16(gator_ctx* c, const float* vert431, int32_t B
     return fused_upsample_bf16(c, vert431, B, verts, stream);
 }
 
+extern "C" int gator_enable_block_taps(gator_ctx* c, int32_t on) {
+    if (!c) return fail(GATOR_EINVAL, "gator_enable_block_taps: null ctx");
+    if (c->impl != GATOR_IMPL_FUSED) return fail(GATOR_EUNSUPPORTED, "gator_enable_block_taps: fused ctx only");
+    c->block_taps = on != 0;
+    return GATOR_OK;
+}
+
 extern "C" int gator_get_tap(gator_ctx* c, const char* name, float* dst, int64_t capacity, int64_t* count, void* stream) {
     if (!c || !name || !dst) return fail(GATOR_EINVAL, "gator_get_tap: null argument");
     const float* src = nullptr;
     int64_t n = 0;
     if (!strcmp(name, "hop_path_bias")) { src = c->hop_bias; n = (int64_t)kH * c->J * c->J; }
     else {
-        auto it = c->taps.find(name);
-        if (it == c->taps.end()) return fail(GATOR_EMISSING, "gator_get_tap: no tap named '%s' from the last forward", name);
-        src = it->second.first;
-        n = it->second.second;
+        static const struct { const char* name; int id; } kNames[] = {{"feat", TAP_FEAT}, {"mdr_lbf2", TAP_MDR_LBF2}, {"vert431", TAP_VERT431}};
+        int blk = -1;
+        if (!strncmp(name, "gat_block", 9) && name[9] >= '0' && name[9] < '0' + kDepth && !name[10]) blk = name[9] - '0';
+        for (auto& k : kNames)
+            if (!strcmp(name, k.name)) { src = c->taps[k.id].p; n = c->taps[k.id].n; }
+        if (blk >= 0 && c->taps[TAP_GAT_BLOCKS].p) {     // [depth][B][J][128]
+            n = c->taps[TAP_GAT_BLOCKS].n / kDepth;
+            src = c->taps[TAP_GAT_BLOCKS].p + (int64_t)blk * n;
+        }
+        if (!src) return fail(GATOR_EMISSING, "gator_get_tap: no tap named '%s' from the last forward", name);
     }
     if (count) *count = n;
     if (n > capacity) return fail(GATOR_ESHAPE, "gator_get_tap: '%s' needs %lld floats, capacity %lld", name, (long long)n, (long long)capacity);

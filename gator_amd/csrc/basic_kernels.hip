@@ -538,7 +538,7 @@ int basic_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* 
         k_self_attn<<<B * 2, 448, kSelfAttnLds, st>>>(qq, kk, vv, xo);
         linear<0>(st, xo, 64, k.sa_w[3], 64, k.sa_b[3], vf, 64, 0, vf, 64, Vt, 64, 64);
     }
-    c->taps["mdr_lbf2"] = {vf, Vt * 64};
+    c->set_tap(TAP_MDR_LBF2, vf, Vt * 64);
     linear<0>(st, vf, 64, w.motion_w, 64, w.motion_b, nullptr, 0, 0, ac, 23, Vt, 23, 64);
     linear<0>(st, vf, 64, w.biasl_w, 64, w.biasl_b, nullptr, 0, 0, bm, 3, Vt, 3, 64);
     k_head_norm<<<nblk(Vt, 256), 256, 0, st>>>(bm, w.bn_w, w.bn_b, w.bn_mean, w.bn_var, c->alpha, bn, Vt);
@@ -546,7 +546,7 @@ int basic_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* 
     linear<0>(st, col, 1293, w.bconv_w, 1293, w.bconv_b, nullptr, 0, 0, bc, 20, (int64_t)B * 3, 20, 1293);
     if (c->alpha) linear<0>(st, vf, 64, w.scale_w, 64, w.scale_b, nullptr, 0, 0, al, 1, Vt, 1, 64);
     k_head_mix<<<nblk(Vt, 256), 256, 0, st>>>(ac, bc, c->alpha ? al : nullptr, vc, Vt);
-    c->taps["vert431"] = {vc, Vt * 3};
+    c->set_tap(TAP_VERT431, vc, Vt * 3);
     GATOR_HIP_CHECK(hipGetLastError());
     return basic_upsample(c, vc, B, verts, stream);
 }

@@ -160,6 +160,10 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
         f->g_posT = upload(pt);
     }
     // (the lifter reads the reference weight [3J][128J] as it is, gat_fused.hip)
+    {
+        int rc = gat_prepare_device();
+        if (rc) return rc;
+    }
     GATOR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;
@@ -314,6 +318,7 @@ void fused_destroy(gator_ctx* c) {
     if (c->fused->gxbuf) (void)hipFree(c->fused->gxbuf);
     if (c->fused->wxbuf) (void)hipFree(c->fused->wxbuf);
     if (c->fused->up_w16) (void)hipFree(c->fused->up_w16);
+    if (c->fused->blk_tap) (void)hipFree(c->fused->blk_tap);
     if (c->fused->up_w3) (void)hipFree(c->fused->up_w3);
     delete c->fused;
     c->fused = nullptr;
@@ -345,6 +350,9 @@ static int ensure_bf16(gator_ctx* c, int B, void* stream) {
         GATOR_HIP_CHECK(hipMalloc(&f->up_w16, upsample_bf16_weight_elems() * 2));
         int rc = pack_upsample_bf16(c->w.up_w, f->up_w16, stream);
         if (rc) return rc;
+        // One-time: the pack must be COMPLETE before any other stream may read up_w16.  In sub-batch mode the second half
+        // runs on a different (non-blocking) stream whose fork event was recorded before this pack was queued.
+        GATOR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     }
     if (B > f->vcp16_cap) {
         if (f->vcp16) { GATOR_HIP_CHECK(hipDeviceSynchronize()); GATOR_HIP_CHECK(hipFree(f->vcp16)); }
@@ -417,7 +425,7 @@ int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float*
     }
     GATOR_HIP_CHECK(hipEventRecord((hipEvent_t)f->ev_join, (hipStream_t)f->aux_stream));
     GATOR_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)f->ev_join, 0));
-    c->taps.clear();           // taps describe a whole batch; not available in sub-batch mode
+    c->clear_taps();          // taps describe a whole batch; not available in sub-batch mode
     return rc;
 }
 
@@ -430,7 +438,7 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
         rc = launch_gat(c, f, pose2d, B, pose3d, f->feat, stream, true);
     }
     if (rc) return rc;
-    c->taps["feat"] = {f->feat, (int64_t)B * c->J * kC};
+    c->set_tap(TAP_FEAT, f->feat, (int64_t)B * c->J * kC);
     rc = launch_mdr(c, f, nullptr, B, stream, pose3d, pose2d);      // pose_combine is never materialised on this path
     if (rc) return rc;
     if (bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);

@@ -51,7 +51,9 @@ struct FusedState : FusedWs {
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
     bool mdr_x3 = true;                 // MDR self-attention on split-precision bf16 MFMA (GATOR_MDR_X3=0: fp32-input MFMA)
     bool x3 = true;                     // split-precision vertex regressor (GATOR_UPSAMPLE_X3=0: fp32-input MFMA kernel)
-    void* up_w16 = nullptr;             // bf16 [tap][ob][28][64][8] (packed lazily on the first bf16 call)
+    void* up_w16 = nullptr;             // bf16 [tap][ob][28][64][8] (packed on the first bf16 call, which waits for the pack)
+    float* blk_tap = nullptr;           // debug: residual stream after every GATBlock [depth][B][J][128] (gator_enable_block_taps)
+    int blk_tap_cap = 0;
     // MDR
     MdrLayerP lay[3];
     const float* head_w = nullptr;      // [1 nb][2 kb] combined motion/bias/scale linear
@@ -75,6 +77,7 @@ inline int nblk32(int n) { return (n + 31) / 32; }
 int launch_pack_vc(const float* vc, int B, float* vcp, void* stream);
 int launch_upsample(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream);
 // gat_fused.hip
+int gat_prepare_device();
 int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue = false);
 // upsample_bf16.hip
 size_t upsample_bf16_weight_elems();

@@ -39,7 +39,10 @@ struct GatArgs {
     float* jkv;
     const float *jf5, *jf_p, *jf_b, *posj_T;       // get_joint_feature: columns 0..4 as [5][64], columns 5..132 packed [2][4], bias
     const float *j_n1w[3], *j_n1b[3], *j_wk_p[3], *j_wv_p[3];
-    unsigned long long* stamps;     // diagnostic only (GATOR_GAT_STAMPS=1): per-phase cycle sums of workgroup 0, wave 0
+    float* blk_tap;                 // gator_enable_block_taps: residual stream after every GATBlock, [depth][B][J][128] (else nullptr)
+#ifdef GATOR_DIAG
+    unsigned long long* stamps;     // diagnostic build only (libgator_hip_diag.so): per-phase cycle sums of workgroup 0, wave 0
+#endif
 };
 
 // Per-block small vectors (LayerNorm weights, biases) are staged in LDS one block ahead: 2048 floats in this order.
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
     float* V = R + 16 * TA;               // per-block vectors (V_TOTAL floats)
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // provably wave-uniform (scalar loads, scalar addressing)
+#ifdef GATOR_DIAG
     unsigned long long st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = a.stamps ? clock64() : 0;
 #define GAT_STAMP(i)                                      \
     __builtin_amdgcn_sched_barrier(0);                    \
@@ -207,6 +211,9 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         st_acc[i] += now_ - st_last;                      \
         st_last = now_;                                   \
     }
+#else
+#define GAT_STAMP(i)
+#endif
 
     // ---------------- embedding: GraphLinear(2->64) . GroupNorm(4,64) . GELU . GraphLinear(64->128) + pos (GAT.py:135-144)
     {
@@ -446,6 +453,16 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             GATOR_PIN();
             xw += (c0 + c1) + (c2 + c3);
             store_block(X + wave * kTile, lane, xw);     // every wave finished reading X (LN2) before the HB barrier
+            if (a.blk_tap && (lane & 31) < J) {          // debug tap (off in timed runs): this wave's channel block of the block output
+                float* dst = a.blk_tap + (((size_t)bi * a.B + b) * J + (lane & 31)) * kC + 32 * wave + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = xw[4 * g + j];
+                    *reinterpret_cast<f32x4*>(dst + 8 * g) = v4;
+                }
+            }
         }
         __syncthreads();
         GAT_STAMP(8)
@@ -604,11 +621,24 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         }
     }
     GAT_STAMP(9)
+#ifdef GATOR_DIAG
     if (a.stamps && b == 0 && t == 0)
         for (int i = 0; i < 20; ++i) a.stamps[i] = st_acc[i];
+#endif
 }
 
 }  // namespace
+
+constexpr size_t kGatLds = (20 * kTile + 2048) * sizeof(float);                   // 88 KB
+constexpr size_t kGatLdsX3 = (4 * kTile + 16 * kTileX3 + 2048) * sizeof(float);   // 120 KB
+
+// Dynamic-LDS opt-in of the kernels, per DEVICE: called from fused_create_gat with the ctx's device current (a function
+// attribute set on one device does not carry to another, and a process may hold contexts on several).
+int gat_prepare_device() {
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGatLds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGatLdsX3));
+    return GATOR_OK;
+}
 
 int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue) {
     GatArgs a;
@@ -636,6 +666,17 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         a.jkv = f->jkv; a.jf5 = f->jfeat5; a.jf_p = f->jfeat128_p; a.jf_b = w.jfeat_b; a.posj_T = f->posj_T;
         for (int i = 0; i < 3; ++i) { a.j_n1w[i] = w.lay[i].n1w; a.j_n1b[i] = w.lay[i].n1b; a.j_wk_p[i] = f->lay[i].wk; a.j_wv_p[i] = f->lay[i].wv; }
     }
+    a.blk_tap = nullptr;
+    if (c->block_taps) {
+        if (B > f->blk_tap_cap) {       // debug buffer, allocated on first use only
+            if (f->blk_tap) { GATOR_HIP_CHECK(hipDeviceSynchronize()); GATOR_HIP_CHECK(hipFree(f->blk_tap)); f->blk_tap = nullptr; }
+            GATOR_HIP_CHECK(hipMalloc(&f->blk_tap, (size_t)kDepth * B * c->J * kC * sizeof(float)));
+            f->blk_tap_cap = B;
+        }
+        a.blk_tap = f->blk_tap;
+        c->set_tap(TAP_GAT_BLOCKS, f->blk_tap, (int64_t)kDepth * B * c->J * kC);
+    }
+#ifdef GATOR_DIAG
     a.stamps = nullptr;
     static const bool want_stamps = getenv("GATOR_GAT_STAMPS") != nullptr;
     unsigned long long* d_st = nullptr;
@@ -643,25 +684,19 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         GATOR_HIP_CHECK(hipMalloc(&d_st, 20 * sizeof(unsigned long long)));
         a.stamps = d_st;
     }
-    constexpr size_t kLds = (20 * kTile + 2048) * sizeof(float);                 // 88 KB
-    constexpr size_t kLdsX3 = (4 * kTile + 16 * kTileX3 + 2048) * sizeof(float);   // 120 KB
-    static bool attr = false;
-    if (!attr) {
-        GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-        GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsX3));
-        attr = true;
-    }
-    if (f->gat_x3) k_gat<true><<<B, 256, kLdsX3, (hipStream_t)stream>>>(a);
-    else k_gat<false><<<B, 256, kLds, (hipStream_t)stream>>>(a);
+#endif
+    if (f->gat_x3) k_gat<true><<<B, 256, kGatLdsX3, (hipStream_t)stream>>>(a);
+    else k_gat<false><<<B, 256, kGatLds, (hipStream_t)stream>>>(a);
     GATOR_HIP_CHECK(hipGetLastError());
-    if (d_st) {     // diagnostic build path: synchronous read-back, never used in timed runs
+#ifdef GATOR_DIAG
+    if (d_st) {     // diagnostic build: synchronous read-back
         unsigned long long hst[20];
         GATOR_HIP_CHECK(hipMemcpy(hst, d_st, sizeof(hst), hipMemcpyDeviceToHost));
         GATOR_HIP_CHECK(hipFree(d_st));
         static const char* nm[10] = {"embed", "ln1+qkv+attn+mgcn", "barrier1", "proj+prefetch+barrier2", "xfeat+barrier3",
                                      "back+barrier4", "ln2+fc1+gelu", "barrier5", "fc2+barrier6", "tail"};
         unsigned long long tot = 0;
-        hst[9] += 0; for (int i = 0; i < 10; ++i) tot += hst[i];
+        for (int i = 0; i < 10; ++i) tot += hst[i];
         tot += hst[18] + hst[19];
         hst[1] += hst[10] + hst[11] + hst[12] + hst[13] + hst[14] + hst[15] + hst[16] + hst[17];
         fprintf(stderr, "[k_gat stamps, wg0 wave0, B=%d] total %llu cycles:", B, tot);
@@ -670,6 +705,7 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         fprintf(stderr, " | tail detail: ln+gelu+feat=%llu lifter=%llu joint tokens=%llu", hst[18], hst[19], hst[9]);
         fprintf(stderr, "\n");
     }
+#endif
     return GATOR_OK;
 }
 

@@ -54,6 +54,10 @@ struct Weights {
     const int32_t* vj;        // [431]
 };
 
+// debug taps (gator_get_tap): slot ids and names
+enum TapId { TAP_FEAT = 0, TAP_MDR_LBF2, TAP_VERT431, TAP_GAT_BLOCKS, TAP_COUNT };
+struct Tap { const float* p = nullptr; int64_t n = 0; };
+
 struct FusedState;   // packed weights + workspace of the fused path (fused_*.hip)
 struct ProfRec { const char* name; void* start; void* stop; };
 
@@ -78,7 +82,11 @@ struct gator_ctx {
     size_t ws_floats = 0;
     int cap_batch = 0;
     int last_batch = 0;
-    std::map<std::string, std::pair<const float*, int64_t>> taps;   // name -> (device ptr, numel) of the last forward
+    // debug taps of the last forward: fixed slots (no allocation / map insertion on the forward path)
+    gator::Tap taps[gator::TAP_COUNT] = {};
+    bool block_taps = false;       // gator_enable_block_taps: k_gat also stores the residual stream after every GATBlock
+    void clear_taps() { for (auto& t : taps) t = gator::Tap{}; }
+    void set_tap(int id, const float* p, int64_t n) { taps[id].p = p; taps[id].n = n; }
     gator::FusedState* fused = nullptr;
     // measurement hook (gator_profile_*): (stage name, start event, stop event) per launch
     bool profiling = false;       // StageTimer records only when set; forwards toggle it from prof_stride

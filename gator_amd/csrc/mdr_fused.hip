@@ -43,7 +43,9 @@ struct MdrArgs {
     const float *head_w, *head_b;
     float *hf, *lbf;
     LayerW prev, cur;        // prev: layer whose attention/out-proj runs first; cur: layer whose tokenwise part runs
-    unsigned long long* stamps;   // diagnostic only (GATOR_MDR_STAMPS=1)
+#ifdef GATOR_DIAG
+    unsigned long long* stamps;   // diagnostic build only (libgator_hip_diag.so, GATOR_MDR_STAMPS=1)
+#endif
 };
 
 // ---- row-wise helpers over the 64 channels (2 blocks) of a token (lane pair l, l^32) -------------------------------
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int id = xcd_remap(blockIdx.x, nwg) * 4 + wave;
     if (id >= a.B * kVT) return;
+#ifdef GATOR_DIAG
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = a.stamps ? clock64() : 0;
     const unsigned long long rt0 = a.stamps ? wall_clock64() : 0, ck0 = st_last;
 #define MDR_STAMP(i)                                      \
@@ -329,6 +332,9 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         st_acc[i] += now_ - st_last;                      \
         st_last = now_;                                   \
     }
+#else
+#define MDR_STAMP(i)
+#endif
     const int b = id / kVT, t = id % kVT;
     const size_t tile = ((size_t)b * kVT + t) * 2;          // index of this wave's first block in vf/q/k/v
     const int token = 32 * t + (lane & 31);
@@ -534,6 +540,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         st_op<X>(a.v_out + (tile + 1) * TQ, lane, y1);
     }
     MDR_STAMP(4)
+#ifdef GATOR_DIAG
     if (a.stamps && id == 0 && lane == 0)
         for (int i = 0; i < 8; ++i) a.stamps[i] = st_acc[i];
     if (a.stamps && (id % 64) == 0 && lane == 0) {      // timeline sample: [start, end] in 100 MHz ticks, cycles, XCC id
@@ -546,6 +553,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         q[3] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
     }
+#endif
 }
 
 // Joint tokens: jf = Linear(133->64)(pose_combine) + pos_j (MDR.py:130-134); per layer k = wk(LN1(jf)), v = wv(LN1(jf))
@@ -741,11 +749,18 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.xout = pc ? nullptr : x_out; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
     a.head_w = f->mdr_x3 ? f->wxbuf + (size_t)(f->head_w - f->lay[0].wq) / kTile * kTileX3 : f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = f->lbf;
     const int nwg = (B * kVT + 3) / 4;
+#ifdef GATOR_DIAG
     static const bool want_stamps = getenv("GATOR_MDR_STAMPS") != nullptr;
+    static const size_t solo = getenv("GATOR_MDR_SOLO") ? 60 * 1024 : 0;      // 1 workgroup per CU (1 wave/SIMD)
     unsigned long long* d_st = nullptr;
     if (want_stamps) { GATOR_HIP_CHECK(hipMalloc(&d_st, 512 * sizeof(unsigned long long))); GATOR_HIP_CHECK(hipMemset(d_st, 0, 512 * sizeof(unsigned long long))); }
+#else
+    constexpr size_t solo = 0;
+#endif
     for (int li = 0; li <= 3; ++li) {
+#ifdef GATOR_DIAG
         a.stamps = (li == 1) ? d_st : nullptr;
+#endif
         float** in = set[(li + 1) & 1];
         float** out = set[li & 1];
         a.layer = li;
@@ -754,7 +769,6 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         if (li > 0) a.prev = make_layer(f, c, li - 1);
         if (li < 3) a.cur = make_layer(f, c, li);
         StageTimer tm(c, li == 0 ? "mdr_layer0" : (li < 3 ? "mdr_layer" : "mdr_attn_head"), stream);
-        static const size_t solo = getenv("GATOR_MDR_SOLO") ? 60 * 1024 : 0;      // diagnostic: 1 workgroup per CU (1 wave/SIMD)
         if (f->mdr_x3) {
             if (li == 0) k_mdr_layer<0, true><<<nwg, 256, solo, st>>>(a, nwg);
             else if (li < 3) k_mdr_layer<1, true><<<nwg, 256, solo, st>>>(a, nwg);
@@ -765,7 +779,8 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
             else k_mdr_layer<2, false><<<nwg, 256, 0, st>>>(a, nwg);
         }
     }
-    if (d_st) {     // diagnostic path only
+#ifdef GATOR_DIAG
+    if (d_st) {
         unsigned long long hst[512];
         GATOR_HIP_CHECK(hipMemcpy(hst, d_st, sizeof(hst), hipMemcpyDeviceToHost));
         const int ns = (B * kVT + 63) / 64;
@@ -780,6 +795,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         fprintf(stderr, "[k_mdr_layer<1> stamps, tile 0] attention(2 heads)=%llu outproj+res=%llu cross-attn block=%llu mlp=%llu customLN+qkv=%llu\n",
                 hst[0], hst[1], hst[2], hst[3], hst[4]);
     }
+#endif
     HeadArgs ha;
     ha.hf = f->hf; ha.bn_w = w.bn_w; ha.bn_b = w.bn_b; ha.bn_mean = w.bn_mean; ha.bn_var = w.bn_var;
     ha.bconv_w = w.bconv_w; ha.bconv_b = w.bconv_b; ha.vc = f->vc; ha.vcp = f->vcp;
@@ -787,8 +803,8 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     ha.alpha = c->alpha;
     { StageTimer tm(c, "mdr_head", stream); k_mdr_head<512><<<B, 512, 0, st>>>(ha); }
     GATOR_HIP_CHECK(hipGetLastError());
-    c->taps["mdr_lbf2"] = {f->lbf, (int64_t)B * kV * kE};
-    c->taps["vert431"] = {f->vc, (int64_t)B * kV * 3};
+    c->set_tap(TAP_MDR_LBF2, f->lbf, (int64_t)B * kV * kE);
+    c->set_tap(TAP_VERT431, f->vc, (int64_t)B * kV * 3);
     return GATOR_OK;
 }
 

@@ -71,19 +71,21 @@ __global__ __launch_bounds__(64 * (kX3Waves + 1), 1) void k_upsample_x3(const __
     const int wg = xcd_remap(blockIdx.x, nwg);
     const int mgroups = (MT + kX3Waves - 1) / kX3Waves;
     const int ob = wg / mgroups;
-    const bf16x8* wb = reinterpret_cast<const bf16x8*>(wp) + ((size_t)ob * kS16) * 64 + lane;
+    // wave-uniform base (scalar registers) + one per-lane offset: nine 64-bit per-lane pointers would cost the loader 18 VGPRs
+    const bf16x8* wu = reinterpret_cast<const bf16x8*>(wp) + ((size_t)ob * kS16) * 64;
     const size_t w_tap = (size_t)kOB * kS16 * 64, wpl = (size_t)w_plane / 8;
+#define W_AT(e, step) wu[(size_t)((e) % 3) * wpl + (size_t)((e) / 3) * w_tap + (size_t)(step) * 64 + lane]
     static_assert(kS16 % kX3Ring == 0, "k-steps must be a multiple of the ring depth");
     if (wave == kX3Waves) {
         bf16x8 ring[kX3Ring][9];
 #pragma unroll
         for (int j = 0; j < kX3Ring; ++j)
 #pragma unroll
-            for (int e = 0; e < 9; ++e) ring[j][e] = wb[(size_t)(e % 3) * wpl + (size_t)(e / 3) * w_tap + (size_t)j * 64];
+            for (int e = 0; e < 9; ++e) ring[j][e] = W_AT(e, j);
 #pragma unroll
         for (int e = 0; e < 9; ++e) {
             wl[0][e][lane] = ring[0][e];
-            ring[0][e] = wb[(size_t)(e % 3) * wpl + (size_t)(e / 3) * w_tap + (size_t)kX3Ring * 64];
+            ring[0][e] = W_AT(e, kX3Ring);
         }
         __syncthreads();
 #pragma unroll 1
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(64 * (kX3Waves + 1), 1) void k_upsample_x3(const __
 #pragma unroll
                 for (int e = 0; e < 9; ++e) {
                     wl[(s + 1) & 1][e][lane] = ring[slot][e];                   // W(s+1), issued three steps ago
-                    ring[slot][e] = wb[(size_t)(e % 3) * wpl + (size_t)(e / 3) * w_tap + (size_t)nxt * 64];
+                    ring[slot][e] = W_AT(e, nxt);
                 }
                 __syncthreads();
             }
@@ -105,12 +107,17 @@ __global__ __launch_bounds__(64 * (kX3Waves + 1), 1) void k_upsample_x3(const __
     const int mt_raw = (wg % mgroups) * kX3Waves + wave;
     const bool live = mt_raw < MT;
     const int mt = live ? mt_raw : MT - 1;             // idle waves shadow the last tile (they must keep the barriers)
-    const bf16x8* ab = reinterpret_cast<const bf16x8*>(vcp) + ((size_t)mt * 3 * kS16) * 64 + lane;
+    const bf16x8* ab = reinterpret_cast<const bf16x8*>(vcp) + ((size_t)__builtin_amdgcn_readfirstlane(mt) * 3 * kS16) * 64 + lane;
     const size_t a_lp = (size_t)kS16 * 64, ap = (size_t)a_plane / 8;
     f32x16 big[3], sm[3];
 #pragma unroll
     for (int l = 0; l < 3; ++l) { big[l] = zero16(); sm[l] = zero16(); }
-    bf16x8 x[3][3], xn[3][3];
+    // Activation fragments x[lp][plane] are reloaded ROLLING: the MFMAs run grouped by input position lp (for a fixed output l
+    // that is still tap order k = 0,1,2, so every accumulator sees the same sequence of products as a tap-major loop), and as
+    // soon as the group of lp has been queued its three fragments are re-requested for the next k-step -- the loads fly behind
+    // the remaining groups and the barrier, at no extra registers (a second prefetch set would cost 36 VGPRs and spill: nine
+    // waves per workgroup leave 168).
+    bf16x8 x[3][3];
 #pragma unroll
     for (int l = 0; l < 3; ++l)
 #pragma unroll
@@ -121,31 +128,23 @@ __global__ __launch_bounds__(64 * (kX3Waves + 1), 1) void k_upsample_x3(const __
         const int cur = s & 1;
         const size_t on = (size_t)(s + 1 < kS16 ? s + 1 : s) * 64;
 #pragma unroll
-        for (int l = 0; l < 3; ++l)
+        for (int lp = 0; lp < 3; ++lp) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) xn[l][p] = ab[p * ap + l * a_lp + on];
-        bf16x8 w[3][3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) w[k][p] = wl[cur][3 * k + p][lane];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int l = 0; l < 3; ++l) {
-                const int lp = l + k - 1;              // out l gets input lp through tap k
-                if (lp < 0 || lp > 2) continue;
-                big[l] = GATOR_MFMA_BF16(x[lp][0], w[k][0], big[l]);      // hi*hi
-                sm[l] = GATOR_MFMA_BF16(x[lp][0], w[k][1], sm[l]);        // hi*mid
-                sm[l] = GATOR_MFMA_BF16(x[lp][1], w[k][0], sm[l]);        // mid*hi
-                sm[l] = GATOR_MFMA_BF16(x[lp][1], w[k][1], sm[l]);        // mid*mid
-                sm[l] = GATOR_MFMA_BF16(x[lp][0], w[k][2], sm[l]);        // hi*lo
-                sm[l] = GATOR_MFMA_BF16(x[lp][2], w[k][0], sm[l]);        // lo*hi
+            for (int k = 2; k >= 0; --k) {             // l = lp + 1 - k ascending <=> k descending; accumulators are independent
+                const int l = lp + 1 - k;
+                if (l < 0 || l > 2) continue;
+                const bf16x8 w0 = wl[cur][3 * k + 0][lane], w1 = wl[cur][3 * k + 1][lane], w2 = wl[cur][3 * k + 2][lane];
+                big[l] = GATOR_MFMA_BF16(x[lp][0], w0, big[l]);      // hi*hi
+                sm[l] = GATOR_MFMA_BF16(x[lp][0], w1, sm[l]);        // hi*mid
+                sm[l] = GATOR_MFMA_BF16(x[lp][1], w0, sm[l]);        // mid*hi
+                sm[l] = GATOR_MFMA_BF16(x[lp][1], w1, sm[l]);        // mid*mid
+                sm[l] = GATOR_MFMA_BF16(x[lp][0], w2, sm[l]);        // hi*lo
+                sm[l] = GATOR_MFMA_BF16(x[lp][2], w0, sm[l]);        // lo*hi
             }
+            asm volatile("" ::: "memory");             // keep the reload below behind this group's MFMAs (and its LDS reads above it)
 #pragma unroll
-        for (int l = 0; l < 3; ++l)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) x[l][p] = xn[l][p];
+            for (int p = 0; p < 3; ++p) x[lp][p] = ab[p * ap + lp * a_lp + on];
+        }
         // Every 7 k-steps the hi*hi chain is flushed into an LDS-resident total and restarted from zero: the chain's
         // partial sums stay small (their roundings scale with their magnitude) and only 4 additions happen at full
         // magnitude -- the two-level summation of the fp32 kernel, with LDS instead of 48 more accumulator registers.

@@ -97,6 +97,10 @@ int gator_upsample_f32(gator_ctx* ctx, const float* vert431, int32_t batch, floa
  *   "hop_path_bias" [8,J,J]   "feat" [B,J,128]   "mdr_lbf2" [B,431,64]   "vert431" [B,431,3]
  * dst is a device pointer with room for `capacity` floats; *count receives the element count. */
 int gator_get_tap(gator_ctx* ctx, const char* name, float* dst, int64_t capacity, int64_t* count, void* stream);
+/* Additional taps "gat_block0" .. "gat_block5" [B,J,128]: the residual stream after each GATBlock (lib/models/GAT.py:33-43,
+ * :145-147).  Off by default (the stores cost time); fused ctx only.  Taps never outlive the next call on the ctx; the "feat" tap
+ * of the stand-alone gator_gat_forward_f32 aliases the caller's `feat` buffer. */
+int gator_enable_block_taps(gator_ctx* ctx, int32_t on);
 
 /* Measurement hook (bench.py `roofline`): gator_profile_enable(ctx, n) with n >= 1 brackets every stage launch of every
  * n-th forward by a hipEvent pair recorded on the launch stream (n = 0 switches it off).  gator_profile_read synchronises those events and returns, per stage name

@@ -20,30 +20,30 @@ def golden_shapes(z):
             for k, s in zip(z['state_dict_keys'], z['state_dict_shapes'])}
 
 
-def variant_setup(name):
+def variant_setup(name, upsample_gain=0.2):
     """-> (z, J, alpha, base, numpy seeded weights {key: ndarray})  (same stream order as tools/gen_golden.py)."""
     z = load_golden(name)
     J, alpha, seed = int(z['num_joint']), bool(z['alpha']), int(z['seed'])
     base = synthetic.make_base_data(seed)
-    weights = synthetic.seeded_state_dict(golden_shapes(z), base['rs'])
+    weights = synthetic.seeded_state_dict(golden_shapes(z), base['rs'], upsample_gain=upsample_gain)
     return z, J, alpha, base, weights
 
 
-def oracle_setup(name):
+def oracle_setup(name, upsample_gain=0.2):
     from oracle import gator_oracle as go
-    z, J, alpha, base, weights = variant_setup(name)
+    z, J, alpha, base, weights = variant_setup(name, upsample_gain)
     c = go.Consts(J, synthetic.model_j_regressor(J), base, alpha)
     sd = {k: torch.from_numpy(v) for k, v in weights.items()}
     sd['pose_lifter.graph_adj'] = torch.from_numpy(c.graph_adj)
     return z, c, sd
 
 
-def build_model(name, impl='fused', device='cuda'):
+def build_model(name, impl='fused', device='cuda', upsample_gain=0.2):
     """gator_amd GATOR module of a golden variant with the seeded weights loaded, on `device`."""
     import scipy.sparse as sps
     from gator_amd import models
     from gator_amd.models.GAT import _dense_adj  # noqa: F401
-    z, J, alpha, base, weights = variant_setup(name)
+    z, J, alpha, base, weights = variant_setup(name, upsample_gain)
     sk, fl = _joint_setting(J)
     adj = np.zeros((J, J))
     for a, b in tuple(sk) + tuple(fl):

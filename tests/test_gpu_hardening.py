@@ -1,0 +1,121 @@
+"""Parity hardening (round-1 verdict): a scale-free criterion at two output gains against goldens made by the REAL reference,
+the per-block residual-stream taps, the Procrustes kernel against the reference's own rigid_align, the first bf16 call in
+sub-batch mode, and config 3 (bf16 vertex regressor) at its full size B=2048, J=19."""
+import numpy as np
+import pytest
+import torch
+
+from gator_amd import eval as geval
+from gator_amd import synthetic
+from tests.helpers import build_model, load_golden, oracle_setup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('fixture,gain', [('scale_gain02', 0.2), ('scale_gain10', 1.0)])
+@pytest.mark.parametrize('x3', ['1', '0'])
+def test_scale_free_parity(fixture, gain, x3, monkeypatch):
+    """max|ours - ref fp64| <= 1.5 x max|ref fp32 - ref fp64| on the same weights and inputs (B=64, fixed 512-vertex subset),
+    at the human-scale gain 0.2 AND at gain 1.0 (5 m meshes, where an absolute 1e-3 mm bound is unmeetable by the reference
+    itself): the error follows the reference's own fp32 noise, whatever the magnitude.  Both MFMA forms."""
+    for k in ('GATOR_GAT_X3', 'GATOR_MDR_X3', 'GATOR_UPSAMPLE_X3'):
+        monkeypatch.setenv(k, x3)
+    z = load_golden(fixture)
+    zz, m = build_model(str(z['variant']), 'fused', upsample_gain=gain)
+    sub = torch.from_numpy(z['vertex_subset'].astype(np.int64)).cuda()
+    verts, pose3d = m(torch.from_numpy(z['pose2d']).cuda())
+    ours = np.abs(verts[:, sub].cpu().numpy().astype(np.float64) - z['verts_f64']) * 1e3
+    ref = np.abs(z['ref32_minus_f64'].astype(np.float64)) * 1e3
+    print('\n[%s x3=%s] ours vs ref-fp64: max %.3e rms %.3e mm ; ref-fp32 vs ref-fp64: max %.3e rms %.3e mm ; ratio %.2f'
+          % (fixture, x3, ours.max(), np.sqrt((ours ** 2).mean()), ref.max(), np.sqrt((ref ** 2).mean()), ours.max() / ref.max()))
+    assert ours.max() <= 1.5 * ref.max()
+    assert np.sqrt((ours ** 2).mean()) <= 1.5 * np.sqrt((ref ** 2).mean())
+    assert np.abs(pose3d.cpu().numpy() - z['pose3d_f64']).max() <= 1e-3
+    if gain == 0.2:
+        assert ours.max() <= 1e-3            # the north star's absolute bound at human scale
+
+
+@pytest.mark.parametrize('name', ['h36m17_bn', 'coco19_alpha'])
+def test_block_taps_match_reference(name):
+    """Residual stream after GATBlock 0 and 5 (lib/models/GAT.py:145-147) against the reference's recorded activations."""
+    z, m = build_model(name, 'fused')
+    B, J = z['pose2d'].shape[:2]
+    x = torch.from_numpy(z['pose2d']).cuda()
+    v0, _ = m(x)
+    m.enable_block_taps(True)
+    v1, _ = m(x)
+    assert torch.equal(v0, v1)                                        # the tap stores change nothing
+    for blk in (0, 5):
+        t = m.get_tap('gat_block%d' % blk, (B, J, 128)).cpu().numpy().astype(np.float64)
+        ref = z['gat_block%d' % blk].astype(np.float64)
+        err = np.abs(t - ref).max()
+        print('[%s] gat_block%d max|d| %.2e (scale %.2f)' % (name, blk, err, np.abs(ref).max()))
+        assert err <= 4e-6 * max(1.0, np.abs(ref).max())
+    m.enable_block_taps(False)
+    m(x)
+    with pytest.raises(RuntimeError):
+        m.get_tap('gat_block0', (B, J, 128))
+
+
+def test_rigid_align_kernel_matches_reference_golden():
+    """gator_rigid_align_f32 against lib/coord_utils.py:127-149 itself (tests/golden/rigid_align.npz: random, mirrored,
+    near-coplanar, scaled); inputs are float32 on the device as in the eval loop."""
+    z = load_golden('rigid_align')
+    a, b = torch.from_numpy(z['A'].astype(np.float32)).cuda(), torch.from_numpy(z['B'].astype(np.float32)).cuda()
+    out = geval.rigid_align(a, b).cpu().numpy().astype(np.float64)
+    ref = z['aligned_from_f32']
+    scale = np.abs(ref).max()
+    print('\nrigid_align vs reference: max|d| %.3e mm (scale %.1f mm)' % (np.abs(out - ref).max(), scale))
+    assert np.abs(out - ref).max() <= 2e-6 * scale                   # fp32 output rounding of an fp64 solve
+    pa = float(geval.pa_mpjpe(a, b, eval_joints=list(range(14))))
+    assert abs(pa - float(z['pa_mpjpe'])) <= 1e-4 * float(z['pa_mpjpe'])
+
+
+def test_first_bf16_call_in_subbatch_mode_is_bitwise():
+    """The FIRST gator_forward_bf16 on a fresh context in sub-batch-streams mode (the bf16 weight pack is lazy: the second
+    half-batch runs on another stream and must not read the pack before it is complete)."""
+    x = torch.from_numpy(synthetic.synthetic_pose2d(192, 19, seed=31)).cuda()
+    z, ref_m = build_model('coco19_alpha', 'fused')
+    ref_m.precision = 'bf16'
+    want_v, want_p = ref_m(x)
+    torch.cuda.synchronize()
+    for trial in range(3):
+        z, m = build_model('coco19_alpha', 'fused')
+        m.precision = 'bf16'
+        m.subbatch_streams = 2
+        got_v, got_p = m(x)                                            # first call on a fresh ctx
+        torch.cuda.synchronize()
+        assert torch.equal(got_v, want_v) and torch.equal(got_p, want_p), 'trial %d' % trial
+
+
+def test_bf16_config3_full_size():
+    """BASELINE config 3 at its own size: B=2048 COCO 19-joint, bf16-MFMA vertex regressor.  The oracle is too slow for 2048
+    samples; the fp32 path (parity-tested at this size in test_gpu_fullsize.py) is the anchor, the oracle checks a 24-sample
+    slice, and the size-independent properties (slice == small batch, determinism) hold bitwise."""
+    from oracle import gator_oracle as go
+    B, J = 2048, 19
+    z, m = build_model('coco19_alpha', 'fused')
+    x = torch.from_numpy(synthetic.synthetic_pose2d(B, J, seed=77)).cuda()
+    m.precision = 'bf16'
+    vb, pb = m(x)
+    vb2, _ = m(x)
+    assert torch.equal(vb, vb2)                                        # deterministic
+    vs, _ = m(x[1000:1040])
+    assert torch.equal(vs, vb[1000:1040])                              # a slice of the big batch == the small batch
+    m.precision = 'f32'
+    vf, pf = m(x)
+    assert torch.equal(pb, pf)                                         # GAT is untouched by the regressor's precision
+    d = (vb - vf).abs() * 1e3
+    rms = float(torch.sqrt((d.double() ** 2).mean()))
+    print('\n[bf16 B=2048 J=19] vs fp32 path: max %.3f mm rms %.3f mm' % (float(d.max()), rms))
+    assert float(d.max()) < 8.0 and rms < 1.0
+    jr = synthetic.load_j_regressors()['h36m']
+    reg = geval.JointRegressor(jr, 'cuda')
+    jb, jf = reg(vb) * 1000.0, reg(vf) * 1000.0
+    assert float((jb - jf).abs().max()) < 3.0
+    gt = jf + torch.from_numpy(np.random.RandomState(0).randn(B, 17, 3).astype(np.float32) * 30.0).cuda()
+    assert abs(float(geval.mpjpe(jb, gt)) - float(geval.mpjpe(jf, gt))) < 0.25
+    zz, c, sd = oracle_setup('coco19_alpha')
+    ref, _ = go.gator_forward(sd, c, x[500:524].cpu(), torch.float64)
+    e = np.abs(vb[500:524].cpu().numpy().astype(np.float64) - ref.numpy()) * 1e3
+    assert e.max() < 8.0 and np.sqrt((e ** 2).mean()) < 1.0

@@ -67,3 +67,29 @@ def test_demo_preprocess_plumbing():
     assert x.shape == (19, 2)
     assert np.abs(x - z['pose2d'][0]).max() < 5e-6       # float32 cast at lib/aug_utils.py:63
     assert abs(z['pose2d'].min() + 2.0051) < 1e-3 and abs(z['pose2d'].max() - 2.1714) < 1e-3
+
+
+@pytest.mark.parametrize('fixture,gain', [('scale_gain02', 0.2), ('scale_gain10', 1.0)])
+def test_scale_fixtures_pin_the_oracle(fixture, gain):
+    """B=64 at two output-head gains (the REAL reference's fp32 run and its fp64 anchor on a fixed 512-vertex subset): the fp64
+    oracle reproduces the anchor, and the fp32 oracle is as close to it as the reference's own fp32 run is (scale-free)."""
+    z = load_golden(fixture)
+    zz, c, sd = oracle_setup(str(z['variant']), upsample_gain=gain)
+    x = torch.from_numpy(z['pose2d'])
+    sub = z['vertex_subset'].astype(np.int64)
+    mesh64, p64 = go.gator_forward(sd, c, x, torch.float64)
+    scale = float(z['verts_absmax'])
+    assert np.abs(mesh64.numpy()[:, sub] - z['verts_f64']).max() * 1e3 < 5e-5 * max(1.0, scale)
+    assert np.abs(p64.numpy() - z['pose3d_f64']).max() < 1e-6
+    ref_noise = float(np.abs(z['ref32_minus_f64'].astype(np.float64)).max() * 1e3)
+    mesh32, _ = go.gator_forward(sd, c, x, torch.float32)
+    ours = float(np.abs(mesh32.numpy()[:, sub].astype(np.float64) - z['verts_f64']).max() * 1e3)
+    assert ours <= 1.5 * ref_noise, (ours, ref_noise)
+
+
+def test_rigid_align_matches_reference():
+    """oracle.rigid_align / pa_mpjpe == lib/coord_utils.py:127-149 run on random, mirrored, near-coplanar and scaled sets."""
+    z = load_golden('rigid_align')
+    out = np.stack([go.rigid_align(a, b) for a, b in zip(z['A'], z['B'])])
+    assert np.abs(out - z['aligned']).max() < 1e-9 * np.abs(z['aligned']).max()
+    assert abs(go.pa_mpjpe(z['A'], z['B']) - float(z['pa_mpjpe'])) < 1e-9

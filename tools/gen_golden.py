@@ -128,7 +128,7 @@ def dump_jregressors():
     np.savez(os.path.join(OUT, 'j_regressors.npz'), **z)
 
 
-def run_variant(name, J, alpha, seed, B=4):
+def run_variant(name, J, alpha, seed, B=4, upsample_gain=0.2, subset=None, out_name=None):
     import scipy.sparse as sps
     scratch = tempfile.mkdtemp(prefix='gator_golden_')
     for m in [k for k in sys.modules if k.split('.')[0] in ('models', 'graph_utils', 'coarsening', 'core', 'funcs_utils')]:
@@ -153,10 +153,10 @@ def run_variant(name, J, alpha, seed, B=4):
     model = models.GATOR.get_model(J, 128, 6, graph_adj, 1, torch.Tensor(jreg))
     model.eval()
     sd = model.state_dict()
-    new = synthetic.seeded_state_dict(synthetic.shapes_of(sd), rs)
+    new = synthetic.seeded_state_dict(synthetic.shapes_of(sd), rs, upsample_gain=upsample_gain)
     sd.update({k: torch.from_numpy(v) for k, v in new.items()})
     model.load_state_dict(sd)
-    pose2d = synthetic.synthetic_pose2d(B, J, seed + 1)
+    pose2d = synthetic.synthetic_pose2d(B, J, seed + 1 if subset is None else seed + 17)
     x = torch.from_numpy(pose2d)
 
     taps = {}
@@ -192,6 +192,19 @@ def run_variant(name, J, alpha, seed, B=4):
     hp.spatial = hp.spatial.double()
     with torch.no_grad():
         verts64, pose3d64 = m64(x.double())
+    if subset is not None:
+        # scale-free parity fixture: a fixed vertex subset of a larger batch, reference fp32 output and its fp64 anchor
+        v32, v64 = verts.float().numpy()[:, subset], verts64.numpy()[:, subset]
+        noise = np.abs(verts.double().numpy() - verts64.numpy()).max() * 1e3
+        np.savez(os.path.join(OUT, out_name + '.npz'), variant=name, seed=np.int64(seed), upsample_gain=np.float64(upsample_gain),
+                 pose2d=pose2d, vertex_subset=subset.astype(np.int32), verts_f64=v64,
+                 ref32_minus_f64=(v32.astype(np.float64) - v64).astype(np.float32),
+                 pose3d_f64=pose3d64.numpy(), ref32_noise_mm_all_vertices=np.float64(noise),
+                 verts_absmax=np.float64(np.abs(verts64.numpy()).max()))
+        print('%s: gain %.1f B=%d  |verts| max %.3f m  ref fp32-vs-fp64 max %.3e mm (all vertices), %.3e mm (subset)'
+              % (out_name, upsample_gain, B, np.abs(verts64.numpy()).max(), noise, np.abs(v32 - v64).max() * 1e3))
+        os.chdir(REPO)
+        return
     gat = model.pose_lifter
     out = dict(
         seed=np.int64(seed), alpha=np.bool_(alpha), num_joint=np.int64(J),
@@ -248,10 +261,47 @@ def demo_preprocess_golden():
     print('demo: normalised rows 0-3', ji[:4].round(4).tolist(), 'min %.4f max %.4f' % (ji.min(), ji.max()))
 
 
+def rigid_align_golden():
+    """lib/coord_utils.py:127-149 run as it is: random, mirrored (det < 0 branch), near-coplanar and scaled point sets, plus the
+    PA-MPJPE reduction of data/PW3D/dataset.py:337-375 (per-sample rigid_align on the 14 evaluation joints, mean distance)."""
+    scratch = tempfile.mkdtemp(prefix='gator_golden_')
+    install_shims(scratch, True)
+    for m in [k for k in sys.modules if k in ('coord_utils',)]:
+        del sys.modules[m]
+    import coord_utils
+    rs = np.random.RandomState(4242)
+    A, B = [], []
+    for i in range(24):
+        a = rs.randn(14, 3) * 120
+        q, _ = np.linalg.qr(rs.randn(3, 3))
+        b = (0.5 + rs.rand()) * a @ q.T + rs.randn(3) * 40 + rs.randn(14, 3) * (8 if i % 2 else 0.0)
+        if i % 4 == 1:
+            b[:, 0] = -b[:, 0]                      # mirror image: forces the reflection fix
+        if i % 6 == 2:
+            a[:, 2] *= 1e-3                         # nearly coplanar: smallest singular value ~ 0
+        A.append(a)
+        B.append(b)
+    A, B = np.stack(A), np.stack(B)
+    out = np.stack([coord_utils.rigid_align(a, b) for a, b in zip(A, B)])
+    pa = float(np.mean([np.sqrt(((o - b) ** 2).sum(1)).mean() for o, b in zip(out, B)]))
+    A32, B32 = A.astype(np.float32), B.astype(np.float32)      # the reference feeds float32 arrays from the model
+    out32 = np.stack([coord_utils.rigid_align(a, b) for a, b in zip(A32, B32)])
+    np.savez(os.path.join(OUT, 'rigid_align.npz'), A=A, B=B, aligned=out, pa_mpjpe=np.float64(pa), aligned_from_f32=out32)
+    print('rigid_align: 24 sets, PA error %.4f mm' % pa)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    dump_jregressors()
-    run_variant('h36m17_bn', 17, False, seed=0)
-    run_variant('coco19_alpha', 19, True, seed=100)
-    demo_preprocess_golden()
+    only = sys.argv[1:]
+    if not only or 'base' in only:
+        dump_jregressors()
+        run_variant('h36m17_bn', 17, False, seed=0)
+        run_variant('coco19_alpha', 19, True, seed=100)
+        demo_preprocess_golden()
+    if not only or 'scale' in only:
+        sub = np.sort(np.random.RandomState(99).permutation(6890)[:512])
+        run_variant('h36m17_bn', 17, False, seed=0, B=64, upsample_gain=0.2, subset=sub, out_name='scale_gain02')
+        run_variant('h36m17_bn', 17, False, seed=0, B=64, upsample_gain=1.0, subset=sub, out_name='scale_gain10')
+    if not only or 'rigid' in only:
+        rigid_align_golden()
