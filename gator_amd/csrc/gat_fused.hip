@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
         st_last = now_;                                   \
     }
 #else
-#define GAT_STAMP(i)
+// Production build: no stamps, but the phase boundaries stay scheduling fences -- measured: without them hipcc interleaves the
+// phases' loads and MFMAs differently and k_gat runs 265 -> 364 us at B=256.
+#define GAT_STAMP(i) __builtin_amdgcn_sched_barrier(0);
 #endif
 
     // ---------------- embedding: GraphLinear(2->64) . GroupNorm(4,64) . GELU . GraphLinear(64->128) + pos (GAT.py:135-144)
