@@ -54,8 +54,8 @@ STAGE_MFLOP = {'upsample_bf16': 53.45, 'gat': 56.66, 'mdr_layer0': 48.7, 'mdr_la
 _VF, _QKV = 14 * 2 * 4096, 3 * 14 * 2 * 6144
 STAGE_BYTES = {'mdr_layer0': _VF + _QKV, 'mdr_layer': 2 * (_VF + _QKV), 'mdr_attn_head': _VF + _QKV + 431 * 32 * 4 + 431 * 64 * 4,
                'upsample': 3 * 431 * 2 * 3 + 6890 * 3 * 4, 'gat': 136 + 17 * 128 * 4 + 204 + 12 * 4096}
-STAGE_KERNEL = {'gat': 'k_gat', 'mdr_layer0': 'k_mdr_layer<0, true>', 'mdr_layer': 'k_mdr_layer<1, true>',
-                'mdr_attn_head': 'k_mdr_layer<2, true>', 'upsample': 'k_upsample_x3'}
+STAGE_KERNEL = {'gat': 'k_gat', 'mdr_layer0': 'k_mdr_layer<0,', 'mdr_layer': 'k_mdr_layer<1,',
+                'mdr_attn_head': 'k_mdr_layer<2,', 'upsample': 'k_upsample_x3'}
 
 
 def parse():

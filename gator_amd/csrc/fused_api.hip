@@ -185,7 +185,8 @@ int fused_create(gator_ctx* c, void* stream) {
     const char* x3env = getenv("GATOR_UPSAMPLE_X3");
     f->x3 = !(x3env && atoi(x3env) == 0);
     const char* mx3 = getenv("GATOR_MDR_X3");
-    f->mdr_x3 = !(mx3 && atoi(mx3) == 0);
+    f->mdr_x3 = mx3 ? atoi(mx3) : 2;
+    if (f->mdr_x3 < 0 || f->mdr_x3 > 2) return fail(GATOR_EINVAL, "GATOR_MDR_X3 must be 0, 1 or 2");
     const size_t n_up = f->x3 ? 0 : (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)64 * kTile;
     const size_t total = n_up + 3 * n_layer + 24 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
     GATOR_HIP_CHECK(hipMalloc(&f->wbuf, total * sizeof(float)));

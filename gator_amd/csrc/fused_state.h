@@ -49,7 +49,7 @@ struct FusedState : FusedWs {
     bool gat_x3 = true;                 // GAT linears on split-precision bf16 MFMA (GATOR_GAT_X3=0: fp32-input MFMA)
     float* gxbuf = nullptr;             // X3 tiles of the GAT block weights, tile-for-tile image of gbuf from gblk[0].qkv on
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
-    bool mdr_x3 = true;                 // MDR self-attention on split-precision bf16 MFMA (GATOR_MDR_X3=0: fp32-input MFMA)
+    int mdr_x3 = 2;                     // GATOR_MDR_X3: 0 fp32-input MFMA; 1 exact bf16 x 3 split everywhere; 2 (default) that + the 431x431 attention on two fp16 planes
     bool x3 = true;                     // split-precision vertex regressor (GATOR_UPSAMPLE_X3=0: fp32-input MFMA kernel)
     void* up_w16 = nullptr;             // bf16 [tap][ob][28][64][8] (packed on the first bf16 call, which waits for the pack)
     float* blk_tap = nullptr;           // debug: residual stream after every GATBlock [depth][B][J][128] (gator_enable_block_taps)

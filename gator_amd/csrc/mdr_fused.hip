@@ -224,6 +224,61 @@ __device__ __forceinline__ f32x16 self_attention_head_x3(const float* __restrict
     return (O + O2) * (1.0f / l);
 }
 
+// ---- the same on two-plane fp16 operands (x3_common.h, "X2"): 6 MFMAs per product instead of 12, 3 VALU ops per split value
+// instead of 5.5, 4 KiB tiles instead of 6.  Q and K arrive scaled by 16 (Q also by log2(e)/sqrt(d_k)), so the accumulator holds
+// 256 x the score: the running maximum is kept in that domain and the 2^-8 rides on the FMA that forms the exponent.  V arrives
+// scaled by 16 and the probabilities carry an extra 2^6 (so that their low plane stays a normal fp16 number); both cancel in
+// O / (16 l).
+constexpr float kX2QK = 16.0f, kX2V = 16.0f;
+#define ATTN_TILE_X2(KT, KB, VB, OACC)                                                                      \
+    {                                                                                                       \
+        f32x16 S = x2_mma(KB, qx, zero16());  /* 256 x S^T[key][query] */                                   \
+        float bm = -1e30f;                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+            float sc = S[r];                                                                                \
+            if ((KT) == kVT - 1 && kap(r) + 4 * h >= kV - 32 * (kVT - 1)) sc = -1e30f;                      \
+            S[r] = sc;                                                                                      \
+            bm = fmaxf(bm, sc);                                                                             \
+        }                                                                                                   \
+        bm = fmaxf(bm, xhalf(bm));                                                                          \
+        if (!__all(bm <= m + 2048.0f)) {      /* lazy rescale: P stays <= 2^8 (x 2^6 below) */               \
+            const float mn = fmaxf(m, bm);                                                                  \
+            const float al = __builtin_amdgcn_exp2f((m - mn) * 0.00390625f);                                \
+            O = O * al;                                                                                     \
+            O2 = O2 * al;                                                                                   \
+            l *= al;                                                                                        \
+            m = mn;                                                                                         \
+        }                                                                                                   \
+        const float off = 6.0f - m * 0.00390625f;                                                           \
+        float ps = 0.f;                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+            const float pe = __builtin_amdgcn_exp2f(fmaf(S[r], 0.00390625f, off));                          \
+            S[r] = pe;                                                                                      \
+            ps += pe;                                                                                       \
+        }                                                                                                   \
+        l += ps;                                                                                            \
+        OACC = x2_mma(VB, x2_split(S), OACC);   /* O^T[d][query] += V^T[d][key] P^T[key][query] */          \
+    }
+__device__ __forceinline__ f32x16 self_attention_head_x2(const float* __restrict__ qt, const float* __restrict__ kbase,
+                                                         const float* __restrict__ vbase, int lane) {
+    const int h = lane >> 5;
+    const X2 qx = x2_load(qt, lane);
+    f32x16 O = zero16(), O2 = zero16();
+    float m = -1e30f, l = 0.f;
+    X2 kb = x2_load(kbase, lane), vb = x2_load(vbase, lane);
+#pragma unroll 1
+    for (int kt = 0; kt < kVT; kt += 2) {                   // tiles kt (-> O) and kt + 1 (-> O2); the next tile's K/V in flight
+        X2 kn = x2_load(kbase + (size_t)(kt + 1) * 2 * kTile, lane), vn = x2_load(vbase + (size_t)(kt + 1) * 2 * kTile, lane);
+        ATTN_TILE_X2(kt, kb, vb, O)
+        const int k2 = kt + 2 < kVT ? kt + 2 : kt;
+        kb = x2_load(kbase + (size_t)k2 * 2 * kTile, lane);
+        vb = x2_load(vbase + (size_t)k2 * 2 * kTile, lane);
+        ATTN_TILE_X2(kt + 1, kn, vn, O2)
+    }
+    l += xhalf(l);
+    return (O + O2) * ((1.0f / kX2V) / l);
+}
+
 // ---- cross-attention over the J joint tokens (keys/values precomputed per sample by k_mdr_joint) -------------------------
 __device__ __forceinline__ f32x16 cross_attention_head(const float* __restrict__ kj, const float* __restrict__ vjp,
                                                        const f32x16& qh, int J, int lane) {
@@ -255,8 +310,11 @@ __device__ __forceinline__ f32x16 cross_attention_head(const float* __restrict__
 // ---- weight stream of the tokenwise part: two buffers of one tile pair each (2 x 32 VGPRs).  The pair for the NEXT
 // product is requested right after the current product's MFMAs are queued, so its L2 latency hides behind them and
 // behind the co-resident wave.  MDR_PIN keeps the order (memory ops and scheduler).
-template <bool X> __device__ __forceinline__ void st_op(float* p, int lane, const f32x16& v) {
-    if constexpr (X) x3_store(p, lane, x3_split(v)); else store_block(p, lane, v);
+// Q/K/V tile store in the attention's operand form: 0 fp32 block, 1 exact three-plane bf16 (X3), 2 two-plane fp16 (X2)
+template <int X> __device__ __forceinline__ void st_op(float* p, int lane, const f32x16& v) {
+    if constexpr (X == 1) x3_store(p, lane, x3_split(v));
+    else if constexpr (X == 2) x2_store(p, lane, x2_split(v));
+    else store_block(p, lane, v);
 }
 struct W2 { WTile t[2]; };
 __device__ __forceinline__ W2 ldw2(const float* __restrict__ Wp, int i0, int i1, int lane) {
@@ -298,9 +356,13 @@ template <bool X> __device__ __forceinline__ typename TokOp<X>::A mk(const f32x1
     if constexpr (X) return x3_split(v); else return v;
 }
 
-template <int MODE, bool X>   // 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
+// MODE 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
+// XA   0: everything on the fp32-input MFMA ; 1: split precision (exact bf16 x 3) everywhere ; 2: split-precision linears and
+//         the 431x431 self-attention on two fp16 planes (the default)
+template <int MODE, int XA>
 __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) {
-    constexpr int TQ = X ? kTileX3 : kTile;
+    constexpr bool X = XA != 0;
+    constexpr int TQ = XA == 1 ? kTileX3 : kTile;
     __shared__ f32x4 park[X ? 8 : 1][X ? 256 : 1];
     auto park_vf = [&](const f32x16 (&v)[2]) {
 #pragma unroll
@@ -365,7 +427,12 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         }
     } else {
         f32x16 att[2];
-        if constexpr (X) {
+        if constexpr (XA == 2) {
+            att[0] = self_attention_head_x2(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
+                                            a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
+            att[1] = self_attention_head_x2(a.q_in + (tile + 1) * TQ, a.k_in + ((size_t)b * kVT * 2 + 1) * TQ,
+                                            a.v_in + ((size_t)b * kVT * 2 + 1) * TQ, lane);
+        } else if constexpr (XA == 1) {
             att[0] = self_attention_head_x3(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
                                             a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
             att[1] = self_attention_head_x3(a.q_in + (tile + 1) * TQ, a.k_in + ((size_t)b * kVT * 2 + 1) * TQ,
@@ -513,11 +580,12 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         B = ldw<X>(w.sa1, 2, 3, lane);
         MDR_PIN();
         if constexpr (X) {      // the consumer's softmax works in the exp2 domain: fold log2(e) / sqrt(d_k) into Q once, here
-            y0 = y0 * (kLog2e * 0.17677669529663688110f);
-            y1 = y1 * (kLog2e * 0.17677669529663688110f);
+            constexpr float qs = kLog2e * 0.17677669529663688110f * (XA == 2 ? kX2QK : 1.0f);
+            y0 = y0 * qs;
+            y1 = y1 * qs;
         }
-        st_op<X>(a.q_out + (tile + 0) * TQ, lane, y0);
-        st_op<X>(a.q_out + (tile + 1) * TQ, lane, y1);
+        st_op<XA>(a.q_out + (tile + 0) * TQ, lane, y0);
+        st_op<XA>(a.q_out + (tile + 1) * TQ, lane, y1);
         y0 = lin2_T(A, vfx, load_chanvec_S(w.sa1_b, 0, h));
         A = ldw<X>(w.sa2, 0, 1, lane);
         MDR_PIN();
@@ -526,8 +594,9 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         const float bv0 = w.sa2_b[lane & 31], bv1 = w.sa2_b[32 + (lane & 31)];
         MDR_PIN();
         if (token >= kV) { y0 = zero16(); y1 = zero16(); }                   // pad keys: finite (they are masked anyway)
-        st_op<X>(a.k_out + (tile + 0) * TQ, lane, y0);
-        st_op<X>(a.k_out + (tile + 1) * TQ, lane, y1);
+        if constexpr (XA == 2) { y0 = y0 * kX2QK; y1 = y1 * kX2QK; }
+        st_op<XA>(a.k_out + (tile + 0) * TQ, lane, y0);
+        st_op<XA>(a.k_out + (tile + 1) * TQ, lane, y1);
         y0 = lin2_C(A, vfx);                                                  // V in C-layout: channel on the lane
         y1 = lin2_C(B, vfx);
 #pragma unroll
@@ -536,8 +605,9 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
             y0[r] = ok ? y0[r] + bv0 : 0.f;
             y1[r] = ok ? y1[r] + bv1 : 0.f;
         }
-        st_op<X>(a.v_out + (tile + 0) * TQ, lane, y0);
-        st_op<X>(a.v_out + (tile + 1) * TQ, lane, y1);
+        if constexpr (XA == 2) { y0 = y0 * kX2V; y1 = y1 * kX2V; }
+        st_op<XA>(a.v_out + (tile + 0) * TQ, lane, y0);
+        st_op<XA>(a.v_out + (tile + 1) * TQ, lane, y1);
     }
     MDR_STAMP(4)
 #ifdef GATOR_DIAG
@@ -743,7 +813,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     for (int i = 0; i < 3; ++i) { ja.n1w[i] = w.lay[i].n1w; ja.n1b[i] = w.lay[i].n1b; ja.wk_p[i] = f->lay[i].wk; ja.wv_p[i] = f->lay[i].wv; }
     if (pc) { StageTimer tm(c, "mdr_joint", stream); k_mdr_joint<<<B, 128, 0, st>>>(ja); }    // else: done by k_gat's epilogue
     const size_t per = (size_t)f->cap * kVT * 2 * kTile;      // one [B][14][2] tile set
-    const size_t perq = (size_t)f->cap * kVT * 2 * (f->mdr_x3 ? kTileX3 : kTile);      // q/k/v tile sets: X3 tiles when split-precision
+    const size_t perq = (size_t)f->cap * kVT * 2 * (f->mdr_x3 == 1 ? kTileX3 : kTile);      // q/k/v tile sets: X3 tiles are 1.5x, fp32 and X2 tiles 4 KiB
     float* set[2][4] = {{f->vf, f->q, f->k, f->v}, {f->vf + per, f->q + perq, f->k + perq, f->v + perq}};
     MdrArgs a{};
     a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.xout = pc ? nullptr : x_out; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
@@ -769,14 +839,18 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         if (li > 0) a.prev = make_layer(f, c, li - 1);
         if (li < 3) a.cur = make_layer(f, c, li);
         StageTimer tm(c, li == 0 ? "mdr_layer0" : (li < 3 ? "mdr_layer" : "mdr_attn_head"), stream);
-        if (f->mdr_x3) {
-            if (li == 0) k_mdr_layer<0, true><<<nwg, 256, solo, st>>>(a, nwg);
-            else if (li < 3) k_mdr_layer<1, true><<<nwg, 256, solo, st>>>(a, nwg);
-            else k_mdr_layer<2, true><<<nwg, 256, 0, st>>>(a, nwg);
+        if (f->mdr_x3 == 2) {
+            if (li == 0) k_mdr_layer<0, 2><<<nwg, 256, solo, st>>>(a, nwg);
+            else if (li < 3) k_mdr_layer<1, 2><<<nwg, 256, solo, st>>>(a, nwg);
+            else k_mdr_layer<2, 2><<<nwg, 256, 0, st>>>(a, nwg);
+        } else if (f->mdr_x3 == 1) {
+            if (li == 0) k_mdr_layer<0, 1><<<nwg, 256, solo, st>>>(a, nwg);
+            else if (li < 3) k_mdr_layer<1, 1><<<nwg, 256, solo, st>>>(a, nwg);
+            else k_mdr_layer<2, 1><<<nwg, 256, 0, st>>>(a, nwg);
         } else {
-            if (li == 0) k_mdr_layer<0, false><<<nwg, 256, 0, st>>>(a, nwg);
-            else if (li < 3) k_mdr_layer<1, false><<<nwg, 256, 0, st>>>(a, nwg);
-            else k_mdr_layer<2, false><<<nwg, 256, 0, st>>>(a, nwg);
+            if (li == 0) k_mdr_layer<0, 0><<<nwg, 256, 0, st>>>(a, nwg);
+            else if (li < 3) k_mdr_layer<1, 0><<<nwg, 256, 0, st>>>(a, nwg);
+            else k_mdr_layer<2, 0><<<nwg, 256, 0, st>>>(a, nwg);
         }
     }
 #ifdef GATOR_DIAG

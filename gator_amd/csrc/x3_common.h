@@ -71,6 +71,57 @@ __device__ __forceinline__ f32x16 x3_mma(const X3& A, const X3& B, f32x16 acc) {
     return acc;
 }
 
+// ---- two-plane fp16 operands ("X2"), used ONLY for the 431x431 self-attention of the MDR layers (Q, K, V, P) ----------------
+// x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits, three partial products (hi*hi, hi*lo, lo*hi) per k-step
+// instead of six.  Unlike the exact three-way bf16 split this ROUNDS the operands (2^-23 relative), which is only acceptable
+// where the result is an average over many terms: measured in the fp64 oracle (two real fp16 planes, all other arithmetic exact)
+// the vertices move by 8e-6 mm max / 1.4e-6 mm rms -- 1 % of the path's own fp32 noise -- whereas the same treatment of the
+// token-wise linears costs 4e-4 mm (as much as the whole budget), so those stay on the exact split.  Operands are pre-scaled
+// by powers of two (Q, K, V x 16; P x 64 through the softmax offset) so that the low planes stay out of fp16's subnormal range.
+// Tile = [plane 2][k-step 2][lane 64][8 halves] = 4 KiB (the size of the fp32 tile).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define GATOR_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+struct X2 { f16x8 p[2][2]; };       // [plane hi/lo][k-step]: 16 VGPRs
+
+__device__ __forceinline__ X2 x2_split(const f32x16& v) {
+    X2 o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = v[8 * s + j];
+            const _Float16 h = (_Float16)x;
+            o.p[0][s][j] = h;
+            o.p[1][s][j] = (_Float16)(x - (float)h);
+        }
+    return o;
+}
+__device__ __forceinline__ X2 x2_load(const float* __restrict__ tile, int lane) {
+    const f16x8* q = reinterpret_cast<const f16x8*>(tile) + lane;
+    X2 o;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) o.p[pl][s] = q[(pl * 2 + s) * 64];
+    return o;
+}
+__device__ __forceinline__ void x2_store(float* __restrict__ tile, int lane, const X2& v) {
+    f16x8* q = reinterpret_cast<f16x8*>(tile) + lane;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) q[(pl * 2 + s) * 64] = v.p[pl][s];
+}
+__device__ __forceinline__ f32x16 x2_mma(const X2& A, const X2& B, f32x16 acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        acc = GATOR_MFMA_F16(A.p[1][s], B.p[0][s], acc);      // lo*hi
+        acc = GATOR_MFMA_F16(A.p[0][s], B.p[1][s], acc);      // hi*lo
+        acc = GATOR_MFMA_F16(A.p[0][s], B.p[0][s], acc);      // hi*hi
+    }
+    return acc;
+}
+
 // fused_pack.hip: fp32 packed tiles [g][lane][4] -> X3 tiles, same tile indices
 int fused_repack_x3(const float* src_tiles, float* dst_tiles, int64_t ntiles, void* stream);
 
