@@ -34,7 +34,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
                  o_q = take(3 * tiles), o_k = take(3 * tiles), o_v = take(3 * tiles) /* q/k/v sized for X3 tiles (1.5x) */, o_jkv = take((size_t)cap * 12 * kTile),
                  o_hf = take((size_t)cap * kV * 32), o_lbf = take((size_t)cap * kV * kE), o_feat = take((size_t)cap * J * kC),
                  o_xout = take((size_t)cap * J * 3), o_pc = take((size_t)cap * J * 133),
-                 o_vcp3 = take(upsample_x3_vcp_elems(cap) / 2);
+                 o_vcp3 = take(upsample_x3_vcp_elems(cap) / 2), o_lpart = take(gat_tail_part_floats(cap, J));
     GATOR_HIP_CHECK(hipMalloc(&f->ws, n * sizeof(float)));
     GATOR_HIP_CHECK(hipMemset(f->ws, 0, n * sizeof(float)));
     GATOR_HIP_CHECK(hipDeviceSynchronize());      // the memset runs on the null stream; a non-blocking stream would not wait for it
@@ -42,7 +42,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
     f->cap = cap;
     f->vcp = f->ws + o_vcp; f->vc = f->ws + o_vc; f->vf = f->ws + o_vf; f->q = f->ws + o_q; f->k = f->ws + o_k;
     f->v = f->ws + o_v; f->jkv = f->ws + o_jkv; f->hf = f->ws + o_hf; f->lbf = f->ws + o_lbf; f->feat = f->ws + o_feat;
-    f->xout = f->ws + o_xout; f->pc = f->ws + o_pc; f->vcp3 = f->ws + o_vcp3;
+    f->xout = f->ws + o_xout; f->pc = f->ws + o_pc; f->vcp3 = f->ws + o_vcp3; f->lpart = f->ws + o_lpart;
     return GATOR_OK;
 }
 
@@ -118,6 +118,8 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
     {   // split-precision image of every block's weight grids (the tables mc/md/aoffT/f1b in between are converted too, unused)
         const char* e = getenv("GATOR_GAT_X3");
         f->gat_x3 = !(e && atoi(e) == 0);
+        const char* te = getenv("GATOR_GAT_TAIL");
+        f->gat_split_tail = !(te && atoi(te) == 0);
         if (f->gat_x3) {
             const int64_t ntiles = (p - f->gblk[0].qkv) / kTile;
             GATOR_HIP_CHECK(hipMalloc(&f->gxbuf, (size_t)ntiles * kTileX3 * sizeof(float)));
@@ -439,6 +441,11 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
         rc = launch_gat(c, f, pose2d, B, pose3d, f->feat, stream, true);
     }
     if (rc) return rc;
+    if (f->gat_split_tail) {   // lifter + MDR joint tokens as two batched launches (gat_tail.hip)
+        StageTimer tm(c, "gat_tail", stream);
+        rc = launch_gat_tail(c, f, pose2d, f->feat, B, pose3d, stream, true);
+        if (rc) return rc;
+    }
     c->set_tap(TAP_FEAT, f->feat, (int64_t)B * c->J * kC);
     rc = launch_mdr(c, f, nullptr, B, stream, pose3d, pose2d);      // pose_combine is never materialised on this path
     if (rc) return rc;

@@ -33,6 +33,7 @@ struct FusedWs {
     float *hf = nullptr;                // [B][431][32] head features
     float *lbf = nullptr;               // [B][431][64] tap: verts tokens after LBF3 (reference layout)
     float *feat = nullptr, *xout = nullptr, *pc = nullptr;
+    float *lpart = nullptr;             // [MT][J][2][kTile] lifter partial tiles (gat_tail.hip)
     void* vcp16 = nullptr;              // bf16 packed vert431 for the bf16 vertex GEMM (cap-sized)
     int vcp16_cap = 0;
 };
@@ -46,6 +47,7 @@ struct FusedState : FusedWs {
     // upsample: Wp[tap][ob][cb][4][64][4]
     const float* up_w = nullptr;
     void* up_w3 = nullptr;              // bf16 [plane 3][tap][ob][28][64][8]  hi/mid/lo split of upsample_conv.weight
+    bool gat_split_tail = true;         // full forward: lifter + joint tokens as batched launches (GATOR_GAT_TAIL=0: inside k_gat)
     bool gat_x3 = true;                 // GAT linears on split-precision bf16 MFMA (GATOR_GAT_X3=0: fp32-input MFMA)
     float* gxbuf = nullptr;             // X3 tiles of the GAT block weights, tile-for-tile image of gbuf from gblk[0].qkv on
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
@@ -79,6 +81,9 @@ int launch_upsample(const FusedState* f, const gator_ctx* c, int B, float* verts
 // gat_fused.hip
 int gat_prepare_device();
 int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue = false);
+// gat_tail.hip
+size_t gat_tail_part_floats(int B, int J);
+int launch_gat_tail(gator_ctx* c, FusedState* f, const float* pose2d, const float* feat, int B, float* x_out, void* stream, bool joint);
 // upsample_bf16.hip
 size_t upsample_bf16_weight_elems();
 size_t upsample_bf16_vcp_elems(int B);

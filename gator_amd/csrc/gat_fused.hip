@@ -192,7 +192,8 @@ __device__ __forceinline__ f32x16 lin4l(Grp<true>& g, const float* T, int lane, 
     return init;
 }
 
-template <bool X3K>
+// TAIL = false: the kernel ends with `feat`; the lifter and the MDR joint tokens run as batched launches (gat_tail.hip)
+template <bool X3K, bool TAIL>
 __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* X = lds;                       // residual stream, 4 tiles (T-layout)
@@ -493,6 +494,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             }
         }
     }
+    if constexpr (!TAIL) return;
     float* XO = R + 6 * kTile;            // x_out of this sample (3J floats), for the joint-token epilogue
     GAT_STAMP(18)
     // lifter (GAT.py:151-152): x_out[o] = <feat flattened [J*128], W[o]> + b[o].  The weight rows are read as the reference
@@ -637,8 +639,10 @@ constexpr size_t kGatLdsX3 = (4 * kTile + 16 * kTileX3 + 2048) * sizeof(float); 
 // Dynamic-LDS opt-in of the kernels, per DEVICE: called from fused_create_gat with the ctx's device current (a function
 // attribute set on one device does not carry to another, and a process may hold contexts on several).
 int gat_prepare_device() {
-    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGatLds));
-    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGatLdsX3));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGatLds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGatLdsX3));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGatLds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGatLdsX3));
     return GATOR_OK;
 }
 
@@ -687,9 +691,16 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         a.stamps = d_st;
     }
 #endif
-    if (f->gat_x3) k_gat<true><<<B, 256, kGatLdsX3, (hipStream_t)stream>>>(a);
-    else k_gat<false><<<B, 256, kGatLds, (hipStream_t)stream>>>(a);
+    const bool split_tail = joint_epilogue && f->gat_split_tail;
+    if (split_tail) {
+        if (f->gat_x3) k_gat<true, false><<<B, 256, kGatLdsX3, (hipStream_t)stream>>>(a);
+        else k_gat<false, false><<<B, 256, kGatLds, (hipStream_t)stream>>>(a);
+    } else {
+        if (f->gat_x3) k_gat<true, true><<<B, 256, kGatLdsX3, (hipStream_t)stream>>>(a);
+        else k_gat<false, true><<<B, 256, kGatLds, (hipStream_t)stream>>>(a);
+    }
     GATOR_HIP_CHECK(hipGetLastError());
+
 #ifdef GATOR_DIAG
     if (d_st) {     // diagnostic build: synchronous read-back
         unsigned long long hst[20];
