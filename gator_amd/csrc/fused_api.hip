@@ -164,7 +164,14 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
     // (the lifter reads the reference weight [3J][128J] as it is, gat_fused.hip)
     {
         int rc = gat_prepare_device();
+        if (rc == GATOR_OK) rc = gat_tiled_prepare_device();
         if (rc) return rc;
+        const char* tl = getenv("GATOR_GAT_TILED");
+        f->gat_tiled = tl ? atoi(tl) : -1;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) f->n_cu = prop.multiProcessorCount;
+        const char* tm = getenv("GATOR_GAT_TILED_MIN_BATCH");
+        if (tm && atoi(tm) > 0) f->gat_tiled_min_batch = atoi(tm);
     }
     GATOR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     GATOR_HIP_CHECK(hipGetLastError());
@@ -436,12 +443,33 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
     int rc = fused_ensure_ws(c, B);
     if (rc) return rc;
     FusedState* f = c->fused;
-    {   // x_out [B,3J] IS pose3d [B,J,3]: the kernel writes the caller's buffer; its epilogue also produces the MDR joint K/V
+    // Encoder.  k_gat gives every sample a workgroup (one round of it = one sample per CU); the sample-tiled kernel packs S samples
+    // per workgroup (dense token tiles, weights fetched once per workgroup) and one round of it (n_cu workgroups) costs about as
+    // much as 3.8 rounds of k_gat but covers S = 7 (J=17) or 6 (J=19) times the samples.  So a large batch runs as many FULL
+    // tiled rounds as fit, and the remainder on whichever is cheaper: k_gat if it needs at most 3 rounds, the tiled kernel else.
+    // Within one kernel results are bit-identical whatever the batch; between the two they agree to fp32 rounding noise
+    // (tests/test_gpu_tiled.py), so above the threshold a sample's last bits depend on the batch size and its position in it.
+    // GATOR_GAT_TILED=0 keeps every batch on k_gat (bitwise batch invariance at any size), =1 forces the tiled kernel.
+    int n_tiled = 0;
+    if (f->gat_x3 && f->gat_tiled != 0) {
+        if (f->gat_tiled == 1) n_tiled = B;
+        else if (B >= f->gat_tiled_min_batch) {
+            const int round = f->n_cu * gat_tiled_samples_per_wg(c->J);
+            n_tiled = (B / round) * round;
+            if (B - n_tiled > 3 * f->n_cu) n_tiled = B;
+        }
+    }
+    const bool tiled = n_tiled > 0;
+    {   // x_out [B,3J] IS pose3d [B,J,3]: the tail writes the caller's buffer and produces the MDR joint K/V
         StageTimer tm(c, "gat", stream);
-        rc = launch_gat(c, f, pose2d, B, pose3d, f->feat, stream, true);
+        if (n_tiled > 0) rc = launch_gat_tiled(c, f, pose2d, n_tiled, f->feat, stream, B);
+        if (rc == GATOR_OK && n_tiled < B) {
+            const size_t o = (size_t)n_tiled * c->J;
+            rc = launch_gat(c, f, pose2d + o * 2, B - n_tiled, pose3d + o * 3, f->feat + o * kC, stream, true, B, n_tiled);
+        }
     }
     if (rc) return rc;
-    if (f->gat_split_tail) {   // lifter + MDR joint tokens as two batched launches (gat_tail.hip)
+    if (f->gat_split_tail || tiled) {   // lifter + MDR joint tokens as two batched launches (gat_tail.hip)
         StageTimer tm(c, "gat_tail", stream);
         rc = launch_gat_tail(c, f, pose2d, f->feat, B, pose3d, stream, true);
         if (rc) return rc;

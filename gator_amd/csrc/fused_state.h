@@ -47,6 +47,9 @@ struct FusedState : FusedWs {
     // upsample: Wp[tap][ob][cb][4][64][4]
     const float* up_w = nullptr;
     void* up_w3 = nullptr;              // bf16 [plane 3][tap][ob][28][64][8]  hi/mid/lo split of upsample_conv.weight
+    int gat_tiled = -1;                 // GATOR_GAT_TILED: 0 never, 1 always, -1 (default): by batch size, see fused_forward_one
+    int gat_tiled_min_batch = 1024;
+    int n_cu = 256;                     // compute units of the ctx's device
     bool gat_split_tail = true;         // full forward: lifter + joint tokens as batched launches (GATOR_GAT_TAIL=0: inside k_gat)
     bool gat_x3 = true;                 // GAT linears on split-precision bf16 MFMA (GATOR_GAT_X3=0: fp32-input MFMA)
     float* gxbuf = nullptr;             // X3 tiles of the GAT block weights, tile-for-tile image of gbuf from gblk[0].qkv on
@@ -80,7 +83,13 @@ int launch_pack_vc(const float* vc, int B, float* vcp, void* stream);
 int launch_upsample(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream);
 // gat_fused.hip
 int gat_prepare_device();
-int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue = false);
+int gat_ensure_blk_tap(gator_ctx* c, FusedState* f, int B);
+int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue = false,
+               int B_total = 0, int tap_row0 = 0);
+// gat_tiled.hip
+int gat_tiled_prepare_device();
+int gat_tiled_samples_per_wg(int J);
+int launch_gat_tiled(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total = 0);
 // gat_tail.hip
 size_t gat_tail_part_floats(int B, int J);
 int launch_gat_tail(gator_ctx* c, FusedState* f, const float* pose2d, const float* feat, int B, float* x_out, void* stream, bool joint);

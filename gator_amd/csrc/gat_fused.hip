@@ -39,6 +39,7 @@ struct GatArgs {
     float* jkv;
     const float *jf5, *jf_p, *jf_b, *posj_T;       // get_joint_feature: columns 0..4 as [5][64], columns 5..132 packed [2][4], bias
     const float *j_n1w[3], *j_n1b[3], *j_wk_p[3], *j_wv_p[3];
+    int tapB;                       // batch stride of blk_tap (the whole batch of the call)
     float* blk_tap;                 // gator_enable_block_taps: residual stream after every GATBlock, [depth][B][J][128] (else nullptr)
 #ifdef GATOR_DIAG
     unsigned long long* stamps;     // diagnostic build only (libgator_hip_diag.so): per-phase cycle sums of workgroup 0, wave 0
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             xw += (c0 + c1) + (c2 + c3);
             store_block(X + wave * kTile, lane, xw);     // every wave finished reading X (LN2) before the HB barrier
             if (a.blk_tap && (lane & 31) < J) {          // debug tap (off in timed runs): this wave's channel block of the block output
-                float* dst = a.blk_tap + (((size_t)bi * a.B + b) * J + (lane & 31)) * kC + 32 * wave + 4 * h;
+                float* dst = a.blk_tap + (((size_t)bi * a.tapB + b) * J + (lane & 31)) * kC + 32 * wave + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v4;
@@ -646,7 +647,19 @@ int gat_prepare_device() {
     return GATOR_OK;
 }
 
-int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue) {
+// debug buffer of the per-block taps, [depth][B][J][128], allocated on first use only
+int gat_ensure_blk_tap(gator_ctx* c, FusedState* f, int B) {
+    if (B > f->blk_tap_cap) {
+        if (f->blk_tap) { GATOR_HIP_CHECK(hipDeviceSynchronize()); GATOR_HIP_CHECK(hipFree(f->blk_tap)); f->blk_tap = nullptr; }
+        GATOR_HIP_CHECK(hipMalloc(&f->blk_tap, (size_t)kDepth * B * c->J * kC * sizeof(float)));
+        f->blk_tap_cap = B;
+    }
+    c->set_tap(TAP_GAT_BLOCKS, f->blk_tap, (int64_t)kDepth * B * c->J * kC);
+    return GATOR_OK;
+}
+
+int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue,
+               int B_total, int tap_row0) {
     GatArgs a;
     const Weights& w = c->w;
     a.B = B; a.J = c->J; a.pose2d = pose2d;
@@ -673,14 +686,13 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         for (int i = 0; i < 3; ++i) { a.j_n1w[i] = w.lay[i].n1w; a.j_n1b[i] = w.lay[i].n1b; a.j_wk_p[i] = f->lay[i].wk; a.j_wv_p[i] = f->lay[i].wv; }
     }
     a.blk_tap = nullptr;
+    a.tapB = B;
     if (c->block_taps) {
-        if (B > f->blk_tap_cap) {       // debug buffer, allocated on first use only
-            if (f->blk_tap) { GATOR_HIP_CHECK(hipDeviceSynchronize()); GATOR_HIP_CHECK(hipFree(f->blk_tap)); f->blk_tap = nullptr; }
-            GATOR_HIP_CHECK(hipMalloc(&f->blk_tap, (size_t)kDepth * B * c->J * kC * sizeof(float)));
-            f->blk_tap_cap = B;
-        }
-        a.blk_tap = f->blk_tap;
-        c->set_tap(TAP_GAT_BLOCKS, f->blk_tap, (int64_t)kDepth * B * c->J * kC);
+        const int Bt = B_total > 0 ? B_total : B;
+        int rc = gat_ensure_blk_tap(c, f, Bt);
+        if (rc) return rc;
+        a.blk_tap = f->blk_tap + (size_t)tap_row0 * c->J * kC;      // this launch's samples start at row tap_row0 of the batch
+        a.tapB = Bt;
     }
 #ifdef GATOR_DIAG
     a.stamps = nullptr;
@@ -691,7 +703,9 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         a.stamps = d_st;
     }
 #endif
-    const bool split_tail = joint_epilogue && f->gat_split_tail;
+    // (a launch that covers only part of a batch -- the remainder behind the sample-tiled kernel -- always leaves the tail to the
+    // batched launches, which then run once over the whole batch)
+    const bool split_tail = joint_epilogue && (f->gat_split_tail || (B_total > 0 && B_total != B));
     if (split_tail) {
         if (f->gat_x3) k_gat<true, false><<<B, 256, kGatLdsX3, (hipStream_t)stream>>>(a);
         else k_gat<false, false><<<B, 256, kGatLds, (hipStream_t)stream>>>(a);

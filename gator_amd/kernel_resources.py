@@ -7,7 +7,7 @@ import sys
 
 # kernels of the DEFAULT timed path (split-precision forms): any scratch (spilled registers) here is a build error.  The
 # fp32-input-MFMA forms behind the GATOR_*_X3=0 switches (k_gat<false>, k_mdr_layer<*, 0>) and the all-bf16x3 form (k_mdr_layer<*, 1>) are A/B variants, not checked.
-HOT = ('k_gat<true', 'k_gat_tiled<', 'k_gat_lifter', 'k_gat_joint', 'k_mdr_layer<0, 2>', 'k_mdr_layer<1, 2>', 'k_mdr_layer<2, 2>', 'k_mdr_head<',
+HOT = ('k_gat<true', 'k_gat_lifter', 'k_gat_joint', 'k_mdr_layer<0, 2>', 'k_mdr_layer<1, 2>', 'k_mdr_layer<2, 2>', 'k_mdr_head<',
        'k_upsample_x3', 'k_upsample_bf16', 'k_regress')
 _FIELD = re.compile(r'remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)')
 _NAME = re.compile(r'remark:\s+Function Name: (\S+)')
