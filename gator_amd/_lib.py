@@ -38,6 +38,8 @@ SIGNATURES = {
     'gator_profile_enable': (_I, [_P, _I]),
     'gator_profile_read': (_I, [_P, ctypes.c_char_p, _L, _P, _P, _I, _P]),
     'gator_regress_joints_f32': (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P]),
+    'gator_set_joint_regressor': (_I, [_P, _P, _P, _P, _I, _I]),
+    'gator_forward_joints_f32': (_I, [_P, _P, _I, _P, _P, _P, _P]),
     'gator_preprocess_pose2d_f32': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'gator_rigid_align_f32': (_I, [_P, _P, _I, _I, _P, _P]),
     'gator_floyd_warshall': (_I, [_P, _I, _P, _P]),

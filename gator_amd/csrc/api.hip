@@ -373,6 +373,24 @@ extern "C" int gator_profile_read(gator_ctx* c, char* names, int64_t cap, float*
     return GATOR_OK;
 }
 
+extern "C" int gator_set_joint_regressor(gator_ctx* c, const int32_t* coo_row, const int32_t* coo_col, const float* coo_val, int32_t nnz,
+                                         int32_t n_joint) {
+    if (!c || !coo_row || !coo_col || !coo_val || nnz <= 0 || n_joint <= 0) return fail(GATOR_EINVAL, "gator_set_joint_regressor: bad arguments");
+    if (c->impl != GATOR_IMPL_FUSED || !(c->parts & GATOR_PART_MDR)) return fail(GATOR_EUNSUPPORTED, "gator_set_joint_regressor: fused ctx with the MDR weights only");
+    GATOR_HIP_CHECK(hipSetDevice(c->device));
+    return fused_set_joint_regressor(c, coo_row, coo_col, coo_val, nnz, n_joint);
+}
+
+extern "C" int gator_forward_joints_f32(gator_ctx* c, const float* pose2d, int32_t B, float* joints, float* pose3d, float* verts, void* stream) {
+    int rc = check_fwd(c, pose2d, joints, B, "gator_forward_joints_f32");
+    if (rc) return rc;
+    if (!pose3d) return fail(GATOR_EINVAL, "gator_forward_joints_f32: pose3d is null");
+    if (c->parts != (GATOR_PART_GAT | GATOR_PART_MDR) || c->impl != GATOR_IMPL_FUSED)
+        return fail(GATOR_EUNSUPPORTED, "gator_forward_joints_f32: needs a fused ctx with both GAT and MDR weights");
+    c->last_batch = B;
+    return fused_forward_joints(c, pose2d, B, joints, pose3d, verts, stream);
+}
+
 extern "C" int gator_forward_bf16(gator_ctx* c, const float* pose2d, int32_t B, float* verts, float* pose3d, void* stream) {
     int rc = check_fwd(c, pose2d, verts, B, "gator_forward_bf16");
     if (rc) return rc;

@@ -1,6 +1,7 @@
 // Fused path: create-time packing, workspace, and stage dispatch.  No fallback to anything but HIP kernels.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -329,6 +330,8 @@ void fused_destroy(gator_ctx* c) {
     if (c->fused->wxbuf) (void)hipFree(c->fused->wxbuf);
     if (c->fused->up_w16) (void)hipFree(c->fused->up_w16);
     if (c->fused->blk_tap) (void)hipFree(c->fused->blk_tap);
+    for (void* p : {c->fused->jr_blk, c->fused->jr_ent, (void*)c->fused->jr_w, (void*)c->fused->jr_rowptr, (void*)c->fused->jr_P})
+        if (p) (void)hipFree(p);
     if (c->fused->up_w3) (void)hipFree(c->fused->up_w3);
     delete c->fused;
     c->fused = nullptr;
@@ -401,7 +404,7 @@ int fused_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* 
     return fused_mdr_forward_impl(c, pc, B, verts, stream, false);
 }
 
-static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream, bool bf16);
+static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream, bool bf16, float* joints = nullptr);
 
 // Sub-batch pipelining: with >= 2 x 64 samples the batch runs as two halves on two streams (fork/join by events, so the
 // caller's stream semantics are unchanged and the pattern is graph-capturable).  Samples are independent and every kernel
@@ -439,7 +442,7 @@ int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float*
     return rc;
 }
 
-static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream, bool bf16) {
+static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream, bool bf16, float* joints) {
     int rc = fused_ensure_ws(c, B);
     if (rc) return rc;
     FusedState* f = c->fused;
@@ -477,9 +480,72 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
     c->set_tap(TAP_FEAT, f->feat, (int64_t)B * c->J * kC);
     rc = launch_mdr(c, f, nullptr, B, stream, pose3d, pose2d);      // pose_combine is never materialised on this path
     if (rc) return rc;
+    if (joints) {      // vertex GEMM with the joint-regression epilogue (verts may be null: nothing of 82 kB/mesh is stored)
+        if (!f->x3 || bf16) return fail(GATOR_EUNSUPPORTED, "gator_forward_joints_f32 needs the split-precision vertex regressor");
+        if (B > f->jr_cap) {
+            if (f->jr_P) { GATOR_HIP_CHECK(hipDeviceSynchronize()); GATOR_HIP_CHECK(hipFree(f->jr_P)); f->jr_P = nullptr; }
+            GATOR_HIP_CHECK(hipMalloc(&f->jr_P, (size_t)B * f->jr_nnz * 3 * sizeof(float)));
+            f->jr_cap = B;
+        }
+        { StageTimer tm(c, "upsample", stream); rc = launch_upsample_x3(f, c, B, verts, stream, true); }
+        if (rc) return rc;
+        StageTimer tm(c, "jreg_reduce", stream);
+        return launch_jreg_reduce(f, B, joints, stream);
+    }
     if (bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);
     StageTimer tm(c, "upsample", stream);
     return f->x3 ? launch_upsample_x3(f, c, B, verts, stream) : launch_upsample(f, c, B, verts, stream);
+}
+
+// Register a sparse [nj, 6890] joint regressor (COO, host or device pointers are both read through hipMemcpy) for the fused epilogue
+int fused_set_joint_regressor(gator_ctx* c, const int32_t* row, const int32_t* col, const float* val, int nnz, int nj) {
+    FusedState* f = c->fused;
+    if (!f) return fail(GATOR_EUNSUPPORTED, "gator_set_joint_regressor: fused ctx only");
+    std::vector<int32_t> r(nnz), cc(nnz);
+    std::vector<float> v(nnz);
+    GATOR_HIP_CHECK(hipMemcpy(r.data(), row, nnz * sizeof(int32_t), hipMemcpyDefault));
+    GATOR_HIP_CHECK(hipMemcpy(cc.data(), col, nnz * sizeof(int32_t), hipMemcpyDefault));
+    GATOR_HIP_CHECK(hipMemcpy(v.data(), val, nnz * sizeof(float), hipMemcpyDefault));
+    for (int e = 0; e < nnz; ++e)
+        if (r[e] < 0 || r[e] >= nj || cc[e] < 0 || cc[e] >= kNV) return fail(GATOR_EINVAL, "gator_set_joint_regressor: entry %d out of range", e);
+    // slots: sorted by (joint, vertex) -> CSR; epilogue entries: sorted by vertex, grouped by 32-vertex block
+    std::vector<int> order(nnz);
+    for (int e = 0; e < nnz; ++e) order[e] = e;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return r[a] != r[b] ? r[a] < r[b] : cc[a] < cc[b]; });
+    std::vector<int> slot_of(nnz), rowptr(nj + 1, 0);
+    for (int s = 0; s < nnz; ++s) { slot_of[order[s]] = s; rowptr[r[order[s]] + 1]++; }
+    for (int j = 0; j < nj; ++j) rowptr[j + 1] += rowptr[j];
+    std::vector<int> byv(nnz);
+    for (int e = 0; e < nnz; ++e) byv[e] = e;
+    std::stable_sort(byv.begin(), byv.end(), [&](int a, int b) { return cc[a] < cc[b]; });
+    std::vector<int32_t> ent(2 * nnz), blk(2 * kOB, 0);
+    std::vector<float> w(nnz);
+    for (int i = 0; i < nnz; ++i) {
+        const int e = byv[i], ob = cc[e] / 32;
+        ent[2 * i] = cc[e]; ent[2 * i + 1] = slot_of[e]; w[i] = v[e];
+        if (blk[2 * ob + 1] == 0) blk[2 * ob] = i;
+        blk[2 * ob + 1]++;
+    }
+    for (void* p : {f->jr_blk, f->jr_ent, (void*)f->jr_w, (void*)f->jr_rowptr, (void*)f->jr_P})
+        if (p) { GATOR_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(p); }
+    f->jr_P = nullptr; f->jr_cap = 0;
+    GATOR_HIP_CHECK(hipMalloc(&f->jr_blk, blk.size() * 4));
+    GATOR_HIP_CHECK(hipMalloc(&f->jr_ent, ent.size() * 4));
+    GATOR_HIP_CHECK(hipMalloc(&f->jr_w, w.size() * 4));
+    GATOR_HIP_CHECK(hipMalloc(&f->jr_rowptr, rowptr.size() * 4));
+    GATOR_HIP_CHECK(hipMemcpy(f->jr_blk, blk.data(), blk.size() * 4, hipMemcpyHostToDevice));
+    GATOR_HIP_CHECK(hipMemcpy(f->jr_ent, ent.data(), ent.size() * 4, hipMemcpyHostToDevice));
+    GATOR_HIP_CHECK(hipMemcpy(f->jr_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    GATOR_HIP_CHECK(hipMemcpy(f->jr_rowptr, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice));
+    f->jr_nnz = nnz; f->jr_nj = nj;
+    return GATOR_OK;
+}
+
+int fused_forward_joints(gator_ctx* c, const float* pose2d, int B, float* joints, float* pose3d, float* verts, void* stream) {
+    FusedState* f = c->fused;
+    if (!f || f->jr_nnz == 0) return fail(GATOR_EINVAL, "gator_forward_joints_f32: call gator_set_joint_regressor first");
+    WsScope ws(f, 0);
+    return fused_forward_one(c, pose2d, B, verts, pose3d, stream, false, joints);
 }
 
 }  // namespace gator

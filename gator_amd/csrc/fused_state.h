@@ -57,6 +57,12 @@ struct FusedState : FusedWs {
     int mdr_x3 = 2;                     // GATOR_MDR_X3: 0 fp32-input MFMA; 1 exact bf16 x 3 split everywhere; 2 (default) that + the 431x431 attention on two fp16 planes
     bool x3 = true;                     // split-precision vertex regressor (GATOR_UPSAMPLE_X3=0: fp32-input MFMA kernel)
     void* up_w16 = nullptr;             // bf16 [tap][ob][28][64][8] (packed on the first bf16 call, which waits for the pack)
+    // joint regressor fused into the vertex GEMM's epilogue (gator_set_joint_regressor / gator_forward_joints_f32)
+    void *jr_blk = nullptr, *jr_ent = nullptr;    // int2 [kOB] (first, count) ; int2 [nnz] (vertex, slot)
+    float* jr_w = nullptr;                        // [nnz] weights in entry order
+    int* jr_rowptr = nullptr;                     // [nj + 1] CSR row pointers over the slots (sorted by joint, then vertex)
+    float* jr_P = nullptr;                        // [cap][nnz][3] partial products
+    int jr_nnz = 0, jr_nj = 0, jr_cap = 0;
     float* blk_tap = nullptr;           // debug: residual stream after every GATBlock [depth][B][J][128] (gator_enable_block_taps)
     int blk_tap_cap = 0;
     // MDR
@@ -103,7 +109,8 @@ size_t upsample_x3_weight_elems();
 size_t upsample_x3_vcp_elems(int B);
 int pack_upsample_x3(const float* up_w, void* dst, void* stream);
 int launch_pack_vc_x3(const float* vc, int B, int cap, void* vcp3, void* stream);
-int launch_upsample_x3(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream);
+int launch_upsample_x3(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints = false);
+int launch_jreg_reduce(const FusedState* f, int B, float* joints, void* stream);
 // mdr_fused.hip
 int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream, const float* x_out = nullptr, const float* pose2d = nullptr);
 

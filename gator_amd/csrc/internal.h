@@ -113,6 +113,8 @@ int fused_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* 
 int fused_upsample(gator_ctx* c, const float* vert431, int B, float* verts, void* stream);
 int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream, bool bf16 = false);
 int fused_upsample_bf16(gator_ctx* c, const float* vert431, int B, float* verts, void* stream);
+int fused_set_joint_regressor(gator_ctx* c, const int32_t* row, const int32_t* col, const float* val, int nnz, int nj);
+int fused_forward_joints(gator_ctx* c, const float* pose2d, int B, float* joints, float* pose3d, float* verts, void* stream);
 }  // namespace gator
 
 namespace gator {

@@ -60,11 +60,22 @@ struct __attribute__((packed)) F3 { float x, y, z; };
 // the loader wave four k-steps ahead into a register ring and handed to the compute waves through a double-buffered LDS
 // stage: its vmcnt queue is its own, so the compute waves' (L2-resident) activation prefetch never queues behind an
 // HBM miss (vmcnt retires in order).  Each compute wave register-prefetches its 9 activation fragments one step ahead.
+// Joint-regression epilogue (lib/core/base.py:221, demo/run.py:142: joints = J_regressor @ mesh, a 107-nnz matrix): a wave that
+// has just formed vertex v of its samples also writes w_e * v for every regressor entry e = (joint, v, w_e) of its 32-vertex
+// block into P[sample][e][xyz]; k_jreg_reduce sums each joint's entries in a fixed order.  No atomics, no second pass over the
+// 82 kB/mesh of vertices -- and with `out` == nullptr the vertices are never written at all (evaluation needs the joints only).
+struct JregEpi {
+    const int2* blk;            // [kOB] (first entry, entry count) of every 32-vertex block, entries sorted by vertex
+    const int2* ent;            // (vertex, slot in P) per entry
+    const float* w;             // weight per entry
+    float* P;                   // [B][nnz][3]
+    int nnz;
+};
 constexpr int kX3Waves = 8, kX3Ring = 4;
 __global__ __launch_bounds__(64 * (kX3Waves + 1), 1) void k_upsample_x3(const __bf16* __restrict__ vcp, const __bf16* __restrict__ wp,
                                                                        const float* __restrict__ bias, const float* __restrict__ tpl,
                                                                        float* __restrict__ out, int B, int MT, int nwg, int64_t a_plane,
-                                                                       int64_t w_plane) {
+                                                                       int64_t w_plane, const JregEpi jr) {
     __shared__ bf16x8 wl[2][9][64];
     __shared__ f32x4 tot[kX3Waves][12][64];       // running totals of the hi*hi chains, see the flush below (96 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -176,6 +187,7 @@ __global__ __launch_bounds__(64 * (kX3Waves + 1), 1) void k_upsample_x3(const __
     if (ov >= kNV || !live) return;
     const float bo = bias[ov];
     const float t0 = tpl[ov * 3], t1 = tpl[ov * 3 + 1], t2 = tpl[ov * 3 + 2];
+    const int2 jb = jr.P ? jr.blk[ob] : int2{0, 0};           // regressor entries of this vertex block (most blocks have none)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int smp = 32 * mt + kap(r) + 4 * h;
@@ -184,9 +196,29 @@ __global__ __launch_bounds__(64 * (kX3Waves + 1), 1) void k_upsample_x3(const __
             v.x = ((big[0][r] + sm[0][r]) + bo) + t0;
             v.y = ((big[1][r] + sm[1][r]) + bo) + t1;
             v.z = ((big[2][r] + sm[2][r]) + bo) + t2;
-            *reinterpret_cast<F3*>(out + ((int64_t)smp * kNV + ov) * 3) = v;
+            if (out) *reinterpret_cast<F3*>(out + ((int64_t)smp * kNV + ov) * 3) = v;
+            for (int e = jb.x; e < jb.x + jb.y; ++e) {
+                const int2 en = jr.ent[e];
+                if (en.x == ov) {
+                    const float we = jr.w[e];
+                    F3 q;
+                    q.x = we * v.x; q.y = we * v.y; q.z = we * v.z;
+                    *reinterpret_cast<F3*>(jr.P + ((int64_t)smp * jr.nnz + en.y) * 3) = q;
+                }
+            }
         }
     }
+}
+
+// joints[b][j][c] = sum of joint j's entries of P[b], ascending vertex order, accumulated in fp64
+__global__ void k_jreg_reduce(const float* __restrict__ P, const int* __restrict__ row_ptr, int nnz, int nj, int B, float* __restrict__ joints) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * nj * 3) return;
+    const int c = (int)(i % 3), j = (int)((i / 3) % nj);
+    const int64_t b = i / (3 * nj);
+    double acc = 0.0;
+    for (int e = row_ptr[j]; e < row_ptr[j + 1]; ++e) acc += (double)P[(b * nnz + e) * 3 + c];
+    joints[i] = (float)acc;
 }
 
 }  // namespace
@@ -209,12 +241,22 @@ int launch_pack_vc_x3(const float* vc, int B, int cap, void* vcp3, void* stream)
     return GATOR_OK;
 }
 
-int launch_upsample_x3(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream) {
+int launch_jreg_reduce(const FusedState* f, int B, float* joints, void* stream) {
+    const int64_t n = (int64_t)B * f->jr_nj * 3;
+    k_jreg_reduce<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(f->jr_P, f->jr_rowptr, f->jr_nnz, f->jr_nj, B, joints);
+    GATOR_HIP_CHECK(hipGetLastError());
+    return GATOR_OK;
+}
+
+// verts == nullptr: vertices are not stored (joint regression only); with_joints: also fill f->jr_P for launch_jreg_reduce
+int launch_upsample_x3(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints) {
     const int MT = (B + 31) / 32;
+    JregEpi jr{};
+    if (with_joints) { jr.blk = (const int2*)f->jr_blk; jr.ent = (const int2*)f->jr_ent; jr.w = f->jr_w; jr.P = f->jr_P; jr.nnz = f->jr_nnz; }
     const int64_t w_plane = (int64_t)upsample_x3_weight_elems() / 3, a_plane = (int64_t)upsample_x3_vcp_elems(f->cap) / 3;
     const int nwg = kOB * ((MT + kX3Waves - 1) / kX3Waves);
     k_upsample_x3<<<nwg, 64 * (kX3Waves + 1), 0, (hipStream_t)stream>>>((const __bf16*)f->vcp3, (const __bf16*)f->up_w3, c->w.up_b,
-                                                                       c->w.v6890, verts, B, MT, nwg, a_plane, w_plane);
+                                                                       c->w.v6890, verts, B, MT, nwg, a_plane, w_plane, jr);
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;
 }

@@ -38,5 +38,35 @@ class GATOR(HipModule):
         return verts, pose3d
 
 
+    def set_joint_regressor(self, dense):
+        """Register a [n_joint, 6890] joint regressor (lib/core/base.py:221, demo/run.py:142) for forward_joints()."""
+        import numpy as np
+        d = np.asarray(dense, np.float32)
+        r, c = np.nonzero(d)
+        self._jreg = (np.ascontiguousarray(r.astype(np.int32)), np.ascontiguousarray(c.astype(np.int32)),
+                      np.ascontiguousarray(d[r, c].astype(np.float32)), int(d.shape[0]))
+        self._jreg_ctx = None
+
+    def forward_joints(self, pose2d, with_verts=False):
+        """GATOR.forward + J_regressor @ mesh fused (gator_forward_joints_f32): -> (joints [B,n_joint,3] metres, pose3d [B,J,3] mm
+        [, verts]).  Without `with_verts` no vertex is written at all."""
+        if getattr(self, '_jreg', None) is None:
+            raise RuntimeError('call set_joint_regressor() first')
+        x = self._prep(pose2d, 'GATOR.forward_joints')
+        B = x.shape[0]
+        ctx = self._context(x.device)
+        lib = _lib.load()
+        r, c, v, nj = self._jreg
+        if getattr(self, '_jreg_ctx', None) != ctx.value:
+            _lib.check(lib.gator_set_joint_regressor(ctx, r.ctypes.data, c.ctypes.data, v.ctypes.data, int(r.size), nj), 'gator_set_joint_regressor')
+            self._jreg_ctx = ctx.value
+        joints = torch.empty((B, nj, 3), device=x.device, dtype=torch.float32)
+        pose3d = torch.empty((B, self.num_joint, 3), device=x.device, dtype=torch.float32)
+        verts = torch.empty((B, 6890, 3), device=x.device, dtype=torch.float32) if with_verts else None
+        _lib.check(lib.gator_forward_joints_f32(ctx, x.data_ptr(), B, joints.data_ptr(), pose3d.data_ptr(),
+                                                verts.data_ptr() if with_verts else None, self._stream(x.device)), 'gator_forward_joints_f32')
+        return (joints, pose3d, verts) if with_verts else (joints, pose3d)
+
+
 def get_model(num_joint, embed_dim, depth, graph_adj, GCN_depth, J_regressor, **kw):
     return GATOR(num_joint, embed_dim, depth, graph_adj, GCN_depth, J_regressor, **kw)

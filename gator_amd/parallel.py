@@ -137,12 +137,22 @@ class ShardedForward:
         self._regressor_dense = j_regressor
         self._regressor = None
 
+    def _joint_metrics(self, joints_m, target, sl):
+        """[sum MPJPE, sum PA-MPJPE, samples] from regressed joints in metres (gator_amd.eval, all on the device)."""
+        from . import eval as ev
+        joints = joints_m * 1000.0                                      # metres -> mm (lib/core/base.py:219)
+        tgt = target[sl]
+        kw = {} if self._eval_joints is None else {'eval_joints': self._eval_joints}
+        n = joints.shape[0]
+        return torch.stack([ev.mpjpe(joints, tgt, **kw) * n, ev.pa_mpjpe(joints, tgt, **kw) * n,
+                            torch.tensor(float(n), device=joints.device)]).double()
+
     def _device_metrics(self, verts, pose3d, target, sl):
-        """[sum MPJPE, sum PA-MPJPE, samples] of the samples `sl` of the local batch, on the device (gator_amd.eval)."""
+        """Same from materialised vertices (models without the fused joint-regression epilogue)."""
         from . import eval as ev
         if self._regressor is None:
             self._regressor = ev.JointRegressor(self._regressor_dense, verts.device)
-        joints = self._regressor(verts) * 1000.0                        # metres -> mm (lib/core/base.py:219)
+        joints = self._regressor(verts) * 1000.0
         tgt = target[sl]
         kw = {} if self._eval_joints is None else {'eval_joints': self._eval_joints}
         n = joints.shape[0]
@@ -151,11 +161,19 @@ class ShardedForward:
 
     def _step_eval(self, pose2d_shard):
         fn = self.metrics_fn or self._device_metrics
+        # the HIP model regresses the joints in the vertex GEMM's epilogue: no vertex is ever written (gator_forward_joints_f32)
+        fused = self.metrics_fn is None and hasattr(self.model, 'forward_joints') and self._regressor_dense is not None
+        if fused and getattr(self.model, '_jreg', None) is None:
+            self.model.set_joint_regressor(self._regressor_dense)
         B = pose2d_shard.shape[0]
         acc = None
         for s, e in self._plan(B):
-            verts, pose3d = self.model(pose2d_shard[s:e])
-            part = fn(verts, pose3d, self._target, slice(s, e))
+            if fused:
+                joints, pose3d = self.model.forward_joints(pose2d_shard[s:e])
+                part = self._joint_metrics(joints, self._target, slice(s, e))
+            else:
+                verts, pose3d = self.model(pose2d_shard[s:e])
+                part = fn(verts, pose3d, self._target, slice(s, e))
             acc = part if acc is None else acc + part
         if self.dist is not None and (self.world > 1 or self.always_gather):
             ctx, side = self._side(acc.device)

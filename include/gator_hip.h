@@ -114,6 +114,16 @@ int gator_profile_read(gator_ctx* ctx, char* names, int64_t names_capacity, floa
 int gator_regress_joints_f32(const float* verts, int32_t batch, const int32_t* coo_row, const int32_t* coo_col,
                              const float* coo_val, int32_t nnz, int32_t n_joint, float* joints, void* stream);
 
+/* The same regression FUSED into the forward: register a sparse regressor once (COO; host or device pointers), then
+ * gator_forward_joints_f32 = GATOR.forward + J_regressor @ mesh in one go -- the vertex GEMM's epilogue forms the regressor's
+ * partial products while the vertices are still in registers, a tiny kernel sums them in a fixed order (no atomics).
+ *   joints [B,n_joint,3] f32 (metres, like the mesh; the reference scales by 1000 before regressing, lib/core/base.py:219-221),
+ *   pose3d [B,J,3] (mm); verts [B,6890,3] or NULL: with NULL no vertex is ever written -- evaluation (lib/core/base.py:219-237,
+ *   which copies every mesh to the host twice) then needs 12*n_joint bytes per sample instead of 82 680. */
+int gator_set_joint_regressor(gator_ctx* ctx, const int32_t* coo_row, const int32_t* coo_col, const float* coo_val, int32_t nnz,
+                              int32_t n_joint);
+int gator_forward_joints_f32(gator_ctx* ctx, const float* pose2d, int32_t batch, float* joints, float* pose3d, float* verts, void* stream);
+
 /* "Next" row 8(f)-3: the input contract in front of the path (demo/run.py:103-121,127-134, data/PW3D/dataset.py:168-183,241-250):
  *   joints [batch, num_joint_in, comps] raw 2D joints in pixels (comps >= 2: x, y[, score]); add_pelvis_neck != 0 appends
  *   pelvis = (joint 11 + joint 12)/2 and neck = (joint 5 + joint 6)/2 (COCO order); pose2d [batch, num_joint_out, 2] =

@@ -75,3 +75,61 @@ def test_eval_pipeline_config5(coco):
     print('\n[config5] MPJPE %.4f mm (oracle %.4f)  PA-MPJPE %.4f mm (oracle %.4f)  MPVPE %.3f mm' % (e, e_ref, pa, pa_ref, ev))
     assert abs(e - e_ref) < 1e-3 and abs(pa - pa_ref) < 1e-3
     assert e > 1.0          # a real, non-degenerate error
+
+
+@pytest.mark.parametrize('name,which', [('coco19_alpha', 'h36m'), ('h36m17_bn', 'h36m'), ('coco19_alpha', 'coco')])
+def test_fused_joint_regression_epilogue(name, which):
+    """gator_forward_joints_f32: the regressor's partial products are formed in the vertex GEMM's epilogue and summed in a fixed
+    order -- same joints as regressing the materialised mesh (and as the fp64 oracle), vertices (when asked for) bit-identical
+    to the plain forward, and identical joints whether or not the vertices are stored."""
+    from oracle import gator_oracle as go
+    z, m = build_model(name, 'fused')
+    zz, c, sd = oracle_setup(name)
+    jr = synthetic.load_j_regressors()[which]
+    m.set_joint_regressor(jr)
+    for B in (1, 33, 70):
+        x = torch.from_numpy(synthetic.synthetic_pose2d(B, c.J, seed=40 + B))
+        verts, pose3d = m(x.cuda())
+        j1, p1 = m.forward_joints(x.cuda())
+        j2, p2, v2 = m.forward_joints(x.cuda(), with_verts=True)
+        assert torch.equal(v2, verts) and torch.equal(p1, pose3d) and torch.equal(p2, pose3d)
+        assert torch.equal(j1, j2)
+        sep = geval.JointRegressor(jr, 'cuda')(verts)
+        assert float((j1 - sep).abs().max()) < 2e-6                       # metres; both sum fp32 products in fp64
+        ref, _ = go.gator_forward(sd, c, x, torch.float64)
+        rj = go.regress_joints(jr, ref).numpy()
+        assert np.abs(j1.cpu().numpy() - rj).max() * 1e3 <= 1e-3         # 1e-3 mm against the fp64 oracle
+
+
+def test_eval_mode_b2048_without_vertices():
+    """BASELINE config 5 at B=2048 (J=19 model, mixed gt-/det-like inputs): ShardedForward(mode='eval') regresses the joints in
+    the vertex GEMM's epilogue and reduces MPJPE / PA-MPJPE sums on the device -- no mesh is ever stored or moved.  Against the
+    same metrics from materialised meshes (all 2048) and the numpy oracle (a 32-sample slice)."""
+    from oracle import gator_oracle as go
+    from gator_amd.parallel import ShardedForward
+    B = 2048
+    z, m = build_model('coco19_alpha', 'fused')
+    zz, c, sd = oracle_setup('coco19_alpha')
+    clean = synthetic.synthetic_pose2d(B // 2, 19, seed=21)
+    det = synthetic.synthetic_pose2d(B // 2, 19, seed=22, jitter=0.05)
+    x = torch.from_numpy(np.concatenate([clean, det], 0)).cuda()
+    jr = synthetic.load_j_regressors()['h36m']
+    tgt = torch.from_numpy(np.random.RandomState(5).randn(B, 17, 3).astype(np.float32) * 120).cuda()
+    run = ShardedForward(m, 1, 0, None, micro_batch=1024, mode='eval')
+    run.set_eval(jr, tgt)
+    got = run.step(x)
+    torch.cuda.synchronize()
+    assert float(got[2]) == B
+    verts, _ = m(x)
+    joints = geval.JointRegressor(jr, 'cuda')(verts) * 1000.0
+    want = torch.stack([geval.mpjpe(joints, tgt) * B, geval.pa_mpjpe(joints, tgt) * B]).double()
+    print('\n[config5 B=2048] MPJPE %.4f mm, PA-MPJPE %.4f mm (fused epilogue) vs %.4f / %.4f (materialised meshes)'
+          % (float(got[0]) / B, float(got[1]) / B, float(want[0]) / B, float(want[1]) / B))
+    assert torch.allclose(got[:2], want, rtol=2e-6)
+    sl = slice(1000, 1032)                                                  # straddles nothing special; oracle check on a slice
+    ref, _ = go.gator_forward(sd, c, x[sl].cpu(), torch.float64)
+    rj = go.regress_joints(jr, ref * 1000).numpy()
+    j_f, _ = m.forward_joints(x[sl].contiguous())
+    e_ref = go.mpjpe(rj, tgt[sl].cpu().numpy().astype(np.float64), list(geval.H36M_EVAL_JOINTS))
+    e_got = float(geval.mpjpe(j_f * 1000.0, tgt[sl]))
+    assert abs(e_ref - e_got) < 1e-3
