@@ -42,6 +42,10 @@ SIGNATURES = {
     'gator_forward_joints_f32': (_I, [_P, _P, _I, _P, _P, _P, _P]),
     'gator_preprocess_pose2d_f32': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'gator_rigid_align_f32': (_I, [_P, _P, _I, _I, _P, _P]),
+    'gator_comm_unique_id': (_I, [_P]),
+    'gator_comm_create': (_I, [_P, _I, _I, ctypes.POINTER(_P)]),
+    'gator_comm_destroy': (_I, [_P]),
+    'gator_allgather_verts': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     'gator_floyd_warshall': (_I, [_P, _I, _P, _P]),
     'gator_gen_edge_input': (_I, [_P, _P, _I, _I, _P]),
     'gator_verts_joints_relation': (_I, [_P, _I, _P, _I, _P]),

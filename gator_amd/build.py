@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libgator_hip.so')
 SOURCES = ['api.hip', 'basic_kernels.hip', 'fused_api.hip', 'fused_pack.hip', 'upsample_fused.hip', 'mdr_fused.hip', 'gat_fused.hip', 'gat_tiled.hip', 'gat_tail.hip', 'upsample_bf16.hip', 'upsample_x3.hip', 'caller_kernels.hip',
-           'graph_consts.cpp']
+           'graph_consts.cpp', 'comm_rccl.cpp']
 HEADERS = ['internal.h', os.path.join(ROOT, 'include', 'gator_hip.h')]
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
          '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
@@ -75,7 +75,7 @@ def build(force=False, verbose=True, diag=False):
                     os.remove(obj)
             raise
     if force or procs or _stale(lib, objs):
-        cmd = [hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', lib] + objs
+        cmd = [hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', lib] + objs + ['-ldl']
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

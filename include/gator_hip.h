@@ -137,6 +137,20 @@ int gator_preprocess_pose2d_f32(const float* joints, int32_t batch, int32_t num_
  * the kernel under PA-MPJPE (data/PW3D/dataset.py:337-375). */
 int gator_rigid_align_f32(const float* a, const float* b, int32_t batch, int32_t n_points, float* aligned, void* stream);
 
+/* Multi-GPU: samples are independent, the batch is sharded contiguously over one process per GPU, and the path's one
+ * collective is the all-gather of the predicted vertices [B/N,6890,3] (+ pose3d [B/N,J,3]) over xGMI.  gator_amd/parallel.py issues
+ * it through torch.distributed ("nccl" = RCCL); these entry points do the same on RCCL directly for hosts without torch:
+ * rank 0 calls gator_comm_unique_id and hands the 128 bytes to every rank (any host-side channel), every rank calls
+ * gator_comm_create on its device, then gator_allgather_verts per step (rank-major outputs: rank r's rows at r*batch_local).
+ * librccl is resolved at run time (the copy already loaded in the process, e.g. PyTorch's, else the system one), never linked. */
+#define GATOR_COMM_ID_BYTES 128
+typedef struct gator_comm gator_comm;
+int gator_comm_unique_id(uint8_t* id /* [GATOR_COMM_ID_BYTES] */);
+int gator_comm_create(const uint8_t* id, int32_t rank, int32_t world_size, gator_comm** out);
+int gator_comm_destroy(gator_comm* comm);
+int gator_allgather_verts(gator_comm* comm, const float* verts_local, const float* pose3d_local /* or NULL */, int32_t batch_local,
+                          int32_t num_joint, float* verts_all, float* pose3d_all /* or NULL */, void* stream);
+
 /* Host-side graph constants (no GPU needed).  Replace the absent Cython algos.pyx
  * (lib/models/backbones/setup.py:1-6) and lib/models/backbones/modules.py:6-29, lib/graph_utils.py:71-89. */
 int gator_floyd_warshall(const float* adj, int32_t n, int64_t* dist, int64_t* path);

@@ -76,6 +76,21 @@ def test_single_rank_eval_mode_matches_eval_module(rccl_group):
     assert torch.allclose(got[:2], want, rtol=1e-5), (got, want)
 
 
+def test_native_rccl_allgather_one_rank():
+    """gator_allgather_verts (RCCL resolved at run time from the process, no torch.distributed): one rank = a copy."""
+    from gator_amd.comm import NativeComm
+    comm = NativeComm.create(0, 1, lambda b: b)
+    v = torch.randn(5, 6890, 3, device='cuda')
+    p = torch.randn(5, 17, 3, device='cuda')
+    gv, gp = comm.allgather(v, p)
+    torch.cuda.synchronize()
+    assert torch.equal(gv, v) and torch.equal(gp, p)
+    gv2 = comm.allgather(v)
+    torch.cuda.synchronize()
+    assert torch.equal(gv2, v)
+    comm.close()
+
+
 _TWO_RANK = r'''
 import os, sys, json, torch, torch.distributed as dist
 sys.path.insert(0, %(root)r)
@@ -101,6 +116,20 @@ for micro in (None, 10):
         run.wait()
         ok = ok and bool(torch.equal(gv, rv)) and bool(torch.equal(gp, rp))
         prev = (gv, rv)
+# the same gather through the C ABI's own RCCL communicator (gator_allgather_verts); the id travels over torch's object broadcast
+from gator_amd.comm import NativeComm
+def _bcast(b):
+    box = [b]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+comm = NativeComm.create(rank, world, _bcast)
+full = torch.from_numpy(synthetic.synthetic_pose2d(world * n, 17, seed=99)).to(dev)
+lv, lp = m(full[rank * n:(rank + 1) * n])
+nv, npp = comm.allgather(lv, lp)
+rv, rp = m(full)
+torch.cuda.synchronize()
+ok = ok and bool(torch.equal(nv, rv)) and bool(torch.equal(npp, rp))
+comm.close()
 torch.cuda.synchronize()
 flag = torch.tensor([1.0 if ok else 0.0], device=dev)
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
