@@ -50,8 +50,8 @@ BYTES_PER_MESH = {17: 83020, 19: 83060}        # compulsory HBM byt
 STAGE_MFLOP = {'upsample_bf16': 53.45, 'gat': 56.66, 'mdr_layer0': 48.7, 'mdr_layer': 99.2, 'mdr_attn_head': 51.4, 'mdr_head': 1.3,
                'upsample': 53.45}
 # inter-kernel operand bytes per mesh the dominant kernels are DESIGNED to move: the residual tile set
-# vf (14 tiles x 2 blocks x 4 KiB) and the Q/K/V tile sets as split-precision planes (x 1.5), read and/or written once
-_VF, _QKV = 14 * 2 * 4096, 3 * 14 * 2 * 6144
+# vf (14 tiles x 2 blocks x 4 KiB) and the Q/K/V tile sets, read and/or written once
+_VF, _QKV = 14 * 2 * 4096, 3 * 14 * 2 * 4096          # Q/K/V as two fp16 planes: 4 KiB tiles (6 KiB when GATOR_MDR_X3=1)
 STAGE_BYTES = {'mdr_layer0': _VF + _QKV, 'mdr_layer': 2 * (_VF + _QKV), 'mdr_attn_head': _VF + _QKV + 431 * 32 * 4 + 431 * 64 * 4,
                'upsample': 3 * 431 * 2 * 3 + 6890 * 3 * 4, 'gat': 136 + 17 * 128 * 4 + 204 + 12 * 4096}
 STAGE_KERNEL = {'gat': 'k_gat', 'mdr_layer0': 'k_mdr_layer<0,', 'mdr_layer': 'k_mdr_layer<1,',
@@ -108,10 +108,23 @@ def launch_ranks(a):
     return rc
 
 
+# MFLOP of a stage that run on TWO fp16 planes per operand (3 partial products per fp32 product: the 431x431 self-attention
+# core, QK^T + PV = 47.6 MFLOP per layer) when GATOR_MDR_X3 is 2 (the default); the rest of the stage is on three bf16 planes
+STAGE_X2_MFLOP = {'mdr_layer': 47.6, 'mdr_attn_head': 47.6}
+PEAK_X2_TFLOPS = round(PEAK_BF16_TFLOPS / 3, 1)
+
+
 def stage_pipe(stage, impl):
-    """-> (pipe name, peak TFLOP/s of fp32-equivalent work) for a profiled stage."""
+    """-> (pipe name, peak TFLOP/s of fp32-equivalent work) for a profiled stage.  A stage that mixes the two split forms is
+    priced against the time-weighted ceiling of the arithmetic it executes: total / sum(part_i / peak_i)."""
     sw = STAGE_X3_SWITCH.get(stage)
-    if impl == 'fused' and sw is not None and os.environ.get(sw, '1') != '0':
+    if impl == 'fused' and sw is not None and os.environ.get(sw, '2' if sw == 'GATOR_MDR_X3' else '1') != '0':
+        x2 = STAGE_X2_MFLOP.get(stage, 0.0) if os.environ.get('GATOR_MDR_X3', '2') == '2' else 0.0
+        if x2 > 0:
+            tot = STAGE_MFLOP[stage]
+            peak = tot / (x2 / PEAK_X2_TFLOPS + (tot - x2) / PEAK_X3_TFLOPS)
+            return ('bf16 MFMA, exact 3-plane split (6 partial products) for %.1f MFLOP + fp16 MFMA, 2-plane split (3 partial '
+                    'products) for the %.1f MFLOP attention core' % (tot - x2, x2)), round(peak, 1)
         return 'bf16 MFMA, split precision (3 planes, %d partial products per fp32 product)' % X3_PRODUCTS, PEAK_X3_TFLOPS
     if stage == 'upsample_bf16':
         return 'bf16 MFMA', PEAK_BF16_TFLOPS
@@ -296,7 +309,8 @@ def main():
                 pipe, peak = stage_pipe(stage, a.impl)
                 alg = STAGE_BYTES.get(stage)
                 roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                        'frac': round(ach / peak, 4), 'traffic': traffic,
+                        'frac': round(ach / peak, 4), 'frac_of_all_bf16x3_ceiling_416.7': round(ach / PEAK_X3_TFLOPS, 4),
+                        'frac_of_fp32_mfma_peak_157.3': round(ach / PEAK_F32_TFLOPS, 4), 'traffic': traffic,
                         'algorithmic_bytes': int(alg * B) if alg else None,
                         'traffic_ratio': round(traffic / (alg * B), 3) if (traffic and alg) else None,
                         'avg_launch_ms': round(avg_s * 1e3, 4), 'pipe': pipe,

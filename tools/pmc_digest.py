@@ -5,9 +5,9 @@ Writes profiles/<tag>_* (kernel stats CSV, one CSV per PMC pass, the summary JSO
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 src = os.path.join('gpurun_out', 'prof_' + tag)
-KEEP = ('k_gat', 'k_mdr_layer', 'k_mdr_head', 'k_upsample', 'k_mdr_joint', 'k_pack_vc')
+KEEP = ('k_gat', 'k_mdr_layer', 'k_mdr_head', 'k_upsample', 'k_mdr_joint', 'k_pack_vc', 'k_jreg')
 
 
 def short(name):
@@ -62,6 +62,7 @@ def main():
                 d['write_MB'] = round(avg['WRITE_SIZE'] / 1024, 3)
             if 'SQ_INSTS_VALU_MFMA_BF16' in avg:
                 d['mfma_bf16_insts'] = int(avg['SQ_INSTS_VALU_MFMA_BF16'])
+                d['mfma_f16_insts'] = int(avg.get('SQ_INSTS_VALU_MFMA_F16', 0))
                 d['mfma_f32_insts'] = int(avg.get('SQ_INSTS_VALU_MFMA_F32', 0))
                 if avg.get('GRBM_GUI_ACTIVE'):
                     d['mfma_busy_frac'] = round(avg['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (avg['GRBM_GUI_ACTIVE'] / 8), 4)
