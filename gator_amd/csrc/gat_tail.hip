@@ -95,8 +95,12 @@ __global__ __launch_bounds__(256) void k_gat_joint(const JointTailArgs a) {
     if (t < 3 * J) {
         const int mt = b >> 5, s = b & 31, nt = t >> 5, ro = t & 31;
         const float* p = a.part + ((size_t)mt * J * 2 + nt) * kTile + (((ro >> 3) * 64 + ((ro >> 2) & 1) * 32 + s) * 4 + (ro & 3));
+        float pj[19];                       // all partials in flight at once (a rolled loop pays one L2 round trip per joint)
+#pragma unroll
+        for (int j = 0; j < 19; ++j) pj[j] = p[(size_t)(j < J ? j : 0) * 2 * kTile];
         float acc = 0.f;
-        for (int j = 0; j < J; ++j) acc += p[(size_t)j * 2 * kTile];
+#pragma unroll
+        for (int j = 0; j < 19; ++j) acc += j < J ? pj[j] : 0.f;
         acc += a.lifter_b[t];
         a.x_out[(size_t)b * 3 * J + t] = acc;
         XO[t] = acc;

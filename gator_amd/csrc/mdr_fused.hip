@@ -695,7 +695,6 @@ struct HeadArgs {
 template <int NT>
 __global__ __launch_bounds__(NT) void k_mdr_head(const HeadArgs a) {
     __shared__ float bn[kV][3];
-    __shared__ float part[NT / 64][60];
     __shared__ float bc[20][3];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* hf = a.hf + (size_t)b * kV * 32;
@@ -714,39 +713,37 @@ __global__ __launch_bounds__(NT) void k_mdr_head(const HeadArgs a) {
         for (int c = 0; c < 3; ++c) bn[v][c] = gelu_f(x[c]);
     }
     __syncthreads();
-    {   // Conv1d(431->20,k3,p1) over the xyz axis: every thread walks the (c,k) axis with coalesced weight reads
-        float acc[20][3];
+    {   // Conv1d(431->20,k3,p1) over the xyz axis.  Wave w owns output rows m = w, w+8, w+16 and walks the whole (c,k) axis with
+        // coalesced weight reads: 9 accumulators and 9 wave reductions per wave (all 20 rows in every wave: 60 reductions of 6
+        // cross-lane steps each plus a cross-wave pass -- two thirds of this kernel's time).
+        constexpr int NW = NT / 64;
+        float acc[3][3];
 #pragma unroll
-        for (int m = 0; m < 20; ++m) acc[m][0] = acc[m][1] = acc[m][2] = 0.f;
-        for (int e = t; e < kV * 3; e += NT) {
+        for (int q = 0; q < 3; ++q) acc[q][0] = acc[q][1] = acc[q][2] = 0.f;
+        for (int e = lane; e < kV * 3; e += 64) {
             const int c = e / 3, k = e - 3 * c;
             // tap k of channel c meets input position ll = l + k - 1 (zero padding outside 0..2)
             const float in0 = (k >= 1) ? bn[c][k - 1] : 0.f;        // l=0: ll = k-1
             const float in1 = bn[c][k];                             // l=1: ll = k
             const float in2 = (k <= 1) ? bn[c][k + 1] : 0.f;        // l=2: ll = k+1
 #pragma unroll
-            for (int m = 0; m < 20; ++m) {
-                const float w = a.bconv_w[m * (kV * 3) + e];
-                acc[m][0] += w * in0;
-                acc[m][1] += w * in1;
-                acc[m][2] += w * in2;
+            for (int q = 0; q < 3; ++q) {
+                const int m = wave + NW * q;
+                const float w = a.bconv_w[(m < 20 ? m : 0) * (kV * 3) + e];
+                acc[q][0] += w * in0;
+                acc[q][1] += w * in1;
+                acc[q][2] += w * in2;
             }
         }
 #pragma unroll
-        for (int m = 0; m < 20; ++m)
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
-                float s = acc[m][l];
+                double s = (double)acc[q][l];
                 for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-                if (lane == 0) part[wave][m * 3 + l] = s;
+                const int m = wave + NW * q;
+                if (lane == 0 && m < 20) bc[m][l] = (float)(s + (double)a.bconv_b[m]);
             }
-    }
-    __syncthreads();
-    if (t < 60) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int w = 0; w < NT / 64; ++w) sacc += (double)part[w][t];
-        bc[t / 3][t % 3] = (float)(sacc + (double)a.bconv_b[t / 3]);
     }
     __syncthreads();
     const int mt = b >> 5, sl = b & 31;
