@@ -128,6 +128,110 @@ __global__ void k_rigid_align(const float* __restrict__ A, const float* __restri
 
 using namespace gator;
 
+namespace gator {
+namespace {
+// The GENERAL input chain (data/PW3D/dataset.py:236-250): tight bbox (lib/coord_utils.py:21-39) -> process_bbox (:42-66, which
+// REJECTS a box narrower or lower than one pixel: valid = 0, the datasets drop such samples) -> get_affine_transform with rotation
+// (lib/aug_utils.py:140-173: three float32 point pairs, solved as cv2.getAffineTransform does) -> affine per joint, optional
+// flip_2d_joint (:31-38) -> float32 -> /[W,H] -> per-axis standardisation.  One thread per sample; float32 roundings where the
+// reference has them (bbox, centre/scale, the point pairs, the transformed joints, the division), fp64 in between.
+__global__ void k_preprocess_chain(const float* __restrict__ in, int B, int jin, int comps, int add_pn, const float* __restrict__ rot_deg,
+                                   const int32_t* __restrict__ flip, const int32_t* __restrict__ pairs, int n_pairs, int res_w, int res_h,
+                                   float* __restrict__ out, int32_t* __restrict__ valid) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int J = jin + (add_pn ? 2 : 0);
+    const float* p = in + (size_t)b * jin * comps;
+    double x[32], y[32];
+    for (int j = 0; j < jin; ++j) { x[j] = p[j * comps]; y[j] = p[j * comps + 1]; }
+    if (add_pn) {
+        x[jin] = (x[11] + x[12]) * 0.5;     y[jin] = (y[11] + y[12]) * 0.5;
+        x[jin + 1] = (x[5] + x[6]) * 0.5;   y[jin + 1] = (y[5] + y[6]) * 0.5;
+    }
+    float* o = out + (size_t)b * J * 2;
+    double xmin = x[0], xmax = x[0], ymin = y[0], ymax = y[0];
+    for (int j = 1; j < J; ++j) { xmin = fmin(xmin, x[j]); xmax = fmax(xmax, x[j]); ymin = fmin(ymin, y[j]); ymax = fmax(ymax, y[j]); }
+    // get_bbox: centre +- half extent, cast to float32
+    const double xc = (xmin + xmax) / 2., bw0 = xmax - xmin, yc = (ymin + ymax) / 2., bh0 = ymax - ymin;
+    const double bxmin = xc - 0.5 * bw0, bxmax = xc + 0.5 * bw0, bymin = yc - 0.5 * bh0, bymax = yc + 0.5 * bh0;
+    const float bx = (float)bxmin, by = (float)bymin, bw = (float)(bxmax - bxmin), bh = (float)(bymax - bymin);
+    // process_bbox (float32 arithmetic on the float32 box, as numpy does)
+    const float x2 = bx + (bw - 1.f), y2 = by + (bh - 1.f);
+    const bool ok = (bw * bh > 0.f) && x2 >= bx && y2 >= by;
+    if (valid) valid[b] = ok ? 1 : 0;
+    if (!ok) {
+        for (int j = 0; j < 2 * J; ++j) o[j] = 0.f;
+        return;
+    }
+    float w = x2 - bx, h = y2 - by;
+    const float cx = bx + w / 2.f, cy = by + h / 2.f;
+    const double ar = (double)res_w / (double)res_h;       // cfg.MODEL.input_shape[1] / [0]; python float (fp64) against float32 values
+    if ((double)w > ar * (double)h) h = (float)((double)w / ar);
+    else if ((double)w < ar * (double)h) w = (float)((double)h * ar);
+    const float fx = cx - w / 2.f, fy = cy - h / 2.f;
+    // get_center_scale + get_affine_transform: float32 point pairs
+    const float cen0 = fx + w * 0.5f, cen1 = fy + h * 0.5f;
+    const double rr = M_PI * (rot_deg ? (double)rot_deg[b] : 0.0) / 180.0, sn = sin(rr), cs = cos(rr);
+    const double p1 = (double)(w * -0.5f);
+    const double sd0 = 0.0 * cs - p1 * sn, sd1 = 0.0 * sn + p1 * cs;                      // get_dir([0, -w/2], rot)
+    float src[3][2], dst[3][2];
+    src[0][0] = cen0; src[0][1] = cen1;
+    src[1][0] = (float)((double)cen0 + sd0); src[1][1] = (float)((double)cen1 + sd1);
+    dst[0][0] = res_w * 0.5f; dst[0][1] = res_h * 0.5f;
+    dst[1][0] = (float)((double)(res_w * 0.5) + 0.0); dst[1][1] = (float)((double)(res_h * 0.5) + (double)(res_w * -0.5f));
+    for (int q = 0; q < 2; ++q) {
+        float (*m)[2] = q ? dst : src;
+        const float d0 = m[0][0] - m[1][0], d1 = m[0][1] - m[1][1];
+        m[2][0] = m[1][0] + (-d1); m[2][1] = m[1][1] + d0;                                 // get_3rd_point
+    }
+    // solve [sx sy 1] T^T = [dx dy] for the 2x3 matrix (Cramer, fp64)
+    const double a0 = src[0][0], b0 = src[0][1], a1 = src[1][0], b1 = src[1][1], a2 = src[2][0], b2 = src[2][1];
+    const double det = a0 * (b1 - b2) - b0 * (a1 - a2) + (a1 * b2 - a2 * b1);
+    double T[2][3];
+    for (int r = 0; r < 2; ++r) {
+        const double d0 = dst[0][r], d1 = dst[1][r], d2 = dst[2][r];
+        T[r][0] = (d0 * (b1 - b2) - b0 * (d1 - d2) + (d1 * b2 - d2 * b1)) / det;
+        T[r][1] = (a0 * (d1 - d2) - d0 * (a1 - a2) + (a1 * d2 - a2 * d1)) / det;
+        T[r][2] = (a0 * (b1 * d2 - b2 * d1) - b0 * (a1 * d2 - a2 * d1) + d0 * (a1 * b2 - a2 * b1)) / det;
+    }
+    for (int j = 0; j < J; ++j) {
+        const double nx = T[0][0] * x[j] + T[0][1] * y[j] + T[0][2], ny = T[1][0] * x[j] + T[1][1] * y[j] + T[1][2];
+        x[j] = nx; y[j] = ny;
+    }
+    if (flip && flip[b]) {
+        for (int j = 0; j < J; ++j) x[j] = res_w - x[j] - 1;
+        for (int q = 0; q < n_pairs; ++q) {
+            const int u = pairs[2 * q], v = pairs[2 * q + 1];
+            if (u < J && v < J) { const double tx = x[u], ty = y[u]; x[u] = x[v]; y[u] = y[v]; x[v] = tx; y[v] = ty; }
+        }
+    }
+    float fxn[32], fyn[32];
+    for (int j = 0; j < J; ++j) { fxn[j] = (float)x[j] / (float)res_w; fyn[j] = (float)y[j] / (float)res_h; }   // astype(float32); /= [W,H]
+    double mx = 0.0, my = 0.0;
+    for (int j = 0; j < J; ++j) { mx += fxn[j]; my += fyn[j]; }
+    mx /= J; my /= J;
+    double vx = 0.0, vy = 0.0;
+    for (int j = 0; j < J; ++j) { vx += (fxn[j] - mx) * (fxn[j] - mx); vy += (fyn[j] - my) * (fyn[j] - my); }
+    const double sx = sqrt(vx / J), sy = sqrt(vy / J);
+    for (int j = 0; j < J; ++j) { o[j * 2] = (float)((fxn[j] - mx) / sx); o[j * 2 + 1] = (float)((fyn[j] - my) / sy); }
+}
+}  // namespace
+}  // namespace gator
+
+extern "C" int gator_preprocess_chain_f32(const float* joints, int32_t batch, int32_t num_joint_in, int32_t comps, int32_t add_pelvis_neck,
+                                          const float* rot_deg, const int32_t* flip, const int32_t* flip_pairs, int32_t n_pairs,
+                                          int32_t res_w, int32_t res_h, float* pose2d, int32_t* valid, void* stream) {
+    using namespace gator;
+    if (!joints || !pose2d || batch <= 0 || num_joint_in <= 0 || comps < 2 || res_w <= 0 || res_h <= 0 || n_pairs < 0 || (n_pairs > 0 && !flip_pairs))
+        return fail(GATOR_EINVAL, "gator_preprocess_chain_f32: bad arguments");
+    if (num_joint_in + (add_pelvis_neck ? 2 : 0) > 32) return fail(GATOR_EINVAL, "gator_preprocess_chain_f32: at most 32 joints");
+    if (add_pelvis_neck && num_joint_in < 13) return fail(GATOR_EINVAL, "gator_preprocess_chain_f32: pelvis/neck need the COCO joint order (>= 13 joints)");
+    k_preprocess_chain<<<(batch + 63) / 64, 64, 0, (hipStream_t)stream>>>(joints, batch, num_joint_in, comps, add_pelvis_neck ? 1 : 0, rot_deg, flip,
+                                                                       flip_pairs, n_pairs, res_w, res_h, pose2d, valid);
+    GATOR_HIP_CHECK(hipGetLastError());
+    return GATOR_OK;
+}
+
 extern "C" int gator_preprocess_pose2d_f32(const float* joints, int32_t batch, int32_t num_joint_in, int32_t comps,
                                            int32_t add_pelvis_neck, float* pose2d, void* stream) {
     if (!joints || !pose2d || batch <= 0 || num_joint_in <= 0 || num_joint_in + (add_pelvis_neck ? 2 : 0) > 32 || comps < 2)

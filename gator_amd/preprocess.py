@@ -33,3 +33,25 @@ def coco_to_model_input(joints17):
     if joints17.shape[1] != 17:
         raise ValueError('coco_to_model_input: expected 17 COCO joints, got %d' % joints17.shape[1])
     return normalise_pose2d(joints17, add_pelvis_neck=True)
+
+
+def preprocess_chain(joints, rot_deg=None, flip=None, flip_pairs=(), add_pelvis_neck=False, res=(288, 384)):
+    """The reference's whole input chain on the device (gator_preprocess_chain_f32): bbox -> process_bbox -> affine with rotation /
+    flip -> /[W,H] -> standardise.  joints [B,J,2|3] f32 (pixels); rot_deg [B] f32 or None; flip [B] int32 or None.
+    -> (pose2d [B,J(+2),2], valid [B] int32: 0 where process_bbox rejects the box and the reference drops the sample)."""
+    if not joints.is_cuda:
+        raise RuntimeError('preprocess_chain: joints must live on a HIP device (there is no CPU path)')
+    x = joints.contiguous().float()
+    B, J, C = x.shape
+    dev = x.device
+    out = torch.empty((B, J + (2 if add_pelvis_neck else 0), 2), device=dev, dtype=torch.float32)
+    valid = torch.empty((B,), device=dev, dtype=torch.int32)
+    rot = None if rot_deg is None else torch.as_tensor(rot_deg, dtype=torch.float32, device=dev).contiguous()
+    fl = None if flip is None else torch.as_tensor(flip, dtype=torch.int32, device=dev).contiguous()
+    pairs = torch.as_tensor(list(flip_pairs), dtype=torch.int32, device=dev).reshape(-1, 2).contiguous()
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(_lib.load().gator_preprocess_chain_f32(x.data_ptr(), B, J, C, int(bool(add_pelvis_neck)), rot.data_ptr() if rot is not None else None,
+                                                      fl.data_ptr() if fl is not None else None, pairs.data_ptr() if pairs.numel() else None,
+                                                      int(pairs.shape[0]), int(res[0]), int(res[1]), out.data_ptr(), valid.data_ptr(), st),
+               'gator_preprocess_chain_f32')
+    return out, valid

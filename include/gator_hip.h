@@ -132,6 +132,15 @@ int gator_forward_joints_f32(gator_ctx* ctx, const float* pose2d, int32_t batch,
 int gator_preprocess_pose2d_f32(const float* joints, int32_t batch, int32_t num_joint_in, int32_t comps,
                                 int32_t add_pelvis_neck, float* pose2d, void* stream);
 
+/* The same contract WITHOUT the reduction: the reference's whole chain per sample (data/PW3D/dataset.py:236-250) -- tight bbox
+ * (lib/coord_utils.py:21-39), process_bbox (:42-66), get_affine_transform with in-plane rotation rot_deg[b] (lib/aug_utils.py:140-173),
+ * affine per joint, horizontal flip with left/right pairs when flip[b] != 0 (:31-38), /[res_w,res_h], standardisation.
+ * valid[b] = 0 (and pose2d[b] = 0) where process_bbox returns None (a box under one pixel wide or high; the datasets drop such
+ * samples).  rot_deg / flip / valid may be NULL (no rotation / no flip / not reported); res = (288, 384) in every reference config. */
+int gator_preprocess_chain_f32(const float* joints, int32_t batch, int32_t num_joint_in, int32_t comps, int32_t add_pelvis_neck,
+                               const float* rot_deg, const int32_t* flip, const int32_t* flip_pairs, int32_t n_pairs,
+                               int32_t res_w, int32_t res_h, float* pose2d, int32_t* valid, void* stream);
+
 /* "Next" row 8(f)-2: per-sample similarity (Procrustes) alignment of a onto b, [batch, n_points, 3] each
  * (rigid_transform_3D / rigid_align, lib/coord_utils.py:127-149: 3x3 SVD with the reflection fix, scale, translation);
  * the kernel under PA-MPJPE (data/PW3D/dataset.py:337-375). */

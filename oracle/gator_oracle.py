@@ -280,3 +280,78 @@ def pa_mpjpe(pred_joint, target_joint, eval_joints=None):
             p, t = p[list(eval_joints)], t[list(eval_joints)]
         errs.append(np.sqrt(((rigid_align(p, t) - t) ** 2).sum(1)).mean())
     return float(np.mean(errs))
+
+
+# ---- the general input chain: bbox -> affine (rotation, flip) -> /[W,H] -> standardise ---------------------------------------
+def get_bbox(joint_img):
+    """lib/coord_utils.py:21-39 (tight box of the joints, float32)."""
+    x, y = joint_img[:, 0], joint_img[:, 1]
+    xmin, ymin, xmax, ymax = min(x), min(y), max(x), max(y)
+    xc, w = (xmin + xmax) / 2., xmax - xmin
+    xmin, xmax = xc - 0.5 * w, xc + 0.5 * w
+    yc, h = (ymin + ymax) / 2., ymax - ymin
+    ymin, ymax = yc - 0.5 * h, yc + 0.5 * h
+    return np.array([xmin, ymin, xmax - xmin, ymax - ymin]).astype(np.float32)
+
+
+def process_bbox(bbox, aspect_ratio):
+    """lib/coord_utils.py:42-66: None for a degenerate box (width or height under one pixel), else the aspect-preserving box."""
+    x, y, w, h = bbox
+    x1, y1, x2, y2 = x, y, x + (w - 1), y + (h - 1)
+    if w * h > 0 and x2 >= x1 and y2 >= y1:
+        bbox = np.array([x1, y1, x2 - x1, y2 - y1])
+    else:
+        return None
+    w, h = bbox[2], bbox[3]
+    cx, cy = bbox[0] + w / 2., bbox[1] + h / 2.
+    if w > aspect_ratio * h:
+        h = w / aspect_ratio
+    elif w < aspect_ratio * h:
+        w = h * aspect_ratio
+    bbox[2], bbox[3] = w, h
+    bbox[0], bbox[1] = cx - bbox[2] / 2., cy - bbox[3] / 2.
+    return bbox
+
+
+def affine_from_bbox(bbox, rot, res):
+    """get_center_scale (lib/coord_utils.py:7-18) + get_affine_transform (lib/aug_utils.py:140-173) with shift = 0: three point
+    pairs in float32, solved for the 2x3 matrix as cv2.getAffineTransform does (float64)."""
+    x, y, w, h = bbox
+    center = np.array([x + w * 0.5, y + h * 0.5], np.float32)
+    scale = np.array([w, h], np.float32)
+    rot_rad = np.pi * rot / 180
+    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
+    p = [0, scale[0] * -0.5]
+    src_dir = [p[0] * cs - p[1] * sn, p[0] * sn + p[1] * cs]                  # get_dir, aug_utils.py:188-195
+    src = np.zeros((3, 2), np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    src[0] = center
+    src[1] = center + src_dir
+    dst[0] = [res[0] * 0.5, res[1] * 0.5]
+    dst[1] = np.array([res[0] * 0.5, res[1] * 0.5]) + np.array([0, res[0] * -0.5], np.float32)
+    for m in (src, dst):                                                      # get_3rd_point, aug_utils.py:182-184
+        d = m[0] - m[1]
+        m[2] = m[1] + np.array([-d[1], d[0]], np.float32)
+    a = np.concatenate([src.astype(np.float64), np.ones((3, 1))], 1)
+    return np.linalg.solve(a, dst.astype(np.float64)).T                       # [2,3]
+
+
+def preprocess_pose2d(joint_img, rot=0.0, flip=False, flip_pairs=(), res=(288, 384)):
+    """data/PW3D/dataset.py:236-250 / demo/run.py:124-134: bbox -> process_bbox -> j2d_processing (lib/aug_utils.py:51-64:
+    affine per joint, optional flip_2d_joint :31-38, float32 cast) -> /[W,H] -> per-axis standardisation.  None if the box is
+    degenerate (the datasets drop such samples)."""
+    kp = np.array(joint_img, dtype=np.float64)[:, :2].copy()
+    bbox = process_bbox(get_bbox(kp).copy(), res[0] / res[1])
+    if bbox is None:
+        return None
+    t = affine_from_bbox(bbox, rot, res)
+    for i in range(kp.shape[0]):
+        kp[i] = t @ np.array([kp[i, 0], kp[i, 1], 1.])
+    if flip:
+        kp[:, 0] = res[0] - kp[:, 0] - 1
+        for a, b in flip_pairs:
+            kp[a], kp[b] = kp[b].copy(), kp[a].copy()
+    kp = kp.astype(np.float32)
+    kp /= np.array([[res[0], res[1]]])
+    mean, std = np.mean(kp, axis=0), np.std(kp, axis=0)
+    return (kp.copy() - mean) / std

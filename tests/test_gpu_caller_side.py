@@ -69,3 +69,23 @@ def test_rigid_align_vs_oracle(case):
     p = float(geval.pa_mpjpe(torch.from_numpy(a.astype(np.float32)).cuda(), torch.from_numpy(b.astype(np.float32)).cuda(), eval_joints=tuple(range(N))))
     r = go.pa_mpjpe(a.astype(np.float32), b.astype(np.float32))
     assert abs(p - r) <= 1e-5 * max(1.0, r)
+
+
+def test_general_preprocess_chain_kernel_matches_reference_golden():
+    """gator_preprocess_chain_f32 against the reference's own chain (rotation, flips, rejected boxes) and, for rot = 0 / no flip,
+    against the reduced kernel."""
+    from gator_amd import preprocess as pp
+    from tests.helpers import load_golden
+    z = load_golden('preprocess_chain')
+    j = torch.from_numpy(z['joints'].astype(np.float32)).cuda()
+    out, valid = pp.preprocess_chain(j, rot_deg=z['rot'].astype(np.float32), flip=z['flip'], flip_pairs=[tuple(p) for p in z['flip_pairs']])
+    out, valid = out.cpu().numpy(), valid.cpu().numpy()
+    assert np.array_equal(valid, z['valid'])
+    ok = z['valid'] == 1
+    err = np.abs(out[ok] - z['pose2d'][ok]).max()
+    print('\ngeneral preprocess chain vs reference: max|d| %.2e over %d samples' % (err, int(ok.sum())))
+    assert err < 2e-5                       # float32 inputs (the fixture's joints are float64) + float32 output
+    assert np.all(out[~ok] == 0)
+    plain, v2 = pp.preprocess_chain(j)
+    red = pp.normalise_pose2d(j)
+    assert np.abs(plain[ok].cpu().numpy() - red[ok].cpu().numpy()).max() < 5e-5

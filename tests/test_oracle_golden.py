@@ -93,3 +93,19 @@ def test_rigid_align_matches_reference():
     out = np.stack([go.rigid_align(a, b) for a, b in zip(z['A'], z['B'])])
     assert np.abs(out - z['aligned']).max() < 1e-9 * np.abs(z['aligned']).max()
     assert abs(go.pa_mpjpe(z['A'], z['B']) - float(z['pa_mpjpe'])) < 1e-9
+
+
+def test_general_preprocess_chain_matches_reference():
+    """oracle.preprocess_pose2d == the reference's bbox/affine/flip/normalise chain run as it is on 48 random detections with
+    rotations and flips (tests/golden/preprocess_chain.npz), including the boxes process_bbox rejects (None)."""
+    z = load_golden('preprocess_chain')
+    fp = [tuple(p) for p in z['flip_pairs']]
+    for i in range(len(z['rot'])):
+        o = go.preprocess_pose2d(z['joints'][i], z['rot'][i], bool(z['flip'][i]), fp)
+        if z['valid'][i] == 0:
+            assert o is None
+        else:
+            assert np.abs(o - z['pose2d'][i]).max() < 1e-6, i
+    # rot = 0, no flip: the chain reduces to plain standardisation (what gator_preprocess_pose2d_f32 computes)
+    i = int(np.flatnonzero((z['rot'] == 0) & (z['flip'] == 0) & (z['valid'] == 1))[0])
+    assert np.abs(go.preprocess_pose2d(z['joints'][i]) - go.normalise_pose2d(z['joints'][i])).max() < 5e-6

@@ -261,6 +261,52 @@ def demo_preprocess_golden():
     print('demo: normalised rows 0-3', ji[:4].round(4).tolist(), 'min %.4f max %.4f' % (ji.min(), ji.max()))
 
 
+COCO19_FLIP_PAIRS = ((1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12), (13, 14), (15, 16))     # data/PW3D/dataset.py:33-34
+
+
+def preprocess_chain_golden():
+    """The GENERAL input chain run as it is (lib/coord_utils.py:21-66, lib/aug_utils.py:51-64,140-179; call order of
+    data/PW3D/dataset.py:236-250): random 19-joint detections, rotation in +-30 degrees, random flips, plus boxes that
+    process_bbox rejects (None)."""
+    scratch = tempfile.mkdtemp(prefix='gator_golden_')
+    install_shims(scratch, True)
+    for m in [k for k in sys.modules if k in ('coord_utils', 'aug_utils')]:
+        del sys.modules[m]
+    import aug_utils
+    import coord_utils
+    rs = np.random.RandomState(777)
+    N, J = 48, 19
+    joints = np.zeros((N, J, 2), np.float64)
+    rot = np.zeros(N)
+    flip = np.zeros(N, np.int32)
+    out = np.zeros((N, J, 2), np.float32)
+    valid = np.ones(N, np.int32)
+    for i in range(N):
+        c = rs.rand(2) * np.array([1200, 800]) + 100
+        ext = np.array([rs.rand() * 300 + 20, rs.rand() * 500 + 40]) * (0.3 + rs.rand())
+        joints[i] = c + (rs.rand(J, 2) - 0.5) * ext
+        if i % 3:
+            rot[i] = np.clip(rs.randn() * 30, -60, 60)
+        flip[i] = int(i % 4 == 1)
+        if i in (7, 23):
+            joints[i] = joints[i, :1]                       # all joints coincide: w = h = 0
+        if i == 31:
+            joints[i, :, 0] = joints[i, 0, 0] + np.linspace(0, 0.5, J)      # narrower than one pixel
+        bbox = coord_utils.get_bbox(joints[i])
+        bbox = coord_utils.process_bbox(bbox.copy())
+        if bbox is None:
+            valid[i] = 0
+            continue
+        ji, _ = aug_utils.j2d_processing(joints[i].copy(), (288, 384), bbox, rot[i], int(flip[i]), COCO19_FLIP_PAIRS)
+        ji = ji[:, :2]
+        ji /= np.array([[288, 384]])
+        mean, std = np.mean(ji, axis=0), np.std(ji, axis=0)
+        out[i] = (ji.copy() - mean) / std
+    np.savez(os.path.join(OUT, 'preprocess_chain.npz'), joints=joints, rot=rot, flip=flip, flip_pairs=np.array(COCO19_FLIP_PAIRS, np.int32),
+             pose2d=out, valid=valid)
+    print('preprocess chain: %d samples, %d rejected by process_bbox' % (N, int((valid == 0).sum())))
+
+
 def rigid_align_golden():
     """lib/coord_utils.py:127-149 run as it is: random, mirrored (det < 0 branch), near-coplanar and scaled point sets, plus the
     PA-MPJPE reduction of data/PW3D/dataset.py:337-375 (per-sample rigid_align on the 14 evaluation joints, mean distance)."""
@@ -305,3 +351,5 @@ if __name__ == '__main__':
         run_variant('h36m17_bn', 17, False, seed=0, B=64, upsample_gain=1.0, subset=sub, out_name='scale_gain10')
     if not only or 'rigid' in only:
         rigid_align_golden()
+    if not only or 'preprocess' in only:
+        preprocess_chain_golden()
