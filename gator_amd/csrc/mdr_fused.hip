@@ -67,6 +67,35 @@ __device__ __forceinline__ void layernorm64(const f32x16 (&x)[2], const float* _
     y[1] = d1 * rstd * load_chanvec_S(w, 32, h) + load_chanvec_S(b, 32, h);
 }
 
+// per-channel vector from the workgroup's LDS table (k_mdr_layer): 4 ds_read_b128 with two distinct addresses each, against 32
+// scalar loads + 16 v_mov + 16 v_cndmask for the scalar-cache form -- 30 such vectors per tile were 9 % of the kernel's VALU work
+__device__ __forceinline__ f32x16 chanvec_lds(const float* V, int off, int h) {
+    f32x16 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(V + off + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * g + j] = t[j];
+    }
+    return v;
+}
+__device__ __forceinline__ void layernorm64_L(const f32x16 (&x)[2], const float* w, const float* b, int h, f32x16 (&y)[2]) {
+    const float mean = row_sum64(x[0], x[1]) * (1.0f / 64.0f);
+    f32x16 d0 = x[0] - mean, d1 = x[1] - mean;
+    const float var = row_sum64(d0 * d0, d1 * d1) * (1.0f / 64.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    y[0] = d0 * rstd * chanvec_lds(w, 0, h) + chanvec_lds(b, 0, h);
+    y[1] = d1 * rstd * chanvec_lds(w, 32, h) + chanvec_lds(b, 32, h);
+}
+__device__ __forceinline__ void custom_ln64_L(f32x16 (&x)[2], const float* a2, const float* b2, int h) {
+    const float mean = row_sum64(x[0], x[1]) * (1.0f / 64.0f);
+    f32x16 d0 = x[0] - mean, d1 = x[1] - mean;
+    const float std = sqrtf(row_sum64(d0 * d0, d1 * d1) * (1.0f / 63.0f));
+    const float inv = 1.0f / (std + 1e-6f);
+    x[0] = chanvec_lds(a2, 0, h) * d0 * inv + chanvec_lds(b2, 0, h);
+    x[1] = chanvec_lds(a2, 32, h) * d1 * inv + chanvec_lds(b2, 32, h);
+}
+
 // Annotated-Transformer LayerNorm: a_2 * (x - mean) / (std_unbiased + 1e-6) + b_2
 __device__ __forceinline__ void custom_ln64(f32x16 (&x)[2], const float* __restrict__ a2, const float* __restrict__ b2, int h) {
     const float mean = row_sum64(x[0], x[1]) * (1.0f / 64.0f);
@@ -387,6 +416,23 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
             for (int j = 0; j < 4; ++j) v[i >> 2][4 * (i & 3) + j] = t4[j];
         }
     };
+    // per-channel vectors of this launch (biases, norm weights) staged once per workgroup
+    enum { VO_SA3B = 0, VO_N1W = 64, VO_N1B = 128, VO_PROJB = 192, VO_N2W = 256, VO_N2B = 320, VO_FC2B = 384, VO_A2 = 448, VO_B2 = 512,
+           VO_SA0B = 576, VO_SA1B = 640, VO_HEADB = 704, VO_FC1B = 768, VO_TOKW3 = 1024, VO_TOTAL = 1216 };
+    __shared__ __attribute__((aligned(16))) float VT[VO_TOTAL];
+    for (int e = threadIdx.x; e < VO_TOTAL / 4; e += 256) {
+        const int off = 4 * e;
+        const float* src = nullptr;
+        if (off < VO_N1W) { if (MODE > 0) src = a.prev.sa3_b + off; }
+        else if (off >= VO_HEADB && off < VO_HEADB + 32) { if (MODE == 2) src = a.head_b + (off - VO_HEADB); }
+        else if (off >= VO_TOKW3) { if (MODE == 0) src = a.tok_w3 + (off - VO_TOKW3); }
+        else if (MODE < 2 && off < VO_HEADB) {
+            const float* tab[10] = {a.cur.n1w, a.cur.n1b, a.cur.proj_b, a.cur.n2w, a.cur.n2b, a.cur.fc2_b, a.cur.a2, a.cur.b2, a.cur.sa0_b, a.cur.sa1_b};
+            src = tab[(off - VO_N1W) >> 6] + (off & 63);
+        } else if (MODE < 2 && off >= VO_FC1B && off < VO_TOKW3) src = a.cur.fc1_b + (off - VO_FC1B);
+        if (src) reinterpret_cast<f32x4*>(VT)[e] = *reinterpret_cast<const f32x4*>(src);
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int id = xcd_remap(blockIdx.x, nwg) * 4 + wave;
     if (id >= a.B * kVT) return;
@@ -426,9 +472,9 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             f32x16 v = load_block(a.tok_base + ((size_t)t * 2 + nb) * kTile, lane);
-            v += load_chanvec_S(a.tok_w3, 32 * nb, h) * x0;
-            v += load_chanvec_S(a.tok_w3 + 64, 32 * nb, h) * x1;
-            v += load_chanvec_S(a.tok_w3 + 128, 32 * nb, h) * x2;
+            v += chanvec_lds(VT, VO_TOKW3 + 32 * nb, h) * x0;
+            v += chanvec_lds(VT, VO_TOKW3 + 64 + 32 * nb, h) * x1;
+            v += chanvec_lds(VT, VO_TOKW3 + 128 + 32 * nb, h) * x2;
             vf[nb] = v;
         }
     } else {
@@ -457,10 +503,10 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         MDR_STAMP(0)
         // linears[-1] + residual (vanilla_transformer_encoder.py:94, MDR.py:143)
         const Act attx[2] = {mk<X>(att[0]), mk<X>(att[1])};
-        const f32x16 y0 = lin2_T(A, attx, load_chanvec_S(a.prev.sa3_b, 0, h));
+        const f32x16 y0 = lin2_T(A, attx, chanvec_lds(VT, VO_SA3B, h));
         if (MODE == 1) A = ldw<X>(w.wq, 0, 1, lane); else A = ldw<X>(a.head_w, 0, 1, lane);
         MDR_PIN();
-        const f32x16 y1 = lin2_T(B, attx, load_chanvec_S(a.prev.sa3_b, 32, h));
+        const f32x16 y1 = lin2_T(B, attx, chanvec_lds(VT, VO_SA3B + 32, h));
         if (MODE == 1) B = ldw<X>(w.wq, 2, 3, lane);
         MDR_PIN();
         vf[0] += y0;
@@ -479,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
                 }
         }
         const Act vfx[2] = {mk<X>(vf[0]), mk<X>(vf[1])};
-        const f32x16 acc = lin2_T(A, vfx, load_chanvec_S(a.head_b, 0, h));
+        const f32x16 acc = lin2_T(A, vfx, chanvec_lds(VT, VO_HEADB, h));
         if (token < kV) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -498,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         Act fz[2];
         {
             f32x16 fzf[2];
-            layernorm64(vf, w.n1w, w.n1b, h, fzf);
+            layernorm64_L(vf, VT + VO_N1W, VT + VO_N1B, h, fzf);
             fz[0] = mk<X>(fzf[0]);
             fz[1] = mk<X>(fzf[1]);
         }
@@ -512,10 +558,10 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
 #pragma unroll
         for (int hd = 0; hd < 2; ++hd) o[hd] = cross_attention_head(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], a.J, lane);
         const Act ox[2] = {mk<X>(o[0]), mk<X>(o[1])};
-        const f32x16 y0 = lin2_T(A, ox, load_chanvec_S(w.proj_b, 0, h));
+        const f32x16 y0 = lin2_T(A, ox, chanvec_lds(VT, VO_PROJB, h));
         A = ldw<X>(w.fc1, 0, 1, lane);                                            // MLP chunk 0: fc1 rows 0..31
         MDR_PIN();
-        const f32x16 y1 = lin2_T(B, ox, load_chanvec_S(w.proj_b, 32, h));
+        const f32x16 y1 = lin2_T(B, ox, chanvec_lds(VT, VO_PROJB + 32, h));
         B = ldw<X>(w.fc2, 0, 8, lane);                                            //              fc2 columns 0..31, both row blocks
         MDR_PIN();
         vf[0] += y0;
@@ -527,28 +573,27 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         Act y2[2];
         {
             f32x16 y2f[2];
-            layernorm64(vf, w.n2w, w.n2b, h, y2f);
+            layernorm64_L(vf, VT + VO_N2W, VT + VO_N2B, h, y2f);
             y2[0] = mk<X>(y2f[0]);
             y2[1] = mk<X>(y2f[1]);
         }
         if constexpr (X) {      // the residual stream waits in LDS while the MLP needs the registers
             park_vf(vf);
         }
-        acc2[0][0] = load_chanvec_S(w.fc2_b, 0, h);
-        acc2[1][0] = load_chanvec_S(w.fc2_b, 32, h);
+        acc2[0][0] = chanvec_lds(VT, VO_FC2B, h);
+        acc2[1][0] = chanvec_lds(VT, VO_FC2B + 32, h);
         acc2[0][1] = zero16();
         acc2[1][1] = zero16();
 #pragma unroll 1
         for (int c = 0; c < 8; ++c) {           // 256 hidden units in 8 chunks of 32: fc1 -> GELU -> fc2 partial
             f32x16 hdn;
             if constexpr (X) {      // bias after the products: its scalar loads fly during the MFMAs instead of in front of them
-                const SVec b1 = chanvec_issue(w.fc1_b, 32 * c);
                 hdn = lin2_T(A, y2, zero16());
                 if (c < 7) A = ldw<X>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<X>(w.sa0, 0, 1, lane);
                 MDR_PIN();
-                hdn += chanvec_select(b1, h);
+                hdn += chanvec_lds(VT, VO_FC1B + 32 * c, h);
             } else {
-                hdn = lin2_T(A, y2, load_chanvec_S(w.fc1_b, 32 * c, h));
+                hdn = lin2_T(A, y2, chanvec_lds(VT, VO_FC1B + 32 * c, h));
                 if (c < 7) A = ldw<X>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<X>(w.sa0, 0, 1, lane);
                 MDR_PIN();
             }
@@ -573,16 +618,16 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         }
     }
     MDR_STAMP(3)
-    custom_ln64(vf, w.a2, w.b2, h);                                           // MDR.py:142 self.norm
+    custom_ln64_L(vf, VT + VO_A2, VT + VO_B2, h);                                           // MDR.py:142 self.norm
     store_block(a.vf_out + (tile + 0) * kTile, lane, vf[0]);
     store_block(a.vf_out + (tile + 1) * kTile, lane, vf[1]);
     // ---- in-projections of the self-attention (vanilla_transformer_encoder.py:87-89) in the consumer's operand order ----
     {
         const Act vfx[2] = {mk<X>(vf[0]), mk<X>(vf[1])};
-        f32x16 y0 = lin2_T(A, vfx, load_chanvec_S(w.sa0_b, 0, h));
+        f32x16 y0 = lin2_T(A, vfx, chanvec_lds(VT, VO_SA0B, h));
         A = ldw<X>(w.sa1, 0, 1, lane);
         MDR_PIN();
-        f32x16 y1 = lin2_T(B, vfx, load_chanvec_S(w.sa0_b, 32, h));
+        f32x16 y1 = lin2_T(B, vfx, chanvec_lds(VT, VO_SA0B + 32, h));
         B = ldw<X>(w.sa1, 2, 3, lane);
         MDR_PIN();
         if constexpr (X) {      // the consumer's softmax works in the exp2 domain: fold log2(e) / sqrt(d_k) into Q once, here
@@ -592,10 +637,10 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         }
         st_op<XA>(a.q_out + (tile + 0) * TQ, lane, y0);
         st_op<XA>(a.q_out + (tile + 1) * TQ, lane, y1);
-        y0 = lin2_T(A, vfx, load_chanvec_S(w.sa1_b, 0, h));
+        y0 = lin2_T(A, vfx, chanvec_lds(VT, VO_SA1B, h));
         A = ldw<X>(w.sa2, 0, 1, lane);
         MDR_PIN();
-        y1 = lin2_T(B, vfx, load_chanvec_S(w.sa1_b, 32, h));
+        y1 = lin2_T(B, vfx, chanvec_lds(VT, VO_SA1B + 32, h));
         B = ldw<X>(w.sa2, 2, 3, lane);
         const float bv0 = w.sa2_b[lane & 31], bv1 = w.sa2_b[32 + (lane & 31)];
         MDR_PIN();
