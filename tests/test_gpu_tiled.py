@@ -103,3 +103,22 @@ def test_shipped_policy_b2048(monkeypatch):
     z, m1 = _model(monkeypatch, 'h36m17_bn', '0')
     v1, _ = m1(x[1792:].contiguous())
     assert torch.equal(v1, v[1792:])                             # the k_gat remainder
+
+
+def test_config4_single_process_b8192(monkeypatch):
+    """BASELINE config 4's single-process counterpart: B=8192 Human3.6M poses in ONE call (what the 8-GPU all-gather of 1024-sample
+    shards must reproduce up to the encoder-kernel choice): finite, deterministic, sampled accuracy against the fp64 oracle, and a
+    1024-sample shard agrees with the same rows of the big batch to fp32 noise (bitwise when both sit on the tiled encoder)."""
+    from oracle import gator_oracle as go
+    z, m = _model(monkeypatch, 'h36m17_bn', None)
+    zz, c, sd = oracle_setup('h36m17_bn')
+    x = torch.from_numpy(synthetic.synthetic_pose2d(8192, 17, seed=2024)).cuda()
+    v, p = m(x)
+    v2, _ = m(x)
+    assert torch.equal(v, v2) and bool(torch.isfinite(v).all())
+    idx = [0, 1023, 1024, 4095, 7167, 7168, 8191]
+    ref, rp = go.gator_forward(sd, c, x[idx].cpu(), torch.float64)
+    assert np.abs(v[idx].cpu().numpy().astype(np.float64) - ref.numpy()).max() * 1e3 <= 1e-3
+    vs, ps = m(x[3072:4096].contiguous())                        # rank 3's shard of an 8-way split
+    assert torch.equal(vs, v[3072:4096]) and torch.equal(ps, p[3072:4096])     # both run entirely on the tiled encoder
+    del v, v2
