@@ -233,9 +233,9 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
     int gk = 0;                                                              // next group to begin (global order, bi * 62 + g)
     // Weight stream: LDS-DMA two groups ahead.  Every wave copies 6 of a group's 24 pieces (1 KiB each).  All workgroups walk the
     // same 9.5 MB in step, so each group is an L2 miss for everybody at once (Infinity-Cache latency, 1-2 us under load): with
-    // one group of lead the copy was 0.5 of 1.2 ms at B=1024, with two 0.2 of 0.94 ms -- what is left is the ~150 issue cycles
-    // of each global_load_lds.  (Register staging -- plain loads, ds_write_b128 a group later -- issues 7x cheaper but needs a
-    // second 24-register set for the same lead; with one set it measured 1.08 ms.)
+    // one group of lead the copy was 0.5 of 1.2 ms at B=1024; with two it is hidden (issuing the copies in front of the group or
+    // one tile's worth after each tile's MFMAs measures the same).  Register staging (plain loads, ds_write_b128 a group later)
+    // needs a second 24-register set for the same lead; with one set it measured 1.08 ms.
     auto issue = [&](int k) {
         if (k >= kDepth * kGroupsPerBlock) return;
         const float* tl[kGrpTiles];
