@@ -58,7 +58,10 @@ def check(remarks_by_source):
             short = short_name(names.get(mangled, mangled))
             rows.append((source, short, f.get('VGPRs', 0), f.get('AGPRs', 0), f.get('TotalSGPRs', 0),
                          f.get('ScratchSize', 0), f.get('Occupancy', 0), f.get('LDS Size', 0)))
-            if f.get('ScratchSize', 0) > 0 and any(short.startswith(h) for h in HOT):
+            hot = any(short.startswith(h) for h in HOT)
+            if short.startswith('_Z'):           # c++filt could not demangle it (e.g. __bf16 parameters): match the bare kernel name
+                hot = any(re.search(r'\d+%s(?![a-z_])' % re.escape(h.split('<')[0]), short) for h in HOT)
+            if f.get('ScratchSize', 0) > 0 and hot:
                 bad.append('%s: %s spills %d bytes/lane to scratch' % (source, short, f['ScratchSize']))
     if bad:
         raise RuntimeError('register spills in hot kernels:\n  ' + '\n  '.join(bad))
