@@ -235,16 +235,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get('GATOR_BENCH_FORCE_DIST') == '1'      # exercise the N>1 code path (RCCL, side stream, `comm`) with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # backend "nccl" == RCCL on ROCm
     from gator_amd import synthetic
     from gator_amd.parallel import ShardedForward
     J, B = a.joints, a.batch
     model, base, alpha = build_model(J, a.impl, dev)
     model.precision = a.precision
-    runner = ShardedForward(model, world, rank, dist, mode=a.mode)
+    runner = ShardedForward(model, world, rank, dist, mode=a.mode, always_gather=force_dist)
     x = torch.from_numpy(synthetic.synthetic_pose2d(B, J, seed=1000 + rank)).to(dev)     # this rank's shard, resident in HBM
     target = None
     if a.mode == 'eval':      # config 5: synthetic ground-truth joints for the on-device MPJPE / PA-MPJPE sums
@@ -283,7 +285,7 @@ def main():
     if a.mode == 'gather':
         assert out[0].shape == (B * world, 6890, 3)
     comm = None
-    if world > 1:            # outside the timed region: what the collective costs alone, and how much of it the overlap hides
+    if world > 1 or force_dist:   # outside the timed region: what the collective costs alone, and how much of it the overlap hides
         dt_c, _ = block(lambda: model(x), a.steps)
         dt_g, _ = block(lambda: runner.comm_only(), a.steps)
         c_ms, g_ms, t_ms = dt_c / a.steps * 1e3, dt_g / a.steps * 1e3, dt / a.steps * 1e3
