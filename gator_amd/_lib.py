@@ -42,6 +42,7 @@ SIGNATURES = {
     'gator_forward_joints_f32': (_I, [_P, _P, _I, _P, _P, _P, _P]),
     'gator_preprocess_pose2d_f32': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'gator_preprocess_chain_f32': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    'gator_joint_errors_f32': (_I, [_P, _P, _I, _I, _P, _I, _I, ctypes.c_float, _P, _P]),
     'gator_rigid_align_f32': (_I, [_P, _P, _I, _I, _P, _P]),
     'gator_comm_unique_id': (_I, [_P]),
     'gator_comm_create': (_I, [_P, _I, _I, ctypes.POINTER(_P)]),

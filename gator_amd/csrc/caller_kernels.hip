@@ -81,30 +81,27 @@ __device__ void svd3(const double H[3][3], double U[3][3], double s[3], double V
 
 // rigid_transform_3D + rigid_align (lib/coord_utils.py:127-149): H = (A-ca)^T (B-cb) / n = U S V^T; R = V U^T, with the reflection
 // fix (det R < 0: s3 := -s3, V[:,2] := -V[:,2]); c = sum(s) / sum_axis var(A); t = -(cR) ca + cb; out = cR A + t.
-__global__ void k_rigid_align(const float* __restrict__ A, const float* __restrict__ Bt, int nb, int n, float* __restrict__ out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    const float* a = A + (size_t)b * n * 3;
-    const float* t = Bt + (size_t)b * n * 3;
+// similarity (Procrustes) fit of n points a onto t, fp64: aligned = c R a + tr   (lib/coord_utils.py:127-142)
+__device__ void rigid_fit(const double (*a)[3], const double (*t)[3], int n, double& c, double (&R)[3][3], double (&tr)[3]) {
     double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
     for (int i = 0; i < n; ++i)
-        for (int k = 0; k < 3; ++k) { ca[k] += a[i * 3 + k]; cb[k] += t[i * 3 + k]; }
+        for (int k = 0; k < 3; ++k) { ca[k] += a[i][k]; cb[k] += t[i][k]; }
     for (int k = 0; k < 3; ++k) { ca[k] /= n; cb[k] /= n; }
     double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, var = 0.0;
     for (int i = 0; i < n; ++i) {
         double da[3], db[3];
-        for (int k = 0; k < 3; ++k) { da[k] = a[i * 3 + k] - ca[k]; db[k] = t[i * 3 + k] - cb[k]; var += da[k] * da[k]; }
+        for (int k = 0; k < 3; ++k) { da[k] = a[i][k] - ca[k]; db[k] = t[i][k] - cb[k]; var += da[k] * da[k]; }
         for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) H[r][c] += da[r] * db[c];
+            for (int cc = 0; cc < 3; ++cc) H[r][cc] += da[r] * db[cc];
     }
     for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) H[r][c] /= n;
+        for (int cc = 0; cc < 3; ++cc) H[r][cc] /= n;
     var /= n;
-    double U[3][3], s[3], V[3][3], R[3][3];
+    double U[3][3], s[3], V[3][3];
     svd3(H, U, s, V);
     auto mkR = [&]() {
         for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) R[r][c] = V[r][0] * U[c][0] + V[r][1] * U[c][1] + V[r][2] * U[c][2];
+            for (int cc = 0; cc < 3; ++cc) R[r][cc] = V[r][0] * U[cc][0] + V[r][1] * U[cc][1] + V[r][2] * U[cc][2];
     };
     mkR();
     const double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) - R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
@@ -114,13 +111,63 @@ __global__ void k_rigid_align(const float* __restrict__ A, const float* __restri
         for (int r = 0; r < 3; ++r) V[r][2] = -V[r][2];
         mkR();
     }
-    const double c = (s[0] + s[1] + s[2]) / var;
-    double tr[3];
+    c = (s[0] + s[1] + s[2]) / var;
     for (int r = 0; r < 3; ++r) tr[r] = cb[r] - c * (R[r][0] * ca[0] + R[r][1] * ca[1] + R[r][2] * ca[2]);
+}
+
+constexpr int kMaxPts = 32;
+__global__ void k_rigid_align(const float* __restrict__ A, const float* __restrict__ Bt, int nb, int n, float* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const float* a = A + (size_t)b * n * 3;
+    const float* t = Bt + (size_t)b * n * 3;
+    double pa[kMaxPts][3], pt[kMaxPts][3];
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) { pa[i][k] = a[i * 3 + k]; pt[i][k] = t[i * 3 + k]; }
+    double c, R[3][3], tr[3];
+    rigid_fit(pa, pt, n, c, R, tr);
     float* o = out + (size_t)b * n * 3;
     for (int i = 0; i < n; ++i)
         for (int r = 0; r < 3; ++r)
-            o[i * 3 + r] = (float)(c * (R[r][0] * a[i * 3] + R[r][1] * a[i * 3 + 1] + R[r][2] * a[i * 3 + 2]) + tr[r]);
+            o[i * 3 + r] = (float)(c * (R[r][0] * pa[i][0] + R[r][1] * pa[i][1] + R[r][2] * pa[i][2]) + tr[r]);
+}
+
+// Per-sample evaluation errors in one launch (data/PW3D/dataset.py:273-286, 337-375): err[b][0] = mean distance of the root-aligned
+// evaluation joints (MPJPE), err[b][1] = the same after the similarity alignment of the evaluation joints (PA-MPJPE).
+__global__ void k_joint_errors(const float* __restrict__ P, const float* __restrict__ T, int nb, int nj, const int32_t* __restrict__ idx, int ne,
+                               int root, float scale, float* __restrict__ err) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const float* p = P + (size_t)b * nj * 3;
+    const float* t = T + (size_t)b * nj * 3;
+    double pa[kMaxPts][3], pt[kMaxPts][3];
+    double e0 = 0.0;
+    for (int i = 0; i < ne; ++i) {
+        const int j = idx ? idx[i] : i;
+        double d2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            // float32 arithmetic where the reference has it: mesh * 1000, pred - pred[root], target - target[root], their difference
+            const float pj = p[j * 3 + k] * scale, pr = p[root * 3 + k] * scale;
+            const float dp = pj - pr, dt = t[j * 3 + k] - t[root * 3 + k];
+            pa[i][k] = dp; pt[i][k] = dt;
+            const float d = dp - dt;
+            d2 += (double)d * (double)d;
+        }
+        e0 += sqrt(d2);
+    }
+    double c, R[3][3], tr[3];
+    rigid_fit(pa, pt, ne, c, R, tr);
+    double e1 = 0.0;
+    for (int i = 0; i < ne; ++i) {
+        double d2 = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            const double al = (double)(float)(c * (R[r][0] * pa[i][0] + R[r][1] * pa[i][1] + R[r][2] * pa[i][2]) + tr[r]);
+            d2 += (al - pt[i][r]) * (al - pt[i][r]);
+        }
+        e1 += sqrt(d2);
+    }
+    err[b * 2] = (float)(e0 / ne);
+    err[b * 2 + 1] = (float)(e1 / ne);
 }
 
 }  // namespace
@@ -242,8 +289,20 @@ extern "C" int gator_preprocess_pose2d_f32(const float* joints, int32_t batch, i
     return GATOR_OK;
 }
 
+extern "C" int gator_joint_errors_f32(const float* pred_joints, const float* target_joints, int32_t batch, int32_t n_joint,
+                                      const int32_t* eval_joints, int32_t n_eval, int32_t root, float pred_scale, float* errors, void* stream) {
+    using namespace gator;
+    if (!pred_joints || !target_joints || !errors || batch <= 0 || n_joint <= 0 || root < 0 || root >= n_joint)
+        return fail(GATOR_EINVAL, "gator_joint_errors_f32: bad arguments");
+    const int ne = eval_joints ? n_eval : n_joint;
+    if (ne < 3 || ne > 32) return fail(GATOR_EINVAL, "gator_joint_errors_f32: 3..32 evaluation joints");
+    k_joint_errors<<<(batch + 63) / 64, 64, 0, (hipStream_t)stream>>>(pred_joints, target_joints, batch, n_joint, eval_joints, ne, root, pred_scale, errors);
+    GATOR_HIP_CHECK(hipGetLastError());
+    return GATOR_OK;
+}
+
 extern "C" int gator_rigid_align_f32(const float* a, const float* b, int32_t batch, int32_t n_points, float* aligned, void* stream) {
-    if (!a || !b || !aligned || batch <= 0 || n_points < 3) return fail(GATOR_EINVAL, "gator_rigid_align_f32: bad arguments");
+    if (!a || !b || !aligned || batch <= 0 || n_points < 3 || n_points > 32) return fail(GATOR_EINVAL, "gator_rigid_align_f32: bad arguments (3..32 points)");
     k_rigid_align<<<(batch + 63) / 64, 64, 0, (hipStream_t)stream>>>(a, b, batch, n_points, aligned);
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;

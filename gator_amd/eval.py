@@ -79,3 +79,19 @@ def pa_mpjpe(pred_joint, target_joint, eval_joints=H36M_EVAL_JOINTS):
     idx = torch.as_tensor(eval_joints, device=pred_joint.device)
     p, t = pred_joint[:, idx], target_joint[:, idx]
     return torch.sqrt(((rigid_align(p, t) - t) ** 2).sum(2)).mean()
+
+
+def joint_errors(pred_joint, target_joint, eval_joints=H36M_EVAL_JOINTS, root=0, pred_scale=1.0):
+    """Per-sample (MPJPE, PA-MPJPE) in one launch (gator_joint_errors_f32): pred_joint [B,nj,3] (multiplied by pred_scale on the fly:
+    1000 for metres -> mm), target_joint [B,nj,3] -> [B,2].  mpjpe()/pa_mpjpe() above are its two columns averaged over the batch."""
+    if not (pred_joint.is_cuda and target_joint.is_cuda):
+        raise RuntimeError('joint_errors: inputs must live on a HIP device')
+    p, t = pred_joint.contiguous().float(), target_joint.contiguous().float()
+    B, nj = p.shape[0], p.shape[1]
+    out = torch.empty((B, 2), device=p.device, dtype=torch.float32)
+    idx = None if eval_joints is None else torch.as_tensor(list(eval_joints), dtype=torch.int32, device=p.device)
+    st = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+    _lib.check(_lib.load().gator_joint_errors_f32(p.data_ptr(), t.data_ptr(), B, nj, idx.data_ptr() if idx is not None else None,
+                                                  int(idx.numel()) if idx is not None else 0, int(root), float(pred_scale), out.data_ptr(), st),
+               'gator_joint_errors_f32')
+    return out

@@ -140,12 +140,12 @@ class ShardedForward:
     def _joint_metrics(self, joints_m, target, sl):
         """[sum MPJPE, sum PA-MPJPE, samples] from regressed joints in metres (gator_amd.eval, all on the device)."""
         from . import eval as ev
-        joints = joints_m * 1000.0                                      # metres -> mm (lib/core/base.py:219)
-        tgt = target[sl]
         kw = {} if self._eval_joints is None else {'eval_joints': self._eval_joints}
-        n = joints.shape[0]
-        return torch.stack([ev.mpjpe(joints, tgt, **kw) * n, ev.pa_mpjpe(joints, tgt, **kw) * n,
-                            torch.tensor(float(n), device=joints.device)]).double()
+        err = ev.joint_errors(joints_m, target[sl], pred_scale=1000.0, **kw)     # metres -> mm (lib/core/base.py:219); one launch
+        n = err.shape[0]
+        if getattr(self, '_count', None) is None or self._count[0] != n or self._count[1].device != err.device:
+            self._count = (n, torch.tensor([float(n)], device=err.device, dtype=torch.float64))
+        return torch.cat([err.double().sum(0), self._count[1]])
 
     def _device_metrics(self, verts, pose3d, target, sl):
         """Same from materialised vertices (models without the fused joint-regression epilogue)."""

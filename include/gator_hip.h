@@ -160,6 +160,14 @@ int gator_comm_destroy(gator_comm* comm);
 int gator_allgather_verts(gator_comm* comm, const float* verts_local, const float* pose3d_local /* or NULL */, int32_t batch_local,
                           int32_t num_joint, float* verts_all, float* pose3d_all /* or NULL */, void* stream);
 
+/* Evaluation errors of a batch in ONE launch (data/PW3D/dataset.py:273-286 compute_both_err, :337-375 PA alignment):
+ *   pred_joints [B,n_joint,3] (scaled by pred_scale, e.g. 1000 for metres -> mm, lib/core/base.py:219), target_joints [B,n_joint,3];
+ *   eval_joints: n_eval joint indices (device) or NULL for all; root: the joint both sets are aligned to.
+ *   errors [B,2]: per sample (MPJPE, PA-MPJPE) = mean joint distance after root alignment, resp. after the similarity alignment of
+ *   the evaluation joints; the caller averages over samples (or all-reduces the sums: gator_amd.parallel, mode='eval'). */
+int gator_joint_errors_f32(const float* pred_joints, const float* target_joints, int32_t batch, int32_t n_joint,
+                           const int32_t* eval_joints, int32_t n_eval, int32_t root, float pred_scale, float* errors, void* stream);
+
 /* Host-side graph constants (no GPU needed).  Replace the absent Cython algos.pyx
  * (lib/models/backbones/setup.py:1-6) and lib/models/backbones/modules.py:6-29, lib/graph_utils.py:71-89. */
 int gator_floyd_warshall(const float* adj, int32_t n, int64_t* dist, int64_t* path);

@@ -133,3 +133,31 @@ def test_eval_mode_b2048_without_vertices():
     e_ref = go.mpjpe(rj, tgt[sl].cpu().numpy().astype(np.float64), list(geval.H36M_EVAL_JOINTS))
     e_got = float(geval.mpjpe(j_f * 1000.0, tgt[sl]))
     assert abs(e_ref - e_got) < 1e-3
+
+
+def test_fused_joint_errors_kernel():
+    """gator_joint_errors_f32 (per-sample MPJPE and PA-MPJPE in one launch) == the numpy oracle (data/PW3D/dataset.py:273-286 and the
+    per-sample Procrustes loop :337-375) and == the separate device functions, incl. the reference's rigid_align golden sets."""
+    from oracle import gator_oracle as go
+    from tests.helpers import load_golden
+    rs = np.random.RandomState(8)
+    B = 70
+    pred = (rs.randn(B, 17, 3) * 0.2).astype(np.float32)                   # metres
+    tgt = (pred * 1000 + rs.randn(B, 17, 3) * 40).astype(np.float32)        # mm
+    pred[3] = pred[3][:, [0, 1, 2]] * np.array([1, 1, 1e-4], np.float32)    # nearly coplanar
+    err = geval.joint_errors(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), pred_scale=1000.0).cpu().numpy().astype(np.float64)
+    ev = list(geval.H36M_EVAL_JOINTS)
+    for b in (0, 3, 17, 69):
+        p64 = (pred[b] * np.float32(1000)).astype(np.float64)
+        want0 = go.mpjpe(p64[None], tgt[b][None].astype(np.float64), ev)
+        pr, tr = p64 - p64[0:1], tgt[b].astype(np.float64) - tgt[b][0:1].astype(np.float64)
+        want1 = go.pa_mpjpe(pr[None], tr[None], ev)
+        assert abs(err[b, 0] - want0) <= 2e-5 * max(1.0, want0) and abs(err[b, 1] - want1) <= 2e-5 * max(1.0, want1), (b, err[b], want0, want1)
+    mm = torch.from_numpy(pred).cuda() * 1000.0
+    assert abs(float(geval.mpjpe(mm, torch.from_numpy(tgt).cuda())) - err[:, 0].mean()) < 1e-3
+    assert abs(float(geval.pa_mpjpe(mm, torch.from_numpy(tgt).cuda())) - err[:, 1].mean()) < 1e-3
+    z = load_golden('rigid_align')                                          # the reference's own alignments: all 14 points, root 0
+    a, b = z['A'].astype(np.float32), z['B'].astype(np.float32)
+    e = geval.joint_errors(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), eval_joints=None).cpu().numpy()
+    want = np.array([np.sqrt((((o - o[0]) * 0 + (go.rigid_align(x - x[0], y - y[0]) - (y - y[0]))) ** 2).sum(1)).mean() for x, y, o in zip(z['A'], z['B'], z['aligned'])])
+    assert np.abs(e[:, 1] - want).max() <= 1e-4 * want.max()
