@@ -94,17 +94,18 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
         const std::vector<float> M = d2h(r.gcn_M, (size_t)J * kC), b1 = d2h(r.xl1_b, 16);
         // C-layout tiles (channel on the lane, token in the register): tile[nb][g][lane][j] <-> token 8g+4h+j, channel 32nb+(lane&31)
         std::vector<float> mc(4 * kTile), md(4 * kTile);
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < 4; ++nb) {
             for (int g = 0; g < 4; ++g)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 4; ++j) {
                         const int tok = 8 * g + 4 * (lane >> 5) + j, n = 32 * nb + (lane & 31);
-                        const float mv = tok < J ? M[(size_t)tok * kC + n] : 0.f;
-                        mc[((nb * 4 + g) * 64 + lane) * 4 + j] = mv;
-                        md[((nb * 4 + g) * 64 + lane) * 4 + j] = tok < J ? adiag[i * J + tok] * mv : 0.f;
+                        mc[((nb * 4 + g) * 64 + lane) * 4 + j] = tok < J ? M[(size_t)tok * kC + n] : 0.f;
                     }
+            // T-layout (token on the lane, channel in the register): diag(A)[t] * M[t][n], for the token-wise h0 term
+            fill_tile(md.data() + (size_t)nb * kTile, [&](int t, int ch) { return t < J ? adiag[i * J + t] * M[(size_t)t * kC + 32 * nb + ch] : 0.f; });
+        }
         q.mc = upload(mc);
-        q.md = upload(md);
+        q.mdT = upload(md);
         std::vector<float> t1(kTile), t2(kTile);
         fill_tile(t1.data(), [&](int t, int j) { return (t < J && j < J) ? aoff[((size_t)i * J + t) * J + j] : 0.f; });
         q.aoffT = upload(t1);

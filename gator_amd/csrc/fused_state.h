@@ -15,7 +15,7 @@ struct MdrLayerP {                      // packed weights of one LBF layer (devi
 
 struct GatBlockPk {                     // packed tiles of one GATBlock
     const float *qkv, *proj, *w0, *w1, *lin0, *lin1, *back, *fc1, *fc2;
-    const float *mc, *md, *aoffT, *f1b;  // M (C-layout), diag(A).M (C-layout), offdiag(A)^T B-operand tile, hop-2 bias term
+    const float *mc, *mdT, *aoffT, *f1b; // M (channel on lane), diag(A).M (TOKEN on lane), offdiag(A)^T B-operand tile, hop-2 bias term
 };
 
 // Per-sub-batch workspace.  FusedState derives from it so kernels launchers read `f->vf` etc.; fused_forward swaps the

@@ -22,7 +22,7 @@ constexpr float kLog2eG = 1.4426950408889634f;
 struct GatBlockP {   // per-GATBlock packed tiles + reference-layout vectors
     const float *qkv, *proj, *w0, *w1, *lin0, *lin1, *back, *fc1, *fc2;      // packed [NB][KB] tile grids (fp32 tiles, or X3 tiles)
     const float* back32;                                                       // linearback always also as fp32 tiles (its 16-wide k tail)
-    const float *mc, *md, *aoffT, *f1b;                                        // packed tables (see GatTables)
+    const float *mc, *mdT, *aoffT, *f1b;                                       // packed tables: M (channel on lane), diag(A).M (token on lane), offdiag(A)^T, hop-2 bias
     const float* vecs;                                                         // V_TOTAL floats, order above
 };
 
@@ -264,9 +264,6 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
     }
     GAT_STAMP(0)
     f32x16 xw = load_block(X + wave * kTile, lane);       // this wave's block of the residual stream
-    f32x16 ident;                                          // identity as a B operand: I[t_out = lane&31][j = kap(r)+4h]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ident[r] = (kap(r) + 4 * h == (lane & 31)) ? 1.f : 0.f;
 
     // Software pipeline of the weight stream.  One wave per SIMD means nobody hides this wave's L2 latency, so the next
     // 4-tile weight group is always in flight while the current one feeds the MFMAs (rolling buffer G, see lin4r).
@@ -347,11 +344,11 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             }
             GAT_STAMP(14)
             // ---- MGCN (modules.py:243-255): h_k = y @ W[k]; out = diag(A)(M.h0) + offdiag(A)(M.h1) + bias ----
-            const f32x16 mdt = load_block(w.md + (size_t)wave * kTile, lane), mct = load_block(w.mc + (size_t)wave * kTile, lane);
+            const f32x16 mdt = load_block(w.mdT + (size_t)wave * kTile, lane), mct = load_block(w.mc + (size_t)wave * kTile, lane);
             const f32x16 aoff = load_block(w.aoffT, lane);
             const f32x16 bg = load_chanvec_L(V, V_GCNB + 32 * wave, h), bp = load_chanvec_L(V, V_PROJB + 32 * wave, h);
             GATOR_PIN();
-            f32x16 h0 = lin4r<true>(G, y, zero16(), w.w1, wave * 4, lane);
+            f32x16 h0 = lin4r<false>(G, y, zero16(), w.w1, wave * 4, lane);        // token on the lane: its term is token-wise
             GATOR_PIN();
             GAT_STAMP(15)
             f32x16 h1 = lin4r<true>(G, y, zero16(), w.proj, wave * 4, lane);
@@ -359,13 +356,9 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
             GAT_STAMP(16)
             h0 = h0 * mdt;                                                                  // diag(A)[t] * M[t][n] * h0[t][n]
             h1 = h1 * mct;                                                                  // M[t][n] * h1[t][n]
-            {
-                f32x16 gd = zero16();
-                g_out = bg;
-                // sum_j (M.h1)[j][n] * Aoff[t][j]   and   the diagonal term moved from C- to T-layout by an identity product
-                dot16x2(h1, aoff, g_out, h0, ident, gd);
-                g_out += gd;
-            }
+            // sum_j (M.h1)[j][n] * Aoff[t][j] as one MFMA product (two interleaved 8-step chains); the diagonal term needs no
+            // product: h0 was formed with the token on the lane (round 1 moved it there through an identity MFMA product, 16 of 32)
+            g_out = dot16(h1, aoff, bg) + h0;
             GAT_STAMP(17)
             __syncthreads();
             GAT_STAMP(2)
@@ -675,7 +668,7 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         q.qkv = sel(p.qkv); q.proj = sel(p.proj); q.w0 = sel(p.w0); q.w1 = sel(p.w1); q.lin0 = sel(p.lin0); q.lin1 = sel(p.lin1);
         q.back = sel(p.back); q.fc1 = sel(p.fc1); q.fc2 = sel(p.fc2);
         q.back32 = p.back;
-        q.mc = p.mc; q.md = p.md; q.aoffT = p.aoffT; q.f1b = p.f1b;
+        q.mc = p.mc; q.mdT = p.mdT; q.aoffT = p.aoffT; q.f1b = p.f1b;
         q.vecs = f->g_vecs + (size_t)i * 2048;
         (void)r;
     }
