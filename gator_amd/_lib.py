@@ -22,7 +22,7 @@ class GatorConfig(ctypes.Structure):
                 ('max_batch', ctypes.c_int32), ('parts', ctypes.c_int32), ('subbatch_streams', ctypes.c_int32)]
 
 
-# every symbol include/gator_hip.h declares: name -> (restype, argtypes)
+# every symbol include/gator_hip.h and include/gator_train.h declare: name -> (restype, argtypes)
 _P, _I, _L = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
 SIGNATURES = {
     'gator_create': (_I, [ctypes.POINTER(GatorTensor), _I, ctypes.POINTER(GatorConfig), ctypes.POINTER(_P)]),
@@ -51,6 +51,23 @@ SIGNATURES = {
     'gator_floyd_warshall': (_I, [_P, _I, _P, _P]),
     'gator_gen_edge_input': (_I, [_P, _P, _I, _I, _P]),
     'gator_verts_joints_relation': (_I, [_P, _I, _P, _I, _P]),
+    # include/gator_train.h
+    'gator_t_binary': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'gator_t_unary': (_I, [_I, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _P]),
+    'gator_t_reduce_ws_bytes': (_L, [_P, _P]),
+    'gator_t_reduce_sum': (_I, [_P, _P, _P, _P, _P, _I, _P, _P]),
+    'gator_t_gemm': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, ctypes.c_float, _I, _I, _P, _P]),
+    'gator_t_layernorm_fwd': (_I, [_P, _L, _I, _P, _P, ctypes.c_float, _I, _P, _P, _P, _P]),
+    'gator_t_layernorm_bwd': (_I, [_P, _P, _P, _P, _P, _L, _I, ctypes.c_float, _I, _P, _P, _P]),
+    'gator_t_softmax_fwd': (_I, [_P, _L, _I, _P, _P]),
+    'gator_t_softmax_bwd': (_I, [_P, _P, _L, _I, _P, _P]),
+    'gator_t_dropout': (_I, [_P, _L, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P, _P]),
+    'gator_t_mask_scale': (_I, [_P, _P, _L, ctypes.c_float, _P, _P]),
+    'gator_t_adam': (_I, [_P, _P, _P, _P, _L, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _I, _P]),
+    'gator_t_loss_ws_bytes': (_L, [_L, _L]),
+    'gator_t_coord_loss': (_I, [_P, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _P]),
+    'gator_t_normal_loss': (_I, [_P, _P, _P, _P, _P, _L, _L, _L, ctypes.c_float, _P, _P, _P, _P]),
+    'gator_t_edge_loss': (_I, [_P, _P, _P, _P, _P, _L, _L, _L, ctypes.c_float, _P, _P, _P, _P]),
     'gator_last_error': (ctypes.c_char_p, []),
     'gator_version': (ctypes.c_char_p, []),
 }

@@ -7,9 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libgator_hip.so')
-SOURCES = ['api.hip', 'basic_kernels.hip', 'fused_api.hip', 'fused_pack.hip', 'upsample_fused.hip', 'mdr_fused.hip', 'gat_fused.hip', 'gat_tiled.hip', 'gat_tail.hip', 'upsample_bf16.hip', 'upsample_x3.hip', 'caller_kernels.hip',
+SOURCES = ['api.hip', 'basic_kernels.hip', 'fused_api.hip', 'fused_pack.hip', 'upsample_fused.hip', 'mdr_fused.hip', 'gat_fused.hip', 'gat_tiled.hip', 'gat_tail.hip', 'upsample_bf16.hip', 'upsample_x3.hip', 'caller_kernels.hip', 'train_ops.hip',
            'graph_consts.cpp', 'comm_rccl.cpp']
-HEADERS = ['internal.h', os.path.join(ROOT, 'include', 'gator_hip.h')]
+HEADERS = ['internal.h', os.path.join(ROOT, 'include', 'gator_hip.h'), os.path.join(ROOT, 'include', 'gator_train.h')]
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
          '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 # Measured on gfx950 (tools/microbench/coissue.hip): up to six plain VALU instructions (v_fma_f32, v_cvt_pk_bf16_f32, v_cndmask

@@ -1,0 +1,773 @@
+// train_ops.hip -- the training row (include/gator_train.h): stride-aware fp32 primitives from which
+// gator_amd/train/ composes the reference's training step (lib/core/base.py:122-183: forward in train mode, the losses of
+// lib/core/loss.py, backward, Adam).  First correct form of the row: general kernels, exact fp32 products (the fp32-input
+// MFMA for every contraction), fixed summation orders (no atomics anywhere, so a step is bit-reproducible).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "gator_train.h"
+#include "internal.h"
+
+namespace gator {
+namespace {
+
+constexpr int kThreads = 256;
+
+struct Idx4 {
+    int64_t n[4];
+};
+struct Str4 {
+    int64_t s[4];
+};
+
+__device__ __forceinline__ int64_t offset4(int64_t i, const Idx4& n, const Str4& s) {
+    const int64_t i3 = i % n.n[3];
+    i /= n.n[3];
+    const int64_t i2 = i % n.n[2];
+    i /= n.n[2];
+    const int64_t i1 = i % n.n[1];
+    const int64_t i0 = i / n.n[1];
+    return i0 * s.s[0] + i1 * s.s[1] + i2 * s.s[2] + i3 * s.s[3];
+}
+
+// ------------------------------------------------------------------------------------------------------------ elementwise
+__global__ __launch_bounds__(kThreads) void k_t_binary(int op, const float* __restrict__ a, Str4 sa, const float* __restrict__ b, Str4 sb,
+                                                       float* __restrict__ o, Str4 so, Idx4 n, int64_t total) {
+    for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const float x = a[offset4(i, n, sa)], y = b[offset4(i, n, sb)];
+        float r;
+        switch (op) {
+            case 0: r = x + y; break;
+            case 1: r = x - y; break;
+            case 2: r = x * y; break;
+            default: r = x / y; break;
+        }
+        o[offset4(i, n, so)] = r;
+    }
+}
+
+__device__ __forceinline__ float unary_apply(int op, float x, float p0, float p1) {
+    switch (op) {
+        case 0: return p0 * x + p1;
+        case 1: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));                          // F.gelu (erf form)
+        case 2: return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+        case 3: return expf(x);
+        case 4: return 1.0f / sqrtf(x);
+        case 5: return sqrtf(x);
+        case 6: return 1.0f / x;
+        case 7: return fabsf(x);
+        case 8: return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+        case 9: return powf(p0, x);
+        case 10: return x * x;
+        default: return x > p0 ? 1.f : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_unary(int op, const float* __restrict__ x, Str4 sx, float* __restrict__ o, Str4 so, Idx4 n,
+                                                      int64_t total, float p0, float p1) {
+    for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads)
+        o[offset4(i, n, so)] = unary_apply(op, x[offset4(i, n, sx)], p0, p1);
+}
+
+// ------------------------------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {       // all threads get the total; sh: 4 doubles of LDS
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// general form: one workgroup per (output element, slice of the reduction space); the reduction index runs over the reduced
+// dims in order (last reduced dim fastest)
+__global__ __launch_bounds__(kThreads) void k_t_reduce(const float* __restrict__ x, Str4 sx, Idx4 keep, Idx4 red, int64_t R, int nsplit,
+                                                       double* __restrict__ part) {
+    __shared__ double sh[4];
+    const int64_t o = blockIdx.x;
+    const int sp = blockIdx.y;
+    Idx4 kn = keep;
+    int64_t base;
+    {
+        int64_t i = o;
+        const int64_t i3 = i % kn.n[3];
+        i /= kn.n[3];
+        const int64_t i2 = i % kn.n[2];
+        i /= kn.n[2];
+        const int64_t i1 = i % kn.n[1];
+        const int64_t i0 = i / kn.n[1];
+        base = i0 * sx.s[0] + i1 * sx.s[1] + i2 * sx.s[2] + i3 * sx.s[3];
+    }
+    const int64_t per = (R + nsplit - 1) / nsplit, r0 = sp * per, r1 = r0 + per < R ? r0 + per : R;
+    double acc = 0.0;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += kThreads) acc += (double)x[base + offset4(r, red, sx)];
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[o * nsplit + sp] = acc;
+}
+
+// column form: x is [R, N] with row stride ld, N contiguous outputs; thread column-coalesced
+__global__ __launch_bounds__(kThreads) void k_t_reduce_cols(const float* __restrict__ x, int64_t R, int64_t N, int64_t ld, int nsplit,
+                                                            double* __restrict__ part) {
+    __shared__ double sh[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t col = blockIdx.x * 64 + tx;
+    const int sp = blockIdx.y;
+    const int64_t per = (R + nsplit - 1) / nsplit, r0 = sp * per, r1 = r0 + per < R ? r0 + per : R;
+    double acc = 0.0;
+    if (col < N)
+        for (int64_t r = r0 + ty; r < r1; r += 4) acc += (double)x[r * ld + col];
+    sh[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && col < N) part[col * nsplit + sp] = sh[0][tx] + sh[1][tx] + sh[2][tx] + sh[3][tx];
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_reduce_finish(const double* __restrict__ part, int nsplit, int64_t n_out, float* __restrict__ out,
+                                                              int accumulate, float scale) {
+    const int64_t o = blockIdx.x * (int64_t)kThreads + threadIdx.x;
+    if (o >= n_out) return;
+    double s = 0.0;
+    for (int i = 0; i < nsplit; ++i) s += part[o * nsplit + i];
+    const float r = (float)(s * (double)scale);
+    out[o] = accumulate ? out[o] + r : r;
+}
+
+struct ReducePlan {
+    Idx4 keep, red;
+    Str4 s;
+    int64_t n_out = 1, R = 1, ld = 0;
+    int nsplit = 1;
+    bool cols = false;
+};
+
+ReducePlan plan_reduce(const int64_t* shape, const int64_t* stride, const int32_t* red) {
+    ReducePlan p;
+    for (int d = 0; d < 4; ++d) {
+        p.keep.n[d] = red[d] ? 1 : shape[d];
+        p.red.n[d] = red[d] ? shape[d] : 1;
+        p.s.s[d] = stride ? stride[d] : 0;
+        p.n_out *= p.keep.n[d];
+        p.R *= p.red.n[d];
+    }
+    // column form: leading dims reduced, trailing dims kept and contiguous, reduced dims collapse to one row stride
+    int first_keep = 0;
+    while (first_keep < 4 && (red[first_keep] || shape[first_keep] == 1)) ++first_keep;
+    bool tail_keep = true;
+    for (int d = first_keep; d < 4; ++d) tail_keep = tail_keep && (!red[d] || shape[d] == 1);
+    if (stride && tail_keep && first_keep > 0 && first_keep < 4 && p.R > 1) {
+        int64_t expect = 1;
+        bool contig = true;
+        for (int d = 3; d >= first_keep; --d) {
+            if (shape[d] != 1 && stride[d] != expect) contig = false;
+            expect *= shape[d];
+        }
+        int64_t ld = 0;
+        bool lead_ok = true;                        // reduced dims must form one uniform row stride
+        int64_t run = 1;
+        for (int d = first_keep - 1; d >= 0; --d) {
+            if (shape[d] == 1) continue;
+            if (ld == 0) ld = stride[d];
+            if (stride[d] != ld * run) lead_ok = false;
+            run *= shape[d];
+        }
+        if (contig && lead_ok && ld > 0) {
+            p.cols = true;
+            p.ld = ld;
+        }
+    }
+    const int64_t units = p.cols ? (p.n_out + 63) / 64 : p.n_out;
+    int ns = 1;
+    while (units * ns < 1024 && p.R / (ns * 2) >= 512 && ns < 1024) ns *= 2;
+    p.nsplit = ns;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------------------ GEMM
+typedef float f32x16t __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float *A, *B, *bias;
+    float* C;
+    int M, N, K, nb2, ksplit;
+    int64_t am, ak, bk, bn, cm, cn;
+    int64_t a1, a2, b1, b2, c1, c2;
+    float alpha;
+    int accumulate;
+    int a_kfast, b_nfast;
+};
+
+// 64x64 output tile per workgroup, K in steps of 16 through LDS ([k][m] / [k][n] images: the MFMA operand fragments are
+// conflict-free row reads); wave w owns the 32x32 quadrant (w>>1, w&1); v_mfma_f32_32x32x2_f32 keeps fp32 products exact.
+__global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
+    __shared__ float As[2][16][65], Bs[2][16][65];
+    const int tiles_n = (g.N + 63) / 64;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int bi1 = blockIdx.y / g.nb2, bi2 = blockIdx.y % g.nb2;
+    const float* A = g.A + bi1 * g.a1 + bi2 * g.a2;
+    const float* B = g.B + bi1 * g.b1 + bi2 * g.b2;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int kper = ((g.K + g.ksplit - 1) / g.ksplit + 15) / 16 * 16;
+    const int kbeg = blockIdx.z * kper, kend = kbeg + kper < g.K ? kbeg + kper : g.K;
+    f32x16t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m, k;
+            if (g.a_kfast) { k = t & 15; m = (t >> 4) + 16 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
+            const bool ok = (m0 + m) < g.M && (k0 + k) < kend;
+            ra[i] = ok ? A[(int64_t)(m0 + m) * g.am + (int64_t)(k0 + k) * g.ak] : 0.f;
+            int n, kk;
+            if (g.b_nfast) { n = t & 63; kk = (t >> 6) + 4 * i; } else { kk = t & 15; n = (t >> 4) + 16 * i; }
+            const bool okb = (n0 + n) < g.N && (k0 + kk) < kend;
+            rb[i] = okb ? B[(int64_t)(k0 + kk) * g.bk + (int64_t)(n0 + n) * g.bn] : 0.f;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m, k;
+            if (g.a_kfast) { k = t & 15; m = (t >> 4) + 16 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
+            As[buf][k][m] = ra[i];
+            int n, kk;
+            if (g.b_nfast) { n = t & 63; kk = (t >> 6) + 4 * i; } else { kk = t & 15; n = (t >> 4) + 16 * i; }
+            Bs[buf][kk][n] = rb[i];
+        }
+    };
+    int buf = 0;
+    if (kbeg < kend) {
+        fetch(kbeg);
+        stash(0);
+    }
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        const bool more = k0 + 16 < kend;
+        if (more) fetch(k0 + 16);                       // next slice's loads fly over this slice's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float a = As[buf][kk + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float b = Bs[buf][kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* C = g.C + bi1 * g.c1 + bi2 * g.c2 + (g.ksplit > 1 ? (int64_t)blockIdx.z * g.M * g.N : 0);
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= g.N) return;
+    const float bias = (g.bias && g.ksplit == 1) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = m0 + wm * 32 + (i >> 2) * 8 + (lane >> 5) * 4 + (i & 3);
+        if (row < g.M) {
+            float* c = C + (int64_t)row * g.cm + (int64_t)col * g.cn;
+            float v = g.alpha * acc[i] + bias;
+            if (g.accumulate) v += *c;
+            *c = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_splitk_finish(const float* __restrict__ ws, int ksplit, int M, int N, float* __restrict__ C,
+                                                              int64_t cm, int64_t cn, const float* __restrict__ bias, float alpha,
+                                                              int accumulate) {
+    const int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    const int m = (int)(i / N), n = (int)(i % N);
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += ws[(int64_t)k * M * N + i];
+    float v = alpha * s + (bias ? bias[n] : 0.f);
+    float* c = C + (int64_t)m * cm + (int64_t)n * cn;
+    if (accumulate) v += *c;
+    *c = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------ row kernels
+// one wave per row of n contiguous floats
+__global__ __launch_bounds__(kThreads) void k_t_ln_fwd(const float* __restrict__ x, int64_t rows, int n, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float eps, int mode, float* __restrict__ y,
+                                                       float* __restrict__ mean, float* __restrict__ rinv) {
+    const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * n;
+    double s = 0.0;
+    for (int i = lane; i < n; i += 64) s += (double)xr[i];
+    const float mu = (float)(wave_sum(s) / n);
+    double q = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const float d = xr[i] - mu;
+        q += (double)d * d;
+    }
+    q = wave_sum(q);
+    const float ri = mode == 0 ? 1.0f / sqrtf((float)(q / n) + eps) : 1.0f / (sqrtf((float)(q / (n - 1))) + eps);
+    for (int i = lane; i < n; i += 64) {
+        float v = (xr[i] - mu) * ri;
+        if (w) v *= w[i];
+        if (b) v += b[i];
+        y[row * n + i] = v;
+    }
+    if (lane == 0) {
+        mean[row] = mu;
+        rinv[row] = ri;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_ln_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ rinv, const float* __restrict__ w, int64_t rows, int n,
+                                                       float eps, int mode, float* __restrict__ dx, float* __restrict__ dyx) {
+    const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + row * n, *dr = dy + row * n;
+    const float mu = mean[row], ri = rinv[row];
+    double s1 = 0.0, s2 = 0.0;                          // sum dxhat, sum dxhat * xhat
+    for (int i = lane; i < n; i += 64) {
+        const float xh = (xr[i] - mu) * ri, g = dr[i] * (w ? w[i] : 1.f);
+        s1 += (double)g;
+        s2 += (double)g * xh;
+    }
+    const float m1 = (float)(wave_sum(s1) / n), t2 = (float)wave_sum(s2);
+    if (mode == 0) {
+        const float m2 = t2 / n;
+        for (int i = lane; i < n; i += 64) {
+            const float xh = (xr[i] - mu) * ri, g = dr[i] * (w ? w[i] : 1.f);
+            dx[row * n + i] = ri * (g - m1 - xh * m2);
+            if (dyx) dyx[row * n + i] = dr[i] * xh;
+        }
+    } else {
+        // y = w xc / s + b, s = sigma + eps, sigma = sqrt(sum xc^2 / (n-1)):  d sigma = -sum(g xc) / s^2 = -ri * t2
+        const float sden = 1.0f / ri, sigma = sden - eps;
+        const float dsig = -ri * t2;
+        const float c2 = sigma > 0.f ? dsig / ((n - 1) * sigma) : 0.f;
+        for (int i = lane; i < n; i += 64) {
+            const float xc = xr[i] - mu, g = dr[i] * (w ? w[i] : 1.f);
+            dx[row * n + i] = ri * (g - m1) + c2 * xc;
+            if (dyx) dyx[row * n + i] = dr[i] * xc * ri;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_softmax_fwd(const float* __restrict__ x, int64_t rows, int n, float* __restrict__ p) {
+    const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * n;
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) mx = fmaxf(mx, xr[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += expf(xr[i] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float inv = 1.0f / s;
+    for (int i = lane; i < n; i += 64) p[row * n + i] = expf(xr[i] - mx) * inv;
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_softmax_bwd(const float* __restrict__ p, const float* __restrict__ dp, int64_t rows, int n,
+                                                            float* __restrict__ dx) {
+    const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *pr = p + row * n, *dr = dp + row * n;
+    double s = 0.0;
+    for (int i = lane; i < n; i += 64) s += (double)pr[i] * dr[i];
+    const float t = (float)wave_sum(s);
+    for (int i = lane; i < n; i += 64) dx[row * n + i] = pr[i] * (dr[i] - t);
+}
+
+// ------------------------------------------------------------------------------------------------------------ dropout
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_dropout(const float* __restrict__ x, int64_t n, uint32_t thresh, float scale, uint64_t seed,
+                                                        uint64_t offset, float* __restrict__ out, uint8_t* __restrict__ mask) {
+    const int64_t q = blockIdx.x * (int64_t)kThreads + threadIdx.x;          // four elements per thread: one philox block
+    if (q * 4 >= n) return;
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = q * 4 + j;
+        if (i < n) {
+            const uint8_t keep = c[j] >= thresh ? 1 : 0;
+            mask[i] = keep;
+            out[i] = keep ? (x ? x[i] : 1.f) * scale : 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_mask_scale(const float* __restrict__ x, const uint8_t* __restrict__ mask, int64_t n, float scale,
+                                                           float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads)
+        out[i] = mask[i] ? x[i] * scale : 0.f;
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                     int64_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);            // torch: exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ losses
+// CoordLoss (lib/core/loss.py:10-25)
+__global__ __launch_bounds__(kThreads) void k_t_coord_loss(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ valid,
+                                                           Str4 sv, Idx4 n, int64_t total, float gscale, float* __restrict__ grad,
+                                                           double* __restrict__ part) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const float v = valid ? valid[offset4(i, n, sv)] : 1.f;
+        const float d = pred[i] * v - tgt[i] * v;
+        acc += (double)fabsf(d);
+        if (grad) grad[i] += gscale * v * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 scl3(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 add3(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// F.normalize(v, p=2): v / max(|v|, 1e-12)
+__device__ __forceinline__ V3 normalize3(V3 v, float& len) {
+    len = fmaxf(sqrtf(dot3(v, v)), 1e-12f);
+    return scl3(v, 1.0f / len);
+}
+// d |u.n| / d v for u = v / |v|:  sign(u.n) * (n - u (u.n)) / |v|
+__device__ __forceinline__ V3 dcos(V3 u, float len, V3 nrm, float c) {
+    const float sg = c > 0.f ? 1.f : (c < 0.f ? -1.f : 0.f);
+    return scl3(sub3(nrm, scl3(u, c)), sg / len);
+}
+
+// NormalVectorLoss (lib/core/loss.py:59-86): per (sample, face) the three |cos| terms and the gradient at the 3 corners
+__global__ __launch_bounds__(kThreads) void k_t_normal_face(const float* __restrict__ pred, const float* __restrict__ tgt, const int32_t* __restrict__ faces,
+                                                            int64_t B, int64_t V, int64_t F, float* __restrict__ fg, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < B * F; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t b = i / F, f = i % F;
+        const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+        const float *P = pred + b * V * 3, *T = tgt + b * V * 3;
+        const V3 p0 = ld3(P + i0 * 3), p1 = ld3(P + i1 * 3), p2 = ld3(P + i2 * 3);
+        const V3 t0 = ld3(T + i0 * 3), t1 = ld3(T + i1 * 3), t2 = ld3(T + i2 * 3);
+        float l1, l2, l3, lt;
+        const V3 u1 = normalize3(sub3(p1, p0), l1), u2 = normalize3(sub3(p2, p0), l2), u3 = normalize3(sub3(p2, p1), l3);
+        const V3 g1 = normalize3(sub3(t1, t0), lt), g2 = normalize3(sub3(t2, t0), lt);
+        const V3 nrm = normalize3(cross3(g1, g2), lt);
+        const float c1 = dot3(u1, nrm), c2 = dot3(u2, nrm), c3 = dot3(u3, nrm);
+        acc += (double)fabsf(c1) + (double)fabsf(c2) + (double)fabsf(c3);
+        if (fg) {
+            const V3 d1 = dcos(u1, l1, nrm, c1), d2 = dcos(u2, l2, nrm, c2), d3 = dcos(u3, l3, nrm, c3);
+            const V3 q0 = scl3(add3(d1, d2), -1.f), q1 = sub3(d1, d3), q2 = add3(d2, d3);      // v1 = p1-p0, v2 = p2-p0, v3 = p2-p1
+            float* o = fg + i * 9;
+            o[0] = q0.x; o[1] = q0.y; o[2] = q0.z; o[3] = q1.x; o[4] = q1.y; o[5] = q1.z; o[6] = q2.x; o[7] = q2.y; o[8] = q2.z;
+        }
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+// EdgeLengthLoss (lib/core/loss.py:89-112)
+__global__ __launch_bounds__(kThreads) void k_t_edge_face(const float* __restrict__ pred, const float* __restrict__ tgt, const int32_t* __restrict__ faces,
+                                                          int64_t B, int64_t V, int64_t F, float* __restrict__ fg, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < B * F; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t b = i / F, f = i % F;
+        const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+        const float *P = pred + b * V * 3, *T = tgt + b * V * 3;
+        const V3 p0 = ld3(P + i0 * 3), p1 = ld3(P + i1 * 3), p2 = ld3(P + i2 * 3);
+        const V3 t0 = ld3(T + i0 * 3), t1 = ld3(T + i1 * 3), t2 = ld3(T + i2 * 3);
+        const V3 e1 = sub3(p0, p1), e2 = sub3(p0, p2), e3 = sub3(p1, p2);
+        const float d1 = sqrtf(dot3(e1, e1)), d2 = sqrtf(dot3(e2, e2)), d3 = sqrtf(dot3(e3, e3));
+        const V3 h1 = sub3(t0, t1), h2 = sub3(t0, t2), h3 = sub3(t1, t2);
+        const float r1 = d1 - sqrtf(dot3(h1, h1)), r2 = d2 - sqrtf(dot3(h2, h2)), r3 = d3 - sqrtf(dot3(h3, h3));
+        acc += (double)fabsf(r1) + (double)fabsf(r2) + (double)fabsf(r3);
+        if (fg) {
+            auto sg = [](float r) { return r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f); };
+            const V3 a1 = scl3(e1, d1 > 0.f ? sg(r1) / d1 : 0.f), a2 = scl3(e2, d2 > 0.f ? sg(r2) / d2 : 0.f),
+                     a3 = scl3(e3, d3 > 0.f ? sg(r3) / d3 : 0.f);
+            const V3 q0 = add3(a1, a2), q1 = sub3(a3, a1), q2 = scl3(add3(a2, a3), -1.f);
+            float* o = fg + i * 9;
+            o[0] = q0.x; o[1] = q0.y; o[2] = q0.z; o[3] = q1.x; o[4] = q1.y; o[5] = q1.z; o[6] = q2.x; o[7] = q2.y; o[8] = q2.z;
+        }
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+// per (sample, vertex): sum the vertex's corner gradients in list order
+__global__ __launch_bounds__(kThreads) void k_t_face_gather(const float* __restrict__ fg, const int32_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_idx,
+                                                            int64_t B, int64_t V, int64_t F, float gscale, float* __restrict__ grad) {
+    for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < B * V; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t b = i / V, v = i % V;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int e = inc_ptr[v]; e < inc_ptr[v + 1]; ++e) {
+            const float* o = fg + (b * F) * 9 + (int64_t)inc_idx[e] * 3;
+            sx += o[0];
+            sy += o[1];
+            sz += o[2];
+        }
+        grad[i * 3] += gscale * sx;
+        grad[i * 3 + 1] += gscale * sy;
+        grad[i * 3 + 2] += gscale * sz;
+    }
+}
+
+__global__ void k_t_loss_finish(const double* __restrict__ part, int n, double scale, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += part[i];
+        out[0] = (float)(s * scale);
+    }
+}
+
+constexpr int kLossBlocks = 2048;
+
+int grid_for(int64_t total) {
+    int64_t b = (total + kThreads - 1) / kThreads;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+int face_loss(bool normal, const float* pred, const float* target, const int32_t* faces, const int32_t* inc_ptr, const int32_t* inc_idx,
+              int64_t B, int64_t V, int64_t F, float weight, float* loss_out, float* grad, void* ws, hipStream_t st) {
+    if (!pred || !target || !faces || !loss_out || !ws) return fail(1, "face loss: null argument");
+    if (grad && (!inc_ptr || !inc_idx)) return fail(1, "face loss: the gradient needs the vertex incidence lists");
+    double* part = static_cast<double*>(ws);
+    float* fg = grad ? reinterpret_cast<float*>(static_cast<char*>(ws) + 65536) : nullptr;
+    const int blocks = (int)std::min<int64_t>(kLossBlocks, (B * F + kThreads - 1) / kThreads);
+    if (normal)
+        hipLaunchKernelGGL(k_t_normal_face, dim3(blocks), dim3(kThreads), 0, st, pred, target, faces, B, V, F, fg, part);
+    else
+        hipLaunchKernelGGL(k_t_edge_face, dim3(blocks), dim3(kThreads), 0, st, pred, target, faces, B, V, F, fg, part);
+    const double inv = 1.0 / ((double)B * 3.0 * (double)F);
+    hipLaunchKernelGGL(k_t_loss_finish, dim3(1), dim3(64), 0, st, part, blocks, (double)weight * inv, loss_out);
+    if (grad)
+        hipLaunchKernelGGL(k_t_face_gather, dim3(grid_for(B * V)), dim3(kThreads), 0, st, fg, inc_ptr, inc_idx, B, V, F, (float)(weight * inv), grad);
+    return check_launch(normal ? "gator_t_normal_loss" : "gator_t_edge_loss");
+}
+
+}  // namespace
+}  // namespace gator
+
+using namespace gator;
+
+extern "C" {
+
+int gator_t_binary(int op, const float* a, const int64_t* sa, const float* b, const int64_t* sb, float* out, const int64_t* so,
+                   const int64_t* shape, gator_stream stream) {
+    if (!a || !b || !out || op < 0 || op > 3) return fail(1, "gator_t_binary: bad argument");
+    Idx4 n;
+    Str4 A, Bs, O;
+    int64_t total = 1;
+    for (int d = 0; d < 4; ++d) {
+        n.n[d] = shape[d];
+        A.s[d] = sa[d];
+        Bs.s[d] = sb[d];
+        O.s[d] = so[d];
+        total *= shape[d];
+    }
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(k_t_binary, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, op, a, A, b, Bs, out, O, n, total);
+    return check_launch("gator_t_binary");
+}
+
+int gator_t_unary(int op, const float* x, const int64_t* sx, float* out, const int64_t* so, const int64_t* shape, float p0, float p1,
+                  gator_stream stream) {
+    if (!x || !out || op < 0 || op > 11) return fail(1, "gator_t_unary: bad argument");
+    Idx4 n;
+    Str4 X, O;
+    int64_t total = 1;
+    for (int d = 0; d < 4; ++d) {
+        n.n[d] = shape[d];
+        X.s[d] = sx[d];
+        O.s[d] = so[d];
+        total *= shape[d];
+    }
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(k_t_unary, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, op, x, X, out, O, n, total, p0, p1);
+    return check_launch("gator_t_unary");
+}
+
+int64_t gator_t_reduce_ws_bytes(const int64_t* shape, const int32_t* red) {
+    int64_t dummy[4] = {0, 0, 0, 0};
+    ReducePlan p = plan_reduce(shape, dummy, red);      // without strides the general form is assumed: an upper bound on nsplit
+    int ns = 1;
+    while (ns < 1024 && p.R / (ns * 2) >= 512) ns *= 2;
+    return p.n_out * ns * (int64_t)sizeof(double);
+}
+
+int gator_t_reduce_sum(const float* x, const int64_t* sx, const int64_t* shape, const int32_t* red, float* out, int accumulate, void* ws,
+                       gator_stream stream) {
+    if (!x || !out || !ws) return fail(1, "gator_t_reduce_sum: null argument");
+    ReducePlan p = plan_reduce(shape, sx, red);
+    if (p.n_out == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    double* part = static_cast<double*>(ws);
+    if (p.cols)
+        hipLaunchKernelGGL(k_t_reduce_cols, dim3((unsigned)((p.n_out + 63) / 64), p.nsplit), dim3(kThreads), 0, st, x, p.R, p.n_out, p.ld, p.nsplit, part);
+    else {
+        if (p.n_out > 0x7fffffffLL) return fail(1, "gator_t_reduce_sum: too many outputs");
+        hipLaunchKernelGGL(k_t_reduce, dim3((unsigned)p.n_out, p.nsplit), dim3(kThreads), 0, st, x, p.s, p.keep, p.red, p.R, p.nsplit, part);
+    }
+    hipLaunchKernelGGL(k_t_reduce_finish, dim3((unsigned)((p.n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, p.nsplit, p.n_out, out,
+                       accumulate, 1.0f);
+    return check_launch("gator_t_reduce_sum");
+}
+
+int gator_t_gemm(const float* A, const float* B, float* C, int M, int N, int K, const int64_t* sa, const int64_t* sb, const int64_t* sc, int nb1,
+                 int nb2, const int64_t* ba, const int64_t* bb, const int64_t* bc, const float* bias, float alpha, int accumulate, int ksplit,
+                 float* ws, gator_stream stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K < 0 || nb1 <= 0 || nb2 <= 0) return fail(1, "gator_t_gemm: bad argument");
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > 1 && (nb1 != 1 || nb2 != 1 || !ws)) return fail(1, "gator_t_gemm: split-K needs an unbatched product and a workspace");
+    if ((int64_t)nb1 * nb2 > 65535) return fail(1, "gator_t_gemm: more than 65535 batched products");
+    GemmArgs g;
+    g.A = A; g.B = B; g.bias = bias; g.C = ksplit > 1 ? ws : C;
+    g.M = M; g.N = N; g.K = K; g.nb2 = nb2; g.ksplit = ksplit;
+    g.am = sa[0]; g.ak = sa[1]; g.bk = sb[0]; g.bn = sb[1];
+    g.cm = ksplit > 1 ? N : sc[0]; g.cn = ksplit > 1 ? 1 : sc[1];
+    g.a1 = ba[0]; g.a2 = ba[1]; g.b1 = bb[0]; g.b2 = bb[1]; g.c1 = bc[0]; g.c2 = bc[1];
+    g.alpha = ksplit > 1 ? 1.f : alpha;
+    g.accumulate = ksplit > 1 ? 0 : accumulate;
+    g.a_kfast = (g.ak == 1 || g.am != 1) ? 1 : 0;       // lanes run along whichever index is contiguous in memory
+    g.b_nfast = (g.bn == 1 || g.bk != 1) ? 1 : 0;
+    const unsigned tiles = (unsigned)(((M + 63) / 64) * ((N + 63) / 64));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_t_gemm, dim3(tiles, nb1 * nb2, ksplit), dim3(kThreads), 0, st, g);
+    if (ksplit > 1)
+        hipLaunchKernelGGL(k_t_splitk_finish, dim3((unsigned)(((int64_t)M * N + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, ws, ksplit, M, N, C,
+                           sc[0], sc[1], bias, alpha, accumulate);
+    return check_launch("gator_t_gemm");
+}
+
+int gator_t_layernorm_fwd(const float* x, int64_t rows, int n, const float* w, const float* b, float eps, int mode, float* y, float* mean,
+                          float* rinv, gator_stream stream) {
+    if (!x || !y || !mean || !rinv || n < 1 || (mode == 1 && n < 2)) return fail(1, "gator_t_layernorm_fwd: bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_t_ln_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, x, rows, n, w, b, eps, mode, y, mean, rinv);
+    return check_launch("gator_t_layernorm_fwd");
+}
+
+int gator_t_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rinv, const float* w, int64_t rows, int n, float eps,
+                          int mode, float* dx, float* dy_xhat, gator_stream stream) {
+    if (!dy || !x || !mean || !rinv || !dx) return fail(1, "gator_t_layernorm_bwd: null argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_t_ln_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, dy, x, mean, rinv, w, rows, n, eps, mode, dx,
+                       dy_xhat);
+    return check_launch("gator_t_layernorm_bwd");
+}
+
+int gator_t_softmax_fwd(const float* x, int64_t rows, int n, float* p, gator_stream stream) {
+    if (!x || !p || n < 1) return fail(1, "gator_t_softmax_fwd: bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_t_softmax_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, x, rows, n, p);
+    return check_launch("gator_t_softmax_fwd");
+}
+
+int gator_t_softmax_bwd(const float* p, const float* dp, int64_t rows, int n, float* dx, gator_stream stream) {
+    if (!p || !dp || !dx || n < 1) return fail(1, "gator_t_softmax_bwd: bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_t_softmax_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, p, dp, rows, n, dx);
+    return check_launch("gator_t_softmax_bwd");
+}
+
+int gator_t_dropout(const float* x, int64_t n, float rate, uint64_t seed, uint64_t offset, float* out, uint8_t* mask, gator_stream stream) {
+    if (!out || !mask || rate < 0.f || rate >= 1.f) return fail(1, "gator_t_dropout: bad argument");
+    if (n == 0) return 0;
+    const double t = (double)rate * 4294967296.0;
+    const uint32_t thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    const int64_t quads = (n + 3) / 4;
+    hipLaunchKernelGGL(k_t_dropout, dim3((unsigned)((quads + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream, x, n, thresh,
+                       1.0f / (1.0f - rate), seed, offset, out, mask);
+    return check_launch("gator_t_dropout");
+}
+
+int gator_t_mask_scale(const float* x, const uint8_t* mask, int64_t n, float scale, float* out, gator_stream stream) {
+    if (!x || !mask || !out) return fail(1, "gator_t_mask_scale: null argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_t_mask_scale, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, x, mask, n, scale, out);
+    return check_launch("gator_t_mask_scale");
+}
+
+int gator_t_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                 int step, gator_stream stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail(1, "gator_t_adam: bad argument");
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(k_t_adam, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                       (float)bc1, (float)sqrt(bc2));
+    return check_launch("gator_t_adam");
+}
+
+int64_t gator_t_loss_ws_bytes(int64_t B, int64_t F) { return 65536 + B * F * 9 * (int64_t)sizeof(float); }
+
+int gator_t_coord_loss(const float* pred, const float* target, const float* valid, const int64_t* sv, const int64_t* shape, float weight,
+                       float* loss_out, float* grad, void* ws, gator_stream stream) {
+    if (!pred || !target || !loss_out || !ws) return fail(1, "gator_t_coord_loss: null argument");
+    Idx4 n;
+    Str4 S;
+    int64_t total = 1;
+    for (int d = 0; d < 4; ++d) {
+        n.n[d] = shape[d];
+        S.s[d] = (valid && sv) ? sv[d] : 0;
+        total *= shape[d];
+    }
+    if (total == 0) return fail(1, "gator_t_coord_loss: empty input");
+    const int blocks = (int)std::min<int64_t>(kLossBlocks, (total + kThreads - 1) / kThreads);
+    hipStream_t st = (hipStream_t)stream;
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL(k_t_coord_loss, dim3(blocks), dim3(kThreads), 0, st, pred, target, valid, S, n, total, (float)((double)weight / (double)total), grad,
+                       part);
+    hipLaunchKernelGGL(k_t_loss_finish, dim3(1), dim3(64), 0, st, part, blocks, (double)weight / (double)total, loss_out);
+    return check_launch("gator_t_coord_loss");
+}
+
+int gator_t_normal_loss(const float* pred, const float* target, const int32_t* faces, const int32_t* inc_ptr, const int32_t* inc_idx, int64_t B,
+                        int64_t V, int64_t F, float weight, float* loss_out, float* grad, void* ws, gator_stream stream) {
+    return face_loss(true, pred, target, faces, inc_ptr, inc_idx, B, V, F, weight, loss_out, grad, ws, (hipStream_t)stream);
+}
+
+int gator_t_edge_loss(const float* pred, const float* target, const int32_t* faces, const int32_t* inc_ptr, const int32_t* inc_idx, int64_t B,
+                      int64_t V, int64_t F, float weight, float* loss_out, float* grad, void* ws, gator_stream stream) {
+    return face_loss(false, pred, target, faces, inc_ptr, inc_idx, B, V, F, weight, loss_out, grad, ws, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,546 @@
+"""Differentiable fp32 primitives of the training row on the HIP kernels of include/gator_train.h.
+
+torch is the plumbing here: tensors own device memory, views (reshape / permute / expand) are metadata, and
+``torch.autograd.Function`` orders the backward calls.  Every arithmetic operation - forward and backward - is a kernel of
+libgator_hip.so; nothing in this module calls an aten compute op on the data path, and there is no CPU path: inputs must live on
+a HIP device.  The reference gets the same operations from aten through autograd (lib/core/base.py:135-153)."""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+_I64x4 = ctypes.c_int64 * 4
+_I32x4 = ctypes.c_int32 * 4
+_I64x2 = ctypes.c_int64 * 2
+ADD, SUB, MUL, DIV = 0, 1, 2, 3
+U_AFFINE, U_GELU, U_DGELU, U_EXP, U_RSQRT, U_SQRT, U_RECIP, U_ABS, U_SIGN, U_POWBASE, U_SQUARE, U_GT = range(12)
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_device(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('gator_amd.train: tensors must live on a HIP device (there is no CPU path)')
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError('gator_amd.train: float32 only, got %s' % t.dtype)
+
+
+def _v4(t):
+    """(shape4, stride4) of a tensor with <= 4 dims, left-padded."""
+    d = t.dim()
+    if d > 4:
+        raise ValueError('gator_amd.train: at most 4 dims (got %d): reshape first' % d)
+    return [1] * (4 - d) + list(t.shape), [0] * (4 - d) + list(t.stride())
+
+
+def _call(name, *args):
+    _lib.check(getattr(_lib.load(), name)(*args), name)
+
+
+# ------------------------------------------------------------------------------------------------ raw (non-differentiable) kernels
+def raw_binary(op, a, b, out=None):
+    shape = torch.broadcast_shapes(a.shape, b.shape)
+    ae, be = a.expand(shape), b.expand(shape)
+    if out is None:
+        out = torch.empty(shape, device=a.device, dtype=torch.float32)
+    n4, sa = _v4(ae)
+    _, sb = _v4(be)
+    _, so = _v4(out)
+    _call('gator_t_binary', op, ae.data_ptr(), _I64x4(*sa), be.data_ptr(), _I64x4(*sb), out.data_ptr(), _I64x4(*so), _I64x4(*n4), _stream(a))
+    return out
+
+
+def raw_unary(op, x, p0=0.0, p1=0.0, out=None):
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    n4, sx = _v4(x)
+    _, so = _v4(out)
+    _call('gator_t_unary', op, x.data_ptr(), _I64x4(*sx), out.data_ptr(), _I64x4(*so), _I64x4(*n4), float(p0), float(p1), _stream(x))
+    return out
+
+
+def zeros(shape, device):
+    """A zero-filled tensor without an aten fill kernel: (x > +inf) is 0 for every bit pattern of the fresh memory."""
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    if out.numel():
+        raw_unary(U_GT, out.view(-1), float('inf'), 0.0, out=out.view(-1))
+    return out
+
+
+def raw_sum(x, dims, keepdim=False, out=None, accumulate=False):
+    dims = sorted(d % x.dim() for d in dims)
+    n4, sx = _v4(x)
+    pad = 4 - x.dim()
+    red = [0] * 4
+    for d in dims:
+        red[pad + d] = 1
+    kept = [1 if (i in dims) else x.shape[i] for i in range(x.dim())]
+    if out is None:
+        out = torch.empty(kept, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    nbytes = int(lib.gator_t_reduce_ws_bytes(_I64x4(*n4), _I32x4(*red)))
+    ws = torch.empty(max(nbytes, 8), device=x.device, dtype=torch.uint8)
+    _call('gator_t_reduce_sum', x.data_ptr(), _I64x4(*sx), _I64x4(*n4), _I32x4(*red), out.data_ptr(), int(accumulate), ws.data_ptr(), _stream(x))
+    if not keepdim:
+        out = out.reshape([x.shape[i] for i in range(x.dim()) if i not in dims])
+    return out
+
+
+def sum_to(g, shape):
+    """Reduce a broadcast gradient back to `shape` (left-padded broadcasting rules)."""
+    shape = list(shape)
+    if list(g.shape) == shape:
+        return g
+    lead = g.dim() - len(shape)
+    dims = list(range(lead)) + [lead + i for i, n in enumerate(shape) if n == 1 and g.shape[lead + i] != 1]
+    if not dims:
+        return g.reshape(shape)
+    return raw_sum(g, dims, keepdim=True).reshape(shape)
+
+
+def raw_gemm(a, b, out=None, bias=None, alpha=1.0, accumulate=False):
+    """a [n1,n2,M,K] x b [n1,n2,K,N] (any strides, stride 0 = broadcast) -> out [n1,n2,M,N]."""
+    n1, n2, M, K = a.shape
+    N = b.shape[3]
+    if out is None:
+        out = torch.empty((n1, n2, M, N), device=a.device, dtype=torch.float32)
+    sa, sb, so = a.stride(), b.stride(), out.stride()
+    ksplit, ws = 1, None
+    if n1 * n2 == 1 and K >= 4096 and ((M + 63) // 64) * ((N + 63) // 64) < 256:
+        ksplit = max(1, min(64, K // 1024, 512 // (((M + 63) // 64) * ((N + 63) // 64))))
+        if ksplit > 1:
+            ws = torch.empty(ksplit * M * N, device=a.device, dtype=torch.float32)
+    _call('gator_t_gemm', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, _I64x2(sa[2], sa[3]), _I64x2(sb[2], sb[3]), _I64x2(so[2], so[3]),
+          n1, n2, _I64x2(sa[0], sa[1]), _I64x2(sb[0], sb[1]), _I64x2(so[0], so[1]), bias.data_ptr() if bias is not None else None, float(alpha),
+          int(accumulate), ksplit, ws.data_ptr() if ws is not None else None, _stream(a))
+    return out
+
+
+def raw_copy(x):
+    """Contiguous copy through the library's strided copy kernel."""
+    if x.dim() > 4:
+        raise ValueError('raw_copy: at most 4 dims')
+    return raw_unary(U_AFFINE, x, 1.0, 0.0)
+
+
+def _contig(x):
+    return x if x.is_contiguous() else raw_copy(x)
+
+
+# ------------------------------------------------------------------------------------------------ differentiable ops
+class _Binary(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op, a, b):
+        _need_device(a, b)
+        ctx.op, ctx.sa, ctx.sb = op, a.shape, b.shape
+        ctx.save_for_backward(a if op in (MUL, DIV) else None, b if op in (MUL, DIV) else None)
+        return raw_binary(op, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        op = ctx.op
+        a, b = ctx.saved_tensors
+        ga = gb = None
+        if op == ADD:
+            ga, gb = g, g
+        elif op == SUB:
+            ga = g
+            gb = raw_unary(U_AFFINE, g, -1.0, 0.0) if ctx.needs_input_grad[2] else None
+        elif op == MUL:
+            ga = raw_binary(MUL, g, b) if ctx.needs_input_grad[1] else None
+            gb = raw_binary(MUL, g, a) if ctx.needs_input_grad[2] else None
+        else:
+            ga = raw_binary(DIV, g, b) if ctx.needs_input_grad[1] else None
+            if ctx.needs_input_grad[2]:                       # -g a / b^2
+                gb = raw_unary(U_AFFINE, raw_binary(DIV, raw_binary(MUL, g, raw_binary(DIV, a, b)), b), -1.0, 0.0)
+        ga = sum_to(ga, ctx.sa) if (ga is not None and ctx.needs_input_grad[1]) else None
+        gb = sum_to(gb, ctx.sb) if (gb is not None and ctx.needs_input_grad[2]) else None
+        return None, ga, gb
+
+
+def add(a, b):
+    return _Binary.apply(ADD, a, b)
+
+
+def sub(a, b):
+    return _Binary.apply(SUB, a, b)
+
+
+def mul(a, b):
+    return _Binary.apply(MUL, a, b)
+
+
+def div(a, b):
+    return _Binary.apply(DIV, a, b)
+
+
+class _Unary(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op, x, p0, p1):
+        _need_device(x)
+        y = raw_unary(op, x, p0, p1)
+        ctx.op, ctx.p0 = op, p0
+        ctx.save_for_backward(x if op in (U_GELU, U_ABS, U_SQUARE) else None, y if op in (U_EXP, U_RSQRT, U_SQRT, U_RECIP, U_POWBASE) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        import math
+        op = ctx.op
+        x, y = ctx.saved_tensors
+        if op == U_AFFINE:
+            gx = raw_unary(U_AFFINE, g, ctx.p0, 0.0)
+        elif op == U_GELU:
+            gx = raw_binary(MUL, g, raw_unary(U_DGELU, x))
+        elif op == U_EXP:
+            gx = raw_binary(MUL, g, y)
+        elif op == U_RSQRT:                                    # -0.5 y^3
+            gx = raw_binary(MUL, g, raw_unary(U_AFFINE, raw_binary(MUL, raw_binary(MUL, y, y), y), -0.5, 0.0))
+        elif op == U_SQRT:                                     # 0.5 / y
+            gx = raw_binary(DIV, raw_unary(U_AFFINE, g, 0.5, 0.0), y)
+        elif op == U_RECIP:                                    # -y^2
+            gx = raw_binary(MUL, g, raw_unary(U_AFFINE, raw_binary(MUL, y, y), -1.0, 0.0))
+        elif op == U_ABS:
+            gx = raw_binary(MUL, g, raw_unary(U_SIGN, x))
+        elif op == U_POWBASE:                                  # ln(p0) y
+            gx = raw_binary(MUL, g, raw_unary(U_AFFINE, y, math.log(ctx.p0), 0.0))
+        elif op == U_SQUARE:
+            gx = raw_binary(MUL, g, raw_unary(U_AFFINE, x, 2.0, 0.0))
+        else:
+            raise RuntimeError('no gradient for unary op %d' % op)
+        return None, gx, None, None
+
+
+def affine(x, scale=1.0, shift=0.0):
+    return _Unary.apply(U_AFFINE, x, float(scale), float(shift))
+
+
+def gelu(x):
+    return _Unary.apply(U_GELU, x, 0.0, 0.0)
+
+
+def exp(x):
+    return _Unary.apply(U_EXP, x, 0.0, 0.0)
+
+
+def rsqrt(x):
+    return _Unary.apply(U_RSQRT, x, 0.0, 0.0)
+
+
+def sqrt(x):
+    return _Unary.apply(U_SQRT, x, 0.0, 0.0)
+
+
+def recip(x):
+    return _Unary.apply(U_RECIP, x, 0.0, 0.0)
+
+
+def abs_(x):
+    return _Unary.apply(U_ABS, x, 0.0, 0.0)
+
+
+def square(x):
+    return _Unary.apply(U_SQUARE, x, 0.0, 0.0)
+
+
+def pow_base(base, x):
+    return _Unary.apply(U_POWBASE, x, float(base), 0.0)
+
+
+class _Sum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dims, keepdim):
+        _need_device(x)
+        ctx.shape, ctx.dims, ctx.keepdim = x.shape, [d % x.dim() for d in dims], keepdim
+        return raw_sum(x, dims, keepdim)
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.keepdim:
+            kept = [1 if i in ctx.dims else n for i, n in enumerate(ctx.shape)]
+            g = g.reshape(kept)
+        return raw_copy(g.expand(ctx.shape)), None, None
+
+
+def sum_(x, dims, keepdim=False):
+    return _Sum.apply(x, tuple(dims), keepdim)
+
+
+def mean(x, dims, keepdim=False):
+    n = 1
+    for d in dims:
+        n *= x.shape[d]
+    return affine(sum_(x, dims, keepdim), 1.0 / n)
+
+
+def _as4(t, batch_shape):
+    """[..., R, C] with <= 2 leading batch dims -> expanded 4-D view [n1, n2, R, C]."""
+    lead = list(t.shape[:-2])
+    if len(lead) > 2:
+        raise ValueError('matmul: at most two batch dims')
+    t4 = t.reshape([1] * (2 - len(lead)) + list(t.shape)) if len(lead) < 2 else t
+    return t4.expand(list(batch_shape) + list(t.shape[-2:]))
+
+
+class _MatMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        _need_device(a, b)
+        la, lb = list(a.shape[:-2]), list(b.shape[:-2])
+        bs = list(torch.broadcast_shapes(tuple(la), tuple(lb)))
+        bs4 = [1] * (2 - len(bs)) + bs
+        a4, b4 = _as4(a, bs4), _as4(b, bs4)
+        ctx.alpha, ctx.bs, ctx.sa, ctx.sb = alpha, bs, a.shape, b.shape
+        ctx.save_for_backward(a, b)
+        out = raw_gemm(a4, b4, alpha=alpha)
+        return out.reshape(bs + [a.shape[-2], b.shape[-1]])
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        bs4 = [1] * (2 - len(ctx.bs)) + list(ctx.bs)
+        g4 = _as4(g, bs4)
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = raw_gemm(g4, _as4(b, bs4).transpose(2, 3), alpha=ctx.alpha).reshape(list(ctx.bs) + list(ctx.sa[-2:]))
+            ga = sum_to(ga, ctx.sa)
+        if ctx.needs_input_grad[1]:
+            gb = raw_gemm(_as4(a, bs4).transpose(2, 3), g4, alpha=ctx.alpha).reshape(list(ctx.bs) + list(ctx.sb[-2:]))
+            gb = sum_to(gb, ctx.sb)
+        return ga, gb, None
+
+
+def matmul(a, b, alpha=1.0):
+    return _MatMul.apply(a, b, float(alpha))
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b over the last dim (F.linear): one GEMM on the flattened rows; dW is one split-K GEMM over all rows."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_device(x, w, b)
+        x2 = _contig(x).reshape(1, 1, -1, x.shape[-1])
+        w4 = w.reshape(1, 1, w.shape[0], w.shape[1])
+        ctx.save_for_backward(x2, w4)
+        ctx.xshape, ctx.has_b = x.shape, b is not None
+        y = raw_gemm(x2, w4.transpose(2, 3), bias=b)
+        return y.reshape(list(x.shape[:-1]) + [w.shape[0]])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w4 = ctx.saved_tensors
+        g2 = _contig(g).reshape(1, 1, -1, g.shape[-1])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = raw_gemm(g2, w4).reshape(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            gw = raw_gemm(g2.transpose(2, 3), x2).reshape(w4.shape[2], w4.shape[3])
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            gb = raw_sum(g2.reshape(-1, g2.shape[-1]), [0])
+        return gx, gw, gb
+
+
+def linear(x, w, b=None):
+    return _Linear.apply(x, w, b)
+
+
+class _Softmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_device(x)
+        xc = _contig(x)
+        p = torch.empty_like(xc)
+        n = xc.shape[-1]
+        _call('gator_t_softmax_fwd', xc.data_ptr(), xc.numel() // n, n, p.data_ptr(), _stream(x))
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, g):
+        p, = ctx.saved_tensors
+        gc = _contig(g)
+        dx = torch.empty_like(p)
+        n = p.shape[-1]
+        _call('gator_t_softmax_bwd', p.data_ptr(), gc.data_ptr(), p.numel() // n, n, dx.data_ptr(), _stream(p))
+        return dx
+
+
+def softmax(x):
+    """softmax over the last dim"""
+    return _Softmax.apply(x)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps, mode):
+        _need_device(x, w, b)
+        xc = _contig(x)
+        n = xc.shape[-1]
+        rows = xc.numel() // n
+        y = torch.empty_like(xc)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rinv = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _call('gator_t_layernorm_fwd', xc.data_ptr(), rows, n, w.data_ptr() if w is not None else None, b.data_ptr() if b is not None else None,
+              float(eps), int(mode), y.data_ptr(), mean.data_ptr(), rinv.data_ptr(), _stream(x))
+        ctx.save_for_backward(xc, mean, rinv, w)
+        ctx.eps, ctx.mode, ctx.has_b = eps, mode, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, mean, rinv, w = ctx.saved_tensors
+        gc = _contig(g)
+        n = xc.shape[-1]
+        rows = xc.numel() // n
+        dx = torch.empty_like(xc)
+        need_w = w is not None and ctx.needs_input_grad[1]
+        dyx = torch.empty_like(xc) if need_w else None
+        _call('gator_t_layernorm_bwd', gc.data_ptr(), xc.data_ptr(), mean.data_ptr(), rinv.data_ptr(), w.data_ptr() if w is not None else None, rows, n,
+              float(ctx.eps), int(ctx.mode), dx.data_ptr(), dyx.data_ptr() if need_w else None, _stream(xc))
+        gw = raw_sum(dyx.reshape(rows, n), [0]) if need_w else None
+        gb = raw_sum(gc.reshape(rows, n), [0]) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return dx, gw, gb, None, None
+
+
+def layernorm(x, w=None, b=None, eps=1e-5, mode=0):
+    """mode 0: nn.LayerNorm over the last dim; mode 1: lib/models/vanilla_transformer_encoder.py:31-34 (unbiased std, eps on the std)."""
+    return _LayerNorm.apply(x, w, b, float(eps), int(mode))
+
+
+class Generator:
+    """Philox stream of the dropout masks: (seed, running offset).  Every mask draws a fresh offset, so a step is reproducible
+    from (seed, step) and no two sites share random numbers."""
+
+    def __init__(self, seed=0):
+        self.seed, self.offset = int(seed), 0
+
+    def next_offset(self):
+        self.offset += 1
+        return self.offset
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rate, seed, offset):
+        _need_device(x)
+        xc = _contig(x)
+        out = torch.empty_like(xc)
+        mask = torch.empty(xc.shape, device=x.device, dtype=torch.uint8)
+        _call('gator_t_dropout', xc.data_ptr(), xc.numel(), float(rate), ctypes.c_uint64(seed), ctypes.c_uint64(offset), out.data_ptr(), mask.data_ptr(),
+              _stream(x))
+        ctx.save_for_backward(mask)
+        ctx.scale = 1.0 / (1.0 - rate)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mask, = ctx.saved_tensors
+        gc = _contig(g)
+        out = torch.empty_like(gc)
+        _call('gator_t_mask_scale', gc.data_ptr(), mask.data_ptr(), gc.numel(), float(ctx.scale), out.data_ptr(), _stream(gc))
+        return out, None, None, None
+
+
+def dropout(x, rate, gen, training=True):
+    """nn.Dropout: identity when not training or rate == 0."""
+    if not training or rate <= 0.0:
+        return x
+    return _Dropout.apply(x, float(rate), gen.seed, gen.next_offset())
+
+
+def drop_path(x, rate, gen, training=True):
+    """timm DropPath (lib/models/GAT.py:25, MDR.py:57): one keep decision per SAMPLE, kept samples scaled by 1/(1-rate)."""
+    if not training or rate <= 0.0:
+        return x
+    B = x.shape[0]
+    factor = torch.empty(B, device=x.device, dtype=torch.float32)
+    mask = torch.empty(B, device=x.device, dtype=torch.uint8)
+    _call('gator_t_dropout', None, B, float(rate), ctypes.c_uint64(gen.seed), ctypes.c_uint64(gen.next_offset()), factor.data_ptr(), mask.data_ptr(),
+          _stream(x))
+    return mul(x, factor.reshape([B] + [1] * (x.dim() - 1)))
+
+
+class _Contig(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return raw_copy(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def contiguous(x):
+    return x if x.is_contiguous() else _Contig.apply(x)
+
+
+class _Cat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dim, *ts):
+        _need_device(*ts)
+        dim = dim % ts[0].dim()
+        ctx.dim, ctx.sizes = dim, [t.shape[dim] for t in ts]
+        shape = list(ts[0].shape)
+        shape[dim] = sum(ctx.sizes)
+        out = torch.empty(shape, device=ts[0].device, dtype=torch.float32)
+        o = 0
+        for t in ts:
+            raw_unary(U_AFFINE, t, 1.0, 0.0, out=out.narrow(dim, o, t.shape[dim]))
+            o += t.shape[dim]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for n in ctx.sizes:
+            outs.append(g.narrow(ctx.dim, o, n))
+            o += n
+        return (None,) + tuple(outs)
+
+
+def cat(ts, dim):
+    return _Cat.apply(dim, *ts)
+
+
+class _Narrow(torch.autograd.Function):
+    """x.narrow(dim, start, length) as a view; the backward writes the gradient into a zero tensor with library kernels."""
+
+    @staticmethod
+    def forward(ctx, x, dim, start, length):
+        ctx.shape, ctx.dim, ctx.start, ctx.length = x.shape, dim, start, length
+        return x.narrow(dim, start, length)
+
+    @staticmethod
+    def backward(ctx, g):
+        out = zeros(ctx.shape, g.device)
+        raw_unary(U_AFFINE, g, 1.0, 0.0, out=out.narrow(ctx.dim, ctx.start, ctx.length))
+        return out, None, None, None
+
+
+def narrow(x, dim, start, length):
+    return _Narrow.apply(x, dim % x.dim(), start, length)
+
+
+class _Fork(torch.autograd.Function):
+    """n aliases of x whose gradients are summed by the library (instead of autograd's own accumulation with aten adds)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        acc = gs[0]
+        for g in gs[1:]:
+            acc = raw_binary(ADD, acc, g)
+        return acc, None
+
+
+def fork(x, n=2):
+    return _Fork.apply(x, n)

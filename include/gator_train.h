@@ -1,0 +1,83 @@
+/* gator_train.h -- C ABI of the training row: the fp32 primitives the training step of the GATOR path is
+ * composed from on the device.  The reference trains with torch autograd over aten kernels (lib/core/base.py:122-183: forward,
+ * five losses of lib/core/loss.py:10-118, loss.backward(), Adam); here every arithmetic operation of that step -- forward in
+ * training mode, backward, loss, optimiser -- is one of the HIP kernels below, sequenced by gator_amd/train/ (autograd only
+ * orders the calls).  All tensors are float32 device pointers described by a 4-D shape and ELEMENT strides (a stride of 0
+ * broadcasts), so transposes, head splits and broadcast operands need no copies.
+ *
+ * Every function returns 0 on success, else a hipError_t-mapped code with the message in gator_last_error() (gator_hip.h). */
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gator_stream;   /* hipStream_t */
+
+/* elementwise, broadcasting: out = a (op) b.  op: 0 add, 1 sub, 2 mul, 3 div.   replaces aten add/sub/mul/div */
+int gator_t_binary(int op, const float* a, const int64_t* stride_a, const float* b, const int64_t* stride_b, float* out,
+                   const int64_t* stride_out, const int64_t* shape4, gator_stream stream);
+
+/* elementwise: out = f(x; p0, p1).  op: 0 p0*x+p1, 1 gelu (erf form, torch F.gelu), 2 d gelu/dx, 3 exp, 4 rsqrt, 5 sqrt, 6 1/x,
+ * 7 |x|, 8 sign, 9 p0**x, 10 x*x, 11 (x > p0 ? 1 : 0) */
+int gator_t_unary(int op, const float* x, const int64_t* stride_x, float* out, const int64_t* stride_out, const int64_t* shape4,
+                  float p0, float p1, gator_stream stream);
+
+/* out[kept dims] (+)= sum over the dims with reduce4[d] != 0; out is contiguous over the kept dims in order.  Fixed summation
+ * order, double accumulators.  ws: device scratch of gator_t_reduce_ws_bytes() bytes (may be NULL when that is 0). */
+int64_t gator_t_reduce_ws_bytes(const int64_t* shape4, const int32_t* reduce4);
+int gator_t_reduce_sum(const float* x, const int64_t* stride_x, const int64_t* shape4, const int32_t* reduce4, float* out,
+                       int accumulate, void* ws, gator_stream stream);
+
+/* C[b1,b2] = alpha * A[b1,b2] (M x K) . B[b1,b2] (K x N) (+ bias[n]) (+ C if accumulate), fp32-input MFMA (exact fp32 products).
+ * strides in elements: A (m, k), B (k, n), C (m, n), and per batch level for each operand (0 broadcasts).
+ * ksplit > 1 (needs nb1 == nb2 == 1): K is cut into ksplit slices summed in slice order through ws (ksplit*M*N floats). */
+int gator_t_gemm(const float* A, const float* B, float* C, int M, int N, int K, const int64_t* stride_a2, const int64_t* stride_b2,
+                 const int64_t* stride_c2, int nb1, int nb2, const int64_t* batch_a2, const int64_t* batch_b2,
+                 const int64_t* batch_c2, const float* bias, float alpha, int accumulate, int ksplit, float* ws,
+                 gator_stream stream);
+
+/* rows of n contiguous floats.  mode 0: nn.LayerNorm (biased variance, eps inside the root); mode 1: the MDR LayerNorm
+ * (lib/models/vanilla_transformer_encoder.py:31-34: unbiased std, eps added to the std).  w, b may be NULL (no affine).
+ * forward saves mean[rows] and rinv[rows] (1/sqrt(var+eps) resp. 1/(std+eps)); backward writes dx and, if dy_xhat != NULL,
+ * dy * xhat (whose column sums are the weight gradient). */
+int gator_t_layernorm_fwd(const float* x, int64_t rows, int n, const float* w, const float* b, float eps, int mode, float* y,
+                          float* mean, float* rinv, gator_stream stream);
+int gator_t_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rinv, const float* w, int64_t rows,
+                          int n, float eps, int mode, float* dx, float* dy_xhat, gator_stream stream);
+
+/* softmax over rows of n contiguous floats, and its backward dx = p * (dp - sum(dp * p)) */
+int gator_t_softmax_fwd(const float* x, int64_t rows, int n, float* p, gator_stream stream);
+int gator_t_softmax_bwd(const float* p, const float* dp, int64_t rows, int n, float* dx, gator_stream stream);
+
+/* dropout: keep[i] = philox4x32-10(seed, offset; i) >= rate * 2^32; out = x * keep / (1 - rate); mask (uint8) is stored for
+ * gator_t_mask_scale (the backward: out = x * mask * scale).  x == NULL writes the scaled mask itself (DropPath's per-sample factor). */
+int gator_t_dropout(const float* x, int64_t n, float rate, uint64_t seed, uint64_t offset, float* out, uint8_t* mask,
+                    gator_stream stream);
+int gator_t_mask_scale(const float* x, const uint8_t* mask, int64_t n, float scale, float* out, gator_stream stream);
+
+/* torch.optim.Adam (lib/funcs_utils.py:91-95: lr only, betas 0.9/0.999, eps 1e-8, no weight decay) on one flat buffer */
+int gator_t_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int step, gator_stream stream);
+
+/* The mesh losses of lib/core/loss.py on device, value and gradient in one pass each.
+ * coord (CoordLoss, loss.py:10-25):   mean |pred*valid - target*valid|; valid broadcast by strides (shape4 / element strides).
+ * normal (NormalVectorLoss :59-86) and edge (EdgeLengthLoss :89-112) over faces [F,3] int32 of a [B,V,3] mesh.
+ * inc_ptr [V+1] / inc_idx [3F]: for every vertex the list of (3*face + corner) entries it appears in (ascending), so the
+ * gradient is GATHERED per vertex in a fixed order (no atomics, bit-reproducible).
+ * Each writes loss_out[0] = weight * loss and, if grad != NULL, ACCUMULATES weight * d loss / d pred into grad (layout of pred).
+ * ws: device scratch, gator_t_loss_ws_bytes(B, F) bytes. */
+int64_t gator_t_loss_ws_bytes(int64_t B, int64_t F);   /* also covers the coord loss of B*F*9 elements or fewer: pass F >= numel/(9B) */
+int gator_t_coord_loss(const float* pred, const float* target, const float* valid, const int64_t* stride_valid,
+                       const int64_t* shape4, float weight, float* loss_out, float* grad, void* ws, gator_stream stream);
+int gator_t_normal_loss(const float* pred, const float* target, const int32_t* faces, const int32_t* inc_ptr,
+                        const int32_t* inc_idx, int64_t B, int64_t V, int64_t F, float weight, float* loss_out, float* grad,
+                        void* ws, gator_stream stream);
+int gator_t_edge_loss(const float* pred, const float* target, const int32_t* faces, const int32_t* inc_ptr,
+                      const int32_t* inc_idx, int64_t B, int64_t V, int64_t F, float weight, float* loss_out, float* grad,
+                      void* ws, gator_stream stream);
+
+#ifdef __cplusplus
+}
+#endif

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, 'include', 'gator_hip.h')).read()
+    hdr = ''.join(open(os.path.join(ROOT, 'include', h)).read() for h in ('gator_hip.h', 'gator_train.h'))
     declared = set(re.findall(r'\b(gator_[a-z0-9_]+)\s*\(', hdr))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = ctypes.CDLL(_lib.LIB_PATH)
