@@ -120,3 +120,34 @@ def synthetic_pose2d(batch, num_joint, seed=0, jitter=None):
         x = x + jitter * rs.randn(batch, num_joint, 2)
     x = (x - x.mean(1, keepdims=True)) / x.std(1, keepdims=True)
     return x.astype(np.float32)
+
+
+def synthetic_faces(seed=0, num_faces=13776, num_verts=6890):
+    """Stand-in for the licence-gated SMPL face list (lib/core/base.py:63 reads main_dataset.mesh_model.face): seeded random
+    triangles with three distinct vertices each, every vertex used.  Same count as SMPL (13 776)."""
+    rs = np.random.RandomState(seed + 5)
+    a = rs.permutation(num_faces) % num_verts                     # every vertex appears at least once
+    b = (a + 1 + rs.randint(0, num_verts - 1, num_faces)) % num_verts
+    c = rs.randint(0, num_verts, num_faces)
+    bad = (c == a) | (c == b)
+    while bad.any():
+        c[bad] = rs.randint(0, num_verts, int(bad.sum()))
+        bad = (c == a) | (c == b)
+    return np.stack([a, b, c], 1).astype(np.int32)
+
+
+def training_targets(batch, num_joint, base, j_regressor_target, seed=0):
+    """Synthetic stand-ins for one training batch's targets and masks (data/Human36M/dataset.py:393-405 layout): gt mesh =
+    template + smooth noise (metres), regressed joints (mm), lifted pose (mm); one sample's mesh and one joint masked out."""
+    rs = np.random.RandomState(seed + 11)
+    mv = np.asarray(base['smpl_mean_vertices'], np.float32)
+    mesh = (mv[None] * (1.0 + 0.05 * rs.randn(batch, 1, 3)) + 0.02 * rs.randn(batch, mv.shape[0], 3)).astype(np.float32)
+    reg = (np.asarray(j_regressor_target, np.float32)[None] @ (mesh * 1000.0) + 5.0 * rs.randn(batch, j_regressor_target.shape[0], 3)).astype(np.float32)
+    lift = (300.0 * rs.randn(batch, num_joint, 3)).astype(np.float32)
+    mesh_valid = np.ones((batch, mv.shape[0], 1), np.float32)
+    reg_valid = np.ones((batch, j_regressor_target.shape[0], 1), np.float32)
+    lift_valid = np.ones((batch, num_joint, 1), np.float32)
+    if batch > 1:
+        mesh_valid[1] = 0                                          # a sample without a fitted mesh (dataset.py:399)
+        lift_valid[batch - 1, 3] = 0
+    return {'mesh': mesh, 'reg_pose3d': reg, 'lift_pose3d': lift, 'mesh_valid': mesh_valid, 'reg_pose3d_valid': reg_valid, 'lift_pose3d_valid': lift_valid}

@@ -1,0 +1,49 @@
+"""One training step of the reference (Trainer.train, lib/core/base.py:122-153): forward in training mode, the weighted losses,
+backward, Adam - every kernel from libgator_hip.so.  Data parallel: each rank steps on its shard and the flat gradient is
+all-reduced (averaged) once per step before the update."""
+import torch
+
+from . import losses as L
+from . import model as M
+from . import ops
+from .optim import Adam, FlatParams
+
+
+class Trainer:
+    def __init__(self, state_dict, consts, faces, j_regressor, device='cuda', lr=1e-3, rates=None, seed=0, edge_loss_start=15, dist=None):
+        self.params = FlatParams(state_dict, device)
+        self.consts = consts
+        self.losses = L.MeshLosses(faces, j_regressor, device)
+        self.optim = Adam(self.params, lr=lr)
+        self.rates = rates if rates is not None else M.Rates()
+        self.gen = ops.Generator(seed)
+        self.edge_loss_start = edge_loss_start
+        self.dist = dist
+        self.epoch = 0
+
+    @classmethod
+    def from_module(cls, module, faces, j_regressor, device='cuda', **kw):
+        """Train the parameters of a gator_amd.models.GATOR module (reference state_dict layout)."""
+        return cls({k: v.detach().cpu() for k, v in module.state_dict().items()}, M.consts_from_module(module, device), faces, j_regressor, device, **kw)
+
+    def state_dict(self):
+        """Reference-layout state_dict of the trained weights: module.load_state_dict(trainer.state_dict()) puts them on the
+        inference kernels."""
+        return self.params.state_dict()
+
+    def loss_and_grad(self, pose2d, targets, training=True):
+        P = self.params.views()
+        mesh, pose3d = M.gator_forward(P, self.consts, pose2d, self.gen, self.rates, training, self.params.buffers)
+        loss, parts = self.losses.total(mesh, pose3d, targets, with_edge=self.epoch > self.edge_loss_start)
+        grad, = torch.autograd.grad(loss, self.params.flat)
+        return loss.detach(), {k: v.detach() for k, v in parts.items()}, grad
+
+    def step(self, pose2d, targets):
+        """optimizer.zero_grad(); loss.backward(); optimizer.step()  (base.py:151-153)"""
+        loss, parts, grad = self.loss_and_grad(pose2d, targets)
+        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+            self.dist.all_reduce(grad)
+            grad = ops.raw_unary(ops.U_AFFINE, grad, 1.0 / self.dist.get_world_size(), 0.0)
+        self.optim.epoch = self.epoch
+        self.optim.step(grad)
+        return loss, parts

@@ -59,7 +59,7 @@ def hop_path_bias(sd, c, dtype, p='pose_lifter.get_hop_path_encoding.'):
     spatial = sp - 1
     spatial = torch.where(spatial > 0, spatial, torch.ones_like(sp))
     spatial = (1.0 / spatial.expand(H, -1, -1)).to(dtype)          # modules.py:88-93 (float32 in the reference)
-    spb = F.embedding(sp, sd[p + 'spatial_pos_encoder.weight'].to(dtype)).permute(2, 0, 1)
+    spb = F.embedding(sp, sd[p + 'spatial_pos_encoder.weight'].to(dtype), padding_idx=0).permute(2, 0, 1)   # padding_idx: row 0 gets no gradient
     ea = _t(c.edge_input, dtype).permute(2, 0, 1)
     ea = F.linear(ea.reshape(-1, J * J), sd[p + 'edge_encoder.weight'].to(dtype),
                   sd[p + 'edge_encoder.bias'].to(dtype)).reshape(-1, H, J, J)
@@ -138,7 +138,7 @@ def _custom_ln(x, a2, b2, eps=1e-6):
     return a2 * (x - mean) / (std + eps) + b2
 
 
-def mdr_forward(sd, c, pc, dtype=torch.float32, taps=None, p='pose2mesh.'):
+def mdr_forward(sd, c, pc, dtype=torch.float32, taps=None, p='pose2mesh.', train=False):
     """MDR.forward lib/models/MDR.py:124-170 (CrossAttentionBlock :64-69, CrossAttention :34-46,
     MultiHeadedAttention lib/models/vanilla_transformer_encoder.py:82-94, attention :36-46).
     pc [B,J,2+3+128] -> vertices [B,6890,3] (metres)."""
@@ -186,6 +186,9 @@ def mdr_forward(sd, c, pc, dtype=torch.float32, taps=None, p='pose2mesh.'):
     mat_b = F.linear(vf, g('bias_linear.weight'), g('bias_linear.bias'))
     if c.alpha:
         mat_b = F.layer_norm(mat_b, (3,), g('bias_norm.weight'), g('bias_norm.bias'), 1e-5)
+    elif train:  # .train(): batch statistics (running stats updated on copies; they do not enter the output)
+        mat_b = F.batch_norm(mat_b, g('bias_norm.running_mean').clone(), g('bias_norm.running_var').clone(),
+                             g('bias_norm.weight'), g('bias_norm.bias'), True, 0.1, 1e-5)
     else:  # BatchNorm1d(431) in eval mode: channels = the VERTEX axis (MDR.py:119,159)
         mat_b = F.batch_norm(mat_b, g('bias_norm.running_mean'), g('bias_norm.running_var'),
                              g('bias_norm.weight'), g('bias_norm.bias'), False, 0.1, 1e-5)
@@ -214,6 +217,64 @@ def gator_forward(sd, c, pose2d, dtype=torch.float32, taps=None):
             taps['pose3d'] = pose3d
         mesh = mdr_forward(sd, c, pc, dtype, taps)
     return mesh, pose3d
+
+
+# ---- training row: the differentiable forward and the losses, for torch-CPU autograd as the gradient oracle ----
+
+def gator_forward_train(sd, c, pose2d, dtype=torch.float64):
+    """GATOR.forward in .train() mode with every dropout / DropPath probability at 0 (the reference's RNG stream is not
+    reproducible elsewhere): differs from eval only in BatchNorm1d using batch statistics.  Differentiable w.r.t. sd tensors."""
+    pose2d = pose2d.to(dtype)
+    x_out, feat = gat_forward(sd, c, pose2d.reshape(len(pose2d), -1), dtype)
+    pose3d = x_out.reshape(-1, c.J, 3)
+    pc = torch.cat((pose2d, pose3d / 1000, feat), dim=2)
+    return mdr_forward(sd, c, pc, dtype, train=True), pose3d
+
+
+def coord_loss(pred, target, valid):
+    """CoordLoss(has_valid=True), lib/core/loss.py:10-25"""
+    return F.l1_loss(pred * valid, target * valid, reduction='mean')
+
+
+def normal_vector_loss(coord_out, coord_gt, face):
+    """NormalVectorLoss.forward, lib/core/loss.py:59-86"""
+    face = torch.as_tensor(np.asarray(face)).long()
+    nz = lambda v: F.normalize(v, p=2, dim=2)
+    v1_out = nz(coord_out[:, face[:, 1], :] - coord_out[:, face[:, 0], :])
+    v2_out = nz(coord_out[:, face[:, 2], :] - coord_out[:, face[:, 0], :])
+    v3_out = nz(coord_out[:, face[:, 2], :] - coord_out[:, face[:, 1], :])
+    v1_gt = nz(coord_gt[:, face[:, 1], :] - coord_gt[:, face[:, 0], :])
+    v2_gt = nz(coord_gt[:, face[:, 2], :] - coord_gt[:, face[:, 0], :])
+    normal_gt = nz(torch.cross(v1_gt, v2_gt, dim=2))
+    cos = [torch.abs(torch.sum(v * normal_gt, 2, keepdim=True)) for v in (v1_out, v2_out, v3_out)]
+    return torch.cat(cos, 1).mean()
+
+
+def edge_length_loss(coord_out, coord_gt, face):
+    """EdgeLengthLoss.forward, lib/core/loss.py:89-112"""
+    face = torch.as_tensor(np.asarray(face)).long()
+    def d(x, a, b):
+        return torch.sqrt(torch.sum((x[:, face[:, a], :] - x[:, face[:, b], :]) ** 2, 2, keepdim=True))
+    diffs = [torch.abs(d(coord_out, a, b) - d(coord_gt, a, b)) for a, b in ((0, 1), (0, 2), (1, 2))]
+    return torch.cat(diffs, 1).mean()
+
+
+def training_loss(pred_mesh, lift_pose, targets, j_regressor, face, with_edge=False, normal_weight=1e-1, edge_weight=20.0, joint_weight=1e-3):
+    """Trainer.train's loss, lib/core/base.py:136-148 (weights: lib/core/config.py:58-60)."""
+    dt = pred_mesh.dtype
+    t = lambda k: targets[k].to(dt)
+    pred_pose = torch.matmul(torch.as_tensor(np.asarray(j_regressor)).to(dt)[None], pred_mesh * 1000)
+    parts = {
+        'vertice': coord_loss(pred_mesh, t('mesh'), t('mesh_valid')),
+        'normal': normal_weight * normal_vector_loss(pred_mesh, t('mesh'), face),
+        'mesh2joint3d': joint_weight * coord_loss(pred_pose, t('reg_pose3d'), t('reg_pose3d_valid')),
+        'liftedjoint3d': joint_weight * coord_loss(lift_pose, t('lift_pose3d'), t('lift_pose3d_valid')),
+    }
+    loss = parts['vertice'] + parts['normal'] + parts['mesh2joint3d'] + parts['liftedjoint3d']
+    if with_edge:
+        parts['edge'] = edge_weight * edge_length_loss(pred_mesh, t('mesh'), face)
+        loss = loss + parts['edge']
+    return loss, parts
 
 
 # ---- caller-side pieces either side of the path ("next" rows, SURVEY 8f / a0 / a17) --------------------

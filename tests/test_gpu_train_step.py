@@ -1,0 +1,135 @@
+"""The training row end to end on the GPU: loss and per-parameter gradients of one training step from the HIP
+kernels against (a) the recording of the REAL reference's step (tests/golden/train_*.npz, reference in .train() with dropout
+p = 0) and (b) the oracle's torch-CPU float64 autograd at another batch size; then Adam against torch.optim.Adam, dropout
+reproducibility, and trained weights going back onto the inference kernels."""
+import numpy as np
+import pytest
+import torch
+
+from gator_amd import synthetic
+from gator_amd.train import model as M
+from gator_amd.train import ops
+from gator_amd.train.trainer import Trainer
+from tests.helpers import build_model, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def make_trainer(name, rates=None, seed=0, **kw):
+    zz, m = build_model(name, 'fused')
+    z = load_golden('train_' + name)
+    faces = synthetic.synthetic_faces(int(z['seed']))
+    jreg = synthetic.load_j_regressors()['h36m'].astype(np.float32)
+    return z, m, Trainer.from_module(m, faces, jreg, rates=rates if rates is not None else M.Rates(0.0), seed=seed, **kw), jreg
+
+
+def batch_of(z, B=None, shift=0):
+    J, seed = int(z['num_joint']), int(z['seed'])
+    base = synthetic.make_base_data(seed)
+    jreg = synthetic.load_j_regressors()['h36m'].astype(np.float32)
+    if B is None:
+        pose2d, B = z['pose2d'], int(z['batch'])
+    else:
+        pose2d = synthetic.synthetic_pose2d(B, J, seed + 3 + shift)
+    tg = synthetic.training_targets(B, J, base, jreg, seed + shift)
+    return torch.from_numpy(pose2d).cuda(), {k: torch.from_numpy(v).cuda() for k, v in tg.items()}
+
+
+@pytest.mark.parametrize('name', ['h36m17_bn', 'coco19_alpha'])
+def test_training_step_matches_reference_recording(name):
+    """Scale-free criterion per parameter tensor: |ours - ref fp64| <= 4 x |ref fp32 - ref fp64| + 2e-5 max|g|."""
+    z, m, tr, _ = make_trainer(name)
+    tr.epoch = 16                                                    # > edge_loss_start: all five losses (base.py:145-147)
+    x, tg = batch_of(z)
+    loss, parts, grad = tr.loss_and_grad(x, tg)
+    want = z['loss_parts_f64']
+    got = [float(parts[k]) for k in ('vertice', 'normal', 'edge', 'mesh2joint3d', 'liftedjoint3d')] + [float(loss)]
+    print('\n[%s] loss parts ours %s\n%s reference fp64 %s' % (name, np.round(got, 6).tolist(), ' ' * len(name), np.round(want, 6).tolist()))
+    assert np.allclose(got, want, rtol=2e-5)
+    g = grad.cpu().double().numpy()
+    names = [str(k) for k in z['param_names']]
+    assert sorted(tr.params.names) == names
+    slot = dict(zip(tr.params.names, tr.params.slots))
+    worst, worst_k = 0.0, None
+    absmax = dict(zip(names, z['grad_absmax']))
+    for i, k in enumerate(names):
+        a, b, shape = slot[k]
+        idx = z['probe_idx'][i]
+        n = int((idx >= 0).sum())
+        got = g[a:b][idx[:n]]
+        scale, noise = float(z['grad_absmax'][i]), float(z['ref32_minus_f64_max'][i])
+        err = np.abs(got - z['grad_f64'][i][:n]).max()
+        # (the key bias of a softmax attention has an exactly-zero gradient: its noise floor is set by its weight's gradient)
+        sibling = float(absmax.get(k[:-4] + 'weight', 0.0)) if k.endswith('.bias') else 0.0
+        tol = 4.0 * noise + 2e-5 * scale + 1e-6 * sibling + 1e-12
+        assert err <= tol, '%s: err %.3e tol %.3e (max|g| %.3e, ref fp32 noise %.3e)' % (k, err, tol, scale, noise)
+        assert abs(np.abs(g[a:b]).max() - scale) <= 4.0 * noise + 1e-4 * scale + 1e-6 * sibling + 1e-12, k
+        if scale > 1e-9 and err / scale > worst:
+            worst, worst_k = err / scale, k
+    print('[%s] %d parameter tensors; worst probe error / max|g| = %.2e (%s)' % (name, len(names), worst, worst_k))
+
+
+def test_training_step_matches_oracle_autograd_other_batch():
+    """B = 6 (not the recorded batch), J = 19 alpha variant, against torch-CPU float64 autograd of the oracle."""
+    from tests.test_oracle_train_golden import oracle_step
+    name = 'coco19_alpha'
+    z, m, tr, _ = make_trainer(name)
+    tr.epoch = 16
+    x, tg = batch_of(z, 6, shift=9)
+    loss, parts, grad = tr.loss_and_grad(x, tg)
+    _, oloss, oparts, ograds, _ = oracle_step(name, batch=6, seed_shift=9)
+    assert abs(float(loss) - float(oloss.detach())) <= 2e-5 * abs(float(oloss.detach()))
+    g = grad.cpu().double()
+    for k, (a, b, shape) in zip(tr.params.names, tr.params.slots):
+        og = ograds[k]
+        og = torch.zeros(shape, dtype=torch.float64) if og is None else og
+        scale = float(og.abs().max())
+        sib = ograds.get(k[:-4] + 'weight') if k.endswith('.bias') else None          # exactly-zero gradients: see above
+        sibling = float(sib.abs().max()) if sib is not None else 0.0
+        err = float((g[a:b].view(shape) - og).abs().max())
+        assert err <= 1e-4 * scale + 1e-6 * sibling + 1e-9, '%s: %.3e vs max|g| %.3e' % (k, err, scale)
+
+
+def test_adam_matches_torch_and_weights_return_to_inference_kernels():
+    name = 'h36m17_bn'
+    z, m, tr, _ = make_trainer(name, lr=2e-6)                          # Adam's first steps move every weight by ~lr: keep it first-order
+    x, tg = batch_of(z, 8, shift=2)
+    before = tr.params.flat.detach().clone()
+    ref_p = before.cpu().clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=2e-6)
+    losses = []
+    for it in range(3):
+        loss, parts, grad = tr.loss_and_grad(x, tg)
+        tr.optim.step(grad)
+        ref_p.grad = grad.cpu().clone()
+        opt.step()
+        losses.append(float(loss))
+    d = (tr.params.flat.detach().cpu() - ref_p.detach()).abs().max()
+    assert float(d) <= 2.4e-7, float(d)  # (an ulp of the largest weights)                                   # same update rule as torch.optim.Adam
+    assert float((tr.params.flat.detach() - before).abs().max()) > 4e-6
+    assert losses[2] < losses[0]                                        # three steps on one batch reduce its loss
+    rm = tr.params.buffers['pose2mesh.bias_norm.running_mean']
+    assert float(rm.abs().max()) > 0                                    # BatchNorm running statistics moved (momentum 0.1)
+    m.load_state_dict(tr.state_dict())                                  # trained weights -> the fused inference kernels
+    m.eval()
+    verts, pose3d = m(x)
+    P = {k: v for k, v in zip(tr.params.names, [tr.params.flat.detach()[a:b].view(s) for a, b, s in tr.params.slots])}
+    mesh_eval, p3 = M.gator_forward(P, tr.consts, x, training=False, buffers=tr.params.buffers)
+    assert float((verts - mesh_eval).abs().max()) * 1e3 <= 2e-3        # eval forward of the training path == inference path (mm)
+    assert float((pose3d - p3).abs().max()) <= 2e-3
+
+
+def test_dropout_training_step_is_reproducible_and_active():
+    name = 'coco19_alpha'
+    z, m, tr, _ = make_trainer(name, rates=M.Rates(), seed=5)
+    x, tg = batch_of(z, 4, shift=1)
+    l1, _, g1 = tr.loss_and_grad(x, tg)
+    l2, _, g2 = tr.loss_and_grad(x, tg)                                  # the generator advanced: other masks
+    z2, m2, tr2, _ = make_trainer(name, rates=M.Rates(), seed=5)
+    l3, _, g3 = tr2.loss_and_grad(x, tg)                                 # fresh trainer, same seed: bit-identical
+    assert torch.equal(g1, g3) and float(l1) == float(l3)
+    assert not torch.equal(g1, g2)
+    z0, m0, tr0, _ = make_trainer(name)
+    l0, _, g0 = tr0.loss_and_grad(x, tg)
+    assert float((g1 - g0).abs().max()) > 0
+    assert torch.isfinite(g1).all()

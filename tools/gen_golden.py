@@ -84,6 +84,7 @@ def install_shims(scratch, alpha):
     sys.modules.update({'core': core, 'core.config': cc})
     fu = types.ModuleType('funcs_utils')
     fu.load_checkpoint = lambda *a, **k: (_ for _ in ()).throw(ValueError('No checkpoint exists'))
+    fu.stop = sys.exit
     sys.modules['funcs_utils'] = fu
     # cv2: only getAffineTransform is reached (lib/aug_utils.py:164-167)
     cv2 = types.ModuleType('cv2')
@@ -229,6 +230,95 @@ def run_variant(name, J, alpha, seed, B=4, upsample_gain=0.2, subset=None, out_n
     os.chdir(REPO)
 
 
+def train_golden(name, J, alpha, seed, B=4):
+    """One training step's loss and gradients from the REAL reference: model.train() with every nn.Dropout at p = 0 (DropPath
+    is the identity stub) - the reference's RNG stream cannot be reproduced elsewhere - so BatchNorm1d runs on batch statistics;
+    loss = lib/core/base.py:137-148 incl. the edge term, criteria = lib/core/loss.py get_loss(faces) loaded from its file.
+    Stores loss parts and, per parameter, the gradient's max / norm and 48 fixed entries, from the fp32 run and an fp64 run."""
+    import importlib.util
+    import scipy.sparse as sps
+    scratch = tempfile.mkdtemp(prefix='gator_golden_')
+    for m in [k for k in sys.modules if k.split('.')[0] in ('models', 'graph_utils', 'coarsening', 'core', 'funcs_utils')]:
+        del sys.modules[m]
+    install_shims(scratch, alpha)
+    base = synthetic.make_base_data(seed)
+    rs = base['rs']
+    skeleton, flips = gc.joint_setting(J)
+    adj0 = gc.build_adj(J, skeleton, flips)
+    sp, path = gc.floyd_warshall(gc.delete_symmetric_edges(adj0))
+    write_base_data(scratch, base, sp, path, '3dpw' if J == 19 else 'h36m')
+    os.chdir(scratch)
+    import models  # noqa
+    from models.backbones import mesh as ref_mesh
+    ref_mesh.Mesh.__init__.__defaults__ = ('data/base_data/mesh_downsampling.npz', 1, 1, torch.device('cpu'))
+    spec = importlib.util.spec_from_file_location('ref_core_loss', os.path.join(REF, 'lib', 'core', 'loss.py'))
+    ref_loss = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_loss)
+    graph_adj = [None, sps.csr_matrix(adj0)]
+    model = models.GATOR.get_model(J, 128, 6, graph_adj, 1, torch.Tensor(synthetic.model_j_regressor(J)))
+    sd = model.state_dict()
+    new = synthetic.seeded_state_dict(synthetic.shapes_of(sd), rs)
+    sd.update({k: torch.from_numpy(v) for k, v in new.items()})
+    model.load_state_dict(sd)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    faces = synthetic.synthetic_faces(seed)
+    jreg_t = synthetic.load_j_regressors()['h36m'].astype(np.float32)          # target_joint_set regressor (base.py:104)
+    pose2d = synthetic.synthetic_pose2d(B, J, seed + 3)
+    tg = synthetic.training_targets(B, J, base, jreg_t, seed)
+    crit = ref_loss.get_loss(faces=faces)
+
+    def step(mdl, dt):
+        t = {k: torch.from_numpy(v).to(dt) for k, v in tg.items()}
+        mdl.zero_grad()
+        pred_mesh, lift_pose = mdl(torch.from_numpy(pose2d).to(dt))
+        pred_pose = torch.matmul(torch.from_numpy(jreg_t).to(dt)[None, :, :], pred_mesh * 1000)
+        l1 = crit[0](pred_mesh, t['mesh'], t['mesh_valid'])
+        l2 = 1e-1 * crit[1](pred_mesh, t['mesh'])
+        l4 = 1e-3 * crit[3](pred_pose, t['reg_pose3d'], t['reg_pose3d_valid'])
+        l5 = 1e-3 * crit[4](lift_pose, t['lift_pose3d'], t['lift_pose3d_valid'])
+        l3 = 20 * crit[2](pred_mesh, t['mesh'])
+        loss = l1 + l2 + l4 + l5 + l3
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in mdl.named_parameters()}
+        parts = np.array([float(v) for v in (l1, l2, l3, l4, l5, loss)])
+        return parts, grads, pred_mesh.detach(), lift_pose.detach()
+
+    parts32, g32, mesh32, _ = step(model, torch.float32)
+    m64 = model.double()
+    for blk in m64.pose_lifter.blocks:
+        blk.adj = blk.adj.double()
+        blk.gcn.adj = blk.gcn.adj.double()
+    hp = m64.pose_lifter.get_hop_path_encoding
+    hp.edg_adj = hp.edg_adj.double()
+    hp.spatial = hp.spatial.double()
+    parts64, g64, mesh64, lift64 = step(m64, torch.float64)
+    names = sorted(g64.keys())
+    prs = np.random.RandomState(1234)
+    out = dict(seed=np.int64(seed), alpha=np.bool_(alpha), num_joint=np.int64(J), batch=np.int64(B), pose2d=pose2d,
+               loss_parts_f32=parts32, loss_parts_f64=parts64, param_names=np.array(names),
+               mesh_f64_probe=mesh64.numpy()[:, ::97], lift_pose_f64=lift64.numpy())
+    probe_idx, probe64, probe32, gmax, gnorm, noise = [], [], [], [], [], []
+    for k in names:
+        a64, a32 = g64[k].reshape(-1).numpy(), g32[k].reshape(-1).double().numpy()
+        idx = np.sort(prs.choice(a64.size, size=min(48, a64.size), replace=False))
+        pad = np.full(48, -1, np.int64)
+        pad[:idx.size] = idx
+        v64, v32 = np.zeros(48), np.zeros(48)
+        v64[:idx.size], v32[:idx.size] = a64[idx], a32[idx]
+        probe_idx.append(pad); probe64.append(v64); probe32.append(v32)
+        gmax.append(np.abs(a64).max()); gnorm.append(np.sqrt((a64 ** 2).sum())); noise.append(np.abs(a32 - a64).max())
+    out.update(probe_idx=np.stack(probe_idx), grad_f64=np.stack(probe64), grad_f32=np.stack(probe32), grad_absmax=np.array(gmax),
+               grad_norm=np.array(gnorm), ref32_minus_f64_max=np.array(noise))
+    np.savez(os.path.join(OUT, 'train_' + name + '.npz'), **out)
+    rel = np.array(noise) / np.maximum(np.array(gmax), 1e-300)
+    print('train_%s: loss %.6f (fp32 %.6f) parts %s; %d parameter tensors, ref fp32-vs-fp64 gradient error / max|g|: median %.1e max %.1e'
+          % (name, parts64[-1], parts32[-1], parts64[:5].round(5).tolist(), len(names), np.median(rel), rel.max()))
+    os.chdir(REPO)
+
+
 def demo_preprocess_golden():
     """Config 1 plumbing (demo/run.py:193-198,124-133): raw COCO-17 joints -> [1,19,2] normalised input."""
     scratch = tempfile.mkdtemp(prefix='gator_golden_')
@@ -349,6 +439,9 @@ if __name__ == '__main__':
         sub = np.sort(np.random.RandomState(99).permutation(6890)[:512])
         run_variant('h36m17_bn', 17, False, seed=0, B=64, upsample_gain=0.2, subset=sub, out_name='scale_gain02')
         run_variant('h36m17_bn', 17, False, seed=0, B=64, upsample_gain=1.0, subset=sub, out_name='scale_gain10')
+    if not only or 'train' in only:
+        train_golden('h36m17_bn', 17, False, seed=0)
+        train_golden('coco19_alpha', 19, True, seed=100)
     if not only or 'rigid' in only:
         rigid_align_golden()
     if not only or 'preprocess' in only:
