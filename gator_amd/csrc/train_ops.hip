@@ -89,7 +89,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {       // all
 // general form: one workgroup per (output element, slice of the reduction space); the reduction index runs over the reduced
 // dims in order (last reduced dim fastest)
 __global__ __launch_bounds__(kThreads) void k_t_reduce(const float* __restrict__ x, Str4 sx, Idx4 keep, Idx4 red, int64_t R, int nsplit,
-                                                       double* __restrict__ part) {
+                                                       double* __restrict__ part, float* __restrict__ out, int accumulate) {
     __shared__ double sh[4];
     const int64_t o = blockIdx.x;
     const int sp = blockIdx.y;
@@ -109,23 +109,43 @@ __global__ __launch_bounds__(kThreads) void k_t_reduce(const float* __restrict__
     double acc = 0.0;
     for (int64_t r = r0 + threadIdx.x; r < r1; r += kThreads) acc += (double)x[base + offset4(r, red, sx)];
     acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) part[o * nsplit + sp] = acc;
+    if (threadIdx.x == 0) {
+        if (nsplit == 1)
+            out[o] = accumulate ? out[o] + (float)acc : (float)acc;
+        else
+            part[o * nsplit + sp] = acc;
+    }
 }
 
 // column form: x is [R, N] with row stride ld, N contiguous outputs; thread column-coalesced
 __global__ __launch_bounds__(kThreads) void k_t_reduce_cols(const float* __restrict__ x, int64_t R, int64_t N, int64_t ld, int nsplit,
-                                                            double* __restrict__ part) {
+                                                            double* __restrict__ part, float* __restrict__ out, int accumulate) {
     __shared__ double sh[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t col = blockIdx.x * 64 + tx;
     const int sp = blockIdx.y;
     const int64_t per = (R + nsplit - 1) / nsplit, r0 = sp * per, r1 = r0 + per < R ? r0 + per : R;
-    double acc = 0.0;
-    if (col < N)
-        for (int64_t r = r0 + ty; r < r1; r += 4) acc += (double)x[r * ld + col];
-    sh[ty][tx] = acc;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;              // four independent loads in flight per thread, fixed order
+    if (col < N) {
+        int64_t r = r0 + ty;
+        for (; r + 12 < r1; r += 16) {
+            const float v0 = x[r * ld + col], v1 = x[(r + 4) * ld + col], v2 = x[(r + 8) * ld + col], v3 = x[(r + 12) * ld + col];
+            a0 += (double)v0;
+            a1 += (double)v1;
+            a2 += (double)v2;
+            a3 += (double)v3;
+        }
+        for (; r < r1; r += 4) a0 += (double)x[r * ld + col];
+    }
+    sh[ty][tx] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (ty == 0 && col < N) part[col * nsplit + sp] = sh[0][tx] + sh[1][tx] + sh[2][tx] + sh[3][tx];
+    if (ty == 0 && col < N) {
+        const double t = sh[0][tx] + sh[1][tx] + sh[2][tx] + sh[3][tx];
+        if (nsplit == 1)
+            out[col] = accumulate ? out[col] + (float)t : (float)t;
+        else
+            part[col * nsplit + sp] = t;
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void k_t_reduce_finish(const double* __restrict__ part, int nsplit, int64_t n_out, float* __restrict__ out,
@@ -182,8 +202,9 @@ ReducePlan plan_reduce(const int64_t* shape, const int64_t* stride, const int32_
         }
     }
     const int64_t units = p.cols ? (p.n_out + 63) / 64 : p.n_out;
+    const int64_t min_rows = p.cols ? 32 : 512;                  // rows (column form) / elements (general form) per slice
     int ns = 1;
-    while (units * ns < 1024 && p.R / (ns * 2) >= 512 && ns < 1024) ns *= 2;
+    while (units * ns < 2048 && p.R / (ns * 2) >= min_rows && ns < 1024) ns *= 2;
     p.nsplit = ns;
     return p;
 }
@@ -202,10 +223,11 @@ struct GemmArgs {
     int a_kfast, b_nfast;
 };
 
-// 64x64 output tile per workgroup, K in steps of 16 through LDS ([k][m] / [k][n] images: the MFMA operand fragments are
+// 64x64 output tile per workgroup, K in steps of 32 through LDS ([k][m] / [k][n] images: the MFMA operand fragments are
 // conflict-free row reads); wave w owns the 32x32 quadrant (w>>1, w&1); v_mfma_f32_32x32x2_f32 keeps fp32 products exact.
 __global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
-    __shared__ float As[2][16][65], Bs[2][16][65];
+    constexpr int BK = 32;
+    __shared__ float As[2][BK][65], Bs[2][BK][65];
     const int tiles_n = (g.N + 63) / 64;
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
     const int bi1 = blockIdx.y / g.nb2, bi2 = blockIdx.y % g.nb2;
@@ -213,33 +235,34 @@ __global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
     const float* B = g.B + bi1 * g.b1 + bi2 * g.b2;
     const int m0 = tm * 64, n0 = tn * 64;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-    const int kper = ((g.K + g.ksplit - 1) / g.ksplit + 15) / 16 * 16;
+    const int kper = ((g.K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK;
     const int kbeg = blockIdx.z * kper, kend = kbeg + kper < g.K ? kbeg + kper : g.K;
     f32x16t acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float ra[4], rb[4];
+    float ra[8], rb[8];
+    // lanes run along whichever index is contiguous in memory: (k fast) k = t % 32, m = t / 32 + 8 i; (m fast) m = t % 64, k = t / 64 + 4 i
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             int m, k;
-            if (g.a_kfast) { k = t & 15; m = (t >> 4) + 16 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
+            if (g.a_kfast) { k = t & 31; m = (t >> 5) + 8 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
             const bool ok = (m0 + m) < g.M && (k0 + k) < kend;
             ra[i] = ok ? A[(int64_t)(m0 + m) * g.am + (int64_t)(k0 + k) * g.ak] : 0.f;
             int n, kk;
-            if (g.b_nfast) { n = t & 63; kk = (t >> 6) + 4 * i; } else { kk = t & 15; n = (t >> 4) + 16 * i; }
+            if (g.b_nfast) { n = t & 63; kk = (t >> 6) + 4 * i; } else { kk = t & 31; n = (t >> 5) + 8 * i; }
             const bool okb = (n0 + n) < g.N && (k0 + kk) < kend;
             rb[i] = okb ? B[(int64_t)(k0 + kk) * g.bk + (int64_t)(n0 + n) * g.bn] : 0.f;
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             int m, k;
-            if (g.a_kfast) { k = t & 15; m = (t >> 4) + 16 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
+            if (g.a_kfast) { k = t & 31; m = (t >> 5) + 8 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
             As[buf][k][m] = ra[i];
             int n, kk;
-            if (g.b_nfast) { n = t & 63; kk = (t >> 6) + 4 * i; } else { kk = t & 15; n = (t >> 4) + 16 * i; }
+            if (g.b_nfast) { n = t & 63; kk = (t >> 6) + 4 * i; } else { kk = t & 31; n = (t >> 5) + 8 * i; }
             Bs[buf][kk][n] = rb[i];
         }
     };
@@ -249,11 +272,11 @@ __global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
         stash(0);
     }
     __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        const bool more = k0 + 16 < kend;
-        if (more) fetch(k0 + 16);                       // next slice's loads fly over this slice's MFMAs
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) fetch(k0 + BK);                       // next slice's loads fly over this slice's MFMAs
 #pragma unroll
-        for (int kk = 0; kk < 16; kk += 2) {
+        for (int kk = 0; kk < BK; kk += 2) {
             const float a = As[buf][kk + (lane >> 5)][wm * 32 + (lane & 31)];
             const float b = Bs[buf][kk + (lane >> 5)][wn * 32 + (lane & 31)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -396,9 +419,11 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2])
 }
 
 __global__ __launch_bounds__(kThreads) void k_t_dropout(const float* __restrict__ x, int64_t n, uint32_t thresh, float scale, uint64_t seed,
-                                                        uint64_t offset, float* __restrict__ out, uint8_t* __restrict__ mask) {
+                                                        uint64_t offset, const uint64_t* __restrict__ step_counter, float* __restrict__ out,
+                                                        uint8_t* __restrict__ mask) {
     const int64_t q = blockIdx.x * (int64_t)kThreads + threadIdx.x;          // four elements per thread: one philox block
     if (q * 4 >= n) return;
+    if (step_counter) offset += step_counter[0] << 32;
     uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
     uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
 #pragma unroll
@@ -420,8 +445,18 @@ __global__ __launch_bounds__(kThreads) void k_t_mask_scale(const float* __restri
         out[i] = mask[i] ? x[i] * scale : 0.f;
 }
 
+__global__ void k_t_step_advance(uint64_t* c) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += 1;
+}
+
 __global__ __launch_bounds__(kThreads) void k_t_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                     int64_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+                                                     int64_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                     const uint64_t* __restrict__ step_counter) {
+    if (step_counter) {                                              // bias corrections of the step held on the device (graph replay)
+        const double t = (double)step_counter[0];
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    }
     for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
         const float gi = g[i];
         const float mi = m[i] + (gi - m[i]) * (1.f - b1);            // torch: exp_avg.lerp_(grad, 1 - beta1)
@@ -545,12 +580,12 @@ __global__ __launch_bounds__(kThreads) void k_t_face_gather(const float* __restr
     }
 }
 
-__global__ void k_t_loss_finish(const double* __restrict__ part, int n, double scale, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += part[i];
-        out[0] = (float)(s * scale);
-    }
+__global__ __launch_bounds__(kThreads) void k_t_loss_finish(const double* __restrict__ part, int n, double scale, float* __restrict__ out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += kThreads) s += part[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[0] = (float)(s * scale);
 }
 
 constexpr int kLossBlocks = 2048;
@@ -578,7 +613,7 @@ int face_loss(bool normal, const float* pred, const float* target, const int32_t
     else
         hipLaunchKernelGGL(k_t_edge_face, dim3(blocks), dim3(kThreads), 0, st, pred, target, faces, B, V, F, fg, part);
     const double inv = 1.0 / ((double)B * 3.0 * (double)F);
-    hipLaunchKernelGGL(k_t_loss_finish, dim3(1), dim3(64), 0, st, part, blocks, (double)weight * inv, loss_out);
+    hipLaunchKernelGGL(k_t_loss_finish, dim3(1), dim3(kThreads), 0, st, part, blocks, (double)weight * inv, loss_out);
     if (grad)
         hipLaunchKernelGGL(k_t_face_gather, dim3(grid_for(B * V)), dim3(kThreads), 0, st, fg, inc_ptr, inc_idx, B, V, F, (float)(weight * inv), grad);
     return check_launch(normal ? "gator_t_normal_loss" : "gator_t_edge_loss");
@@ -630,7 +665,7 @@ int64_t gator_t_reduce_ws_bytes(const int64_t* shape, const int32_t* red) {
     int64_t dummy[4] = {0, 0, 0, 0};
     ReducePlan p = plan_reduce(shape, dummy, red);      // without strides the general form is assumed: an upper bound on nsplit
     int ns = 1;
-    while (ns < 1024 && p.R / (ns * 2) >= 512) ns *= 2;
+    while (ns < 1024 && p.R / (ns * 2) >= 32) ns *= 2;
     return p.n_out * ns * (int64_t)sizeof(double);
 }
 
@@ -642,12 +677,14 @@ int gator_t_reduce_sum(const float* x, const int64_t* sx, const int64_t* shape, 
     hipStream_t st = (hipStream_t)stream;
     double* part = static_cast<double*>(ws);
     if (p.cols)
-        hipLaunchKernelGGL(k_t_reduce_cols, dim3((unsigned)((p.n_out + 63) / 64), p.nsplit), dim3(kThreads), 0, st, x, p.R, p.n_out, p.ld, p.nsplit, part);
+        hipLaunchKernelGGL(k_t_reduce_cols, dim3((unsigned)((p.n_out + 63) / 64), p.nsplit), dim3(kThreads), 0, st, x, p.R, p.n_out, p.ld, p.nsplit, part, out,
+                           accumulate);
     else {
         if (p.n_out > 0x7fffffffLL) return fail(1, "gator_t_reduce_sum: too many outputs");
-        hipLaunchKernelGGL(k_t_reduce, dim3((unsigned)p.n_out, p.nsplit), dim3(kThreads), 0, st, x, p.s, p.keep, p.red, p.R, p.nsplit, part);
+        hipLaunchKernelGGL(k_t_reduce, dim3((unsigned)p.n_out, p.nsplit), dim3(kThreads), 0, st, x, p.s, p.keep, p.red, p.R, p.nsplit, part, out, accumulate);
     }
-    hipLaunchKernelGGL(k_t_reduce_finish, dim3((unsigned)((p.n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, p.nsplit, p.n_out, out,
+    if (p.nsplit > 1)
+        hipLaunchKernelGGL(k_t_reduce_finish, dim3((unsigned)((p.n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, p.nsplit, p.n_out, out,
                        accumulate, 1.0f);
     return check_launch("gator_t_reduce_sum");
 }
@@ -709,14 +746,21 @@ int gator_t_softmax_bwd(const float* p, const float* dp, int64_t rows, int n, fl
     return check_launch("gator_t_softmax_bwd");
 }
 
-int gator_t_dropout(const float* x, int64_t n, float rate, uint64_t seed, uint64_t offset, float* out, uint8_t* mask, gator_stream stream) {
+int gator_t_step_advance(uint64_t* step_counter, gator_stream stream) {
+    if (!step_counter) return fail(1, "gator_t_step_advance: null counter");
+    hipLaunchKernelGGL(k_t_step_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, step_counter);
+    return check_launch("gator_t_step_advance");
+}
+
+int gator_t_dropout(const float* x, int64_t n, float rate, uint64_t seed, uint64_t offset, const uint64_t* step_counter, float* out, uint8_t* mask,
+                    gator_stream stream) {
     if (!out || !mask || rate < 0.f || rate >= 1.f) return fail(1, "gator_t_dropout: bad argument");
     if (n == 0) return 0;
     const double t = (double)rate * 4294967296.0;
     const uint32_t thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
     const int64_t quads = (n + 3) / 4;
     hipLaunchKernelGGL(k_t_dropout, dim3((unsigned)((quads + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream, x, n, thresh,
-                       1.0f / (1.0f - rate), seed, offset, out, mask);
+                       1.0f / (1.0f - rate), seed, offset, step_counter, out, mask);
     return check_launch("gator_t_dropout");
 }
 
@@ -728,12 +772,13 @@ int gator_t_mask_scale(const float* x, const uint8_t* mask, int64_t n, float sca
 }
 
 int gator_t_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
-                 int step, gator_stream stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail(1, "gator_t_adam: bad argument");
+                 int step, const uint64_t* step_counter, gator_stream stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || (step < 1 && !step_counter)) return fail(1, "gator_t_adam: bad argument");
+    if (step < 1) step = 1;
     if (n == 0) return 0;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(k_t_adam, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                       (float)bc1, (float)sqrt(bc2));
+                       (float)bc1, (float)sqrt(bc2), step_counter);
     return check_launch("gator_t_adam");
 }
 
@@ -756,7 +801,7 @@ int gator_t_coord_loss(const float* pred, const float* target, const float* vali
     double* part = static_cast<double*>(ws);
     hipLaunchKernelGGL(k_t_coord_loss, dim3(blocks), dim3(kThreads), 0, st, pred, target, valid, S, n, total, (float)((double)weight / (double)total), grad,
                        part);
-    hipLaunchKernelGGL(k_t_loss_finish, dim3(1), dim3(64), 0, st, part, blocks, (double)weight / (double)total, loss_out);
+    hipLaunchKernelGGL(k_t_loss_finish, dim3(1), dim3(kThreads), 0, st, part, blocks, (double)weight / (double)total, loss_out);
     return check_launch("gator_t_coord_loss");
 }
 

@@ -110,8 +110,9 @@ def raw_gemm(a, b, out=None, bias=None, alpha=1.0, accumulate=False):
         out = torch.empty((n1, n2, M, N), device=a.device, dtype=torch.float32)
     sa, sb, so = a.stride(), b.stride(), out.stride()
     ksplit, ws = 1, None
-    if n1 * n2 == 1 and K >= 4096 and ((M + 63) // 64) * ((N + 63) // 64) < 256:
-        ksplit = max(1, min(64, K // 1024, 512 // (((M + 63) // 64) * ((N + 63) // 64))))
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if n1 * n2 == 1 and K >= 512 and tiles < 256:          # few output tiles, long K: slices of >= 128 fill the chip
+        ksplit = max(1, min(256, K // 128, 1024 // tiles))
         if ksplit > 1:
             ws = torch.empty(ksplit * M * N, device=a.device, dtype=torch.float32)
     _call('gator_t_gemm', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, _I64x2(sa[2], sa[3]), _I64x2(sb[2], sb[3]), _I64x2(so[2], so[3]),
@@ -414,25 +415,39 @@ def layernorm(x, w=None, b=None, eps=1e-5, mode=0):
 
 class Generator:
     """Philox stream of the dropout masks: (seed, running offset).  Every mask draws a fresh offset, so a step is reproducible
-    from (seed, step) and no two sites share random numbers."""
+    from (seed, step) and no two sites share random numbers.  With a device step counter (`device_steps(dev)`) the offset's high
+    word comes from device memory: `begin_step()` resets the site index and advances the counter with a kernel, so a training
+    step captured in a hipGraph draws new masks at every replay."""
 
     def __init__(self, seed=0):
-        self.seed, self.offset = int(seed), 0
+        self.seed, self.offset, self.counter = int(seed), 0, None
+
+    def device_steps(self, device):
+        self.counter = torch.zeros(1, device=device, dtype=torch.int64)
+        return self
+
+    def begin_step(self):
+        if self.counter is not None:
+            self.offset = 0
+            _call('gator_t_step_advance', self.counter.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(self.counter.device).cuda_stream))
 
     def next_offset(self):
         self.offset += 1
         return self.offset
 
+    def counter_ptr(self):
+        return self.counter.data_ptr() if self.counter is not None else None
+
 
 class _Dropout(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, rate, seed, offset):
+    def forward(ctx, x, rate, seed, offset, counter):
         _need_device(x)
         xc = _contig(x)
         out = torch.empty_like(xc)
         mask = torch.empty(xc.shape, device=x.device, dtype=torch.uint8)
-        _call('gator_t_dropout', xc.data_ptr(), xc.numel(), float(rate), ctypes.c_uint64(seed), ctypes.c_uint64(offset), out.data_ptr(), mask.data_ptr(),
-              _stream(x))
+        _call('gator_t_dropout', xc.data_ptr(), xc.numel(), float(rate), ctypes.c_uint64(seed), ctypes.c_uint64(offset), counter, out.data_ptr(),
+              mask.data_ptr(), _stream(x))
         ctx.save_for_backward(mask)
         ctx.scale = 1.0 / (1.0 - rate)
         return out
@@ -443,14 +458,14 @@ class _Dropout(torch.autograd.Function):
         gc = _contig(g)
         out = torch.empty_like(gc)
         _call('gator_t_mask_scale', gc.data_ptr(), mask.data_ptr(), gc.numel(), float(ctx.scale), out.data_ptr(), _stream(gc))
-        return out, None, None, None
+        return out, None, None, None, None
 
 
 def dropout(x, rate, gen, training=True):
     """nn.Dropout: identity when not training or rate == 0."""
     if not training or rate <= 0.0:
         return x
-    return _Dropout.apply(x, float(rate), gen.seed, gen.next_offset())
+    return _Dropout.apply(x, float(rate), gen.seed, gen.next_offset(), gen.counter_ptr())
 
 
 def drop_path(x, rate, gen, training=True):
@@ -460,8 +475,8 @@ def drop_path(x, rate, gen, training=True):
     B = x.shape[0]
     factor = torch.empty(B, device=x.device, dtype=torch.float32)
     mask = torch.empty(B, device=x.device, dtype=torch.uint8)
-    _call('gator_t_dropout', None, B, float(rate), ctypes.c_uint64(gen.seed), ctypes.c_uint64(gen.next_offset()), factor.data_ptr(), mask.data_ptr(),
-          _stream(x))
+    _call('gator_t_dropout', None, B, float(rate), ctypes.c_uint64(gen.seed), ctypes.c_uint64(gen.next_offset()), gen.counter_ptr(), factor.data_ptr(),
+          mask.data_ptr(), _stream(x))
     return mul(x, factor.reshape([B] + [1] * (x.dim() - 1)))
 
 

@@ -68,6 +68,7 @@ class Adam:
         self.exp_avg = ops.zeros((params.numel,), params.flat.device)
         self.exp_avg_sq = ops.zeros((params.numel,), params.flat.device)
         self.step_count, self.epoch = 0, 0
+        self.device_step = None                      # device uint64 step counter (hipGraph replay): overrides step_count in the kernel
 
     @property
     def lr(self):
@@ -78,4 +79,5 @@ class Adam:
         f = self.p.flat
         st = ctypes.c_void_p(torch.cuda.current_stream(f.device).cuda_stream)
         _lib.check(_lib.load().gator_t_adam(f.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.p.numel,
-                                            float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count, st), 'gator_t_adam')
+                                            float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count,
+                                            self.device_step.data_ptr() if self.device_step is not None else None, st), 'gator_t_adam')

@@ -20,6 +20,7 @@ class Trainer:
         self.edge_loss_start = edge_loss_start
         self.dist = dist
         self.epoch = 0
+        self._graph = None
 
     @classmethod
     def from_module(cls, module, faces, j_regressor, device='cuda', **kw):
@@ -38,9 +39,45 @@ class Trainer:
         grad, = torch.autograd.grad(loss, self.params.flat)
         return loss.detach(), {k: v.detach() for k, v in parts.items()}, grad
 
+    def capture(self, pose2d, targets):
+        """Capture forward + losses + backward of one step (this batch shape) into a hipGraph: the ~3 000 kernel launches of a step
+        become one graph launch, the host only replays.  Dropout offsets and Adam's step index come from a device counter that the
+        graph itself advances, so every replay draws new masks.  The gradient all-reduce and the Adam launch stay outside the graph."""
+        dev = self.params.flat.device
+        self.gen.device_steps(dev)
+        self.optim.device_step = self.gen.counter
+        self._x = pose2d.clone()
+        self._tg = {k: v.clone() for k, v in targets.items()}
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                        # warm-up off the capture: workspaces and the allocator's pools
+            for _ in range(2):
+                self._body()
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.gen.counter.zero_()
+        self.optim.step_count = 0
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._out = self._body()
+        return self
+
+    def _body(self):
+        self.gen.begin_step()
+        return self.loss_and_grad(self._x, self._tg)
+
     def step(self, pose2d, targets):
         """optimizer.zero_grad(); loss.backward(); optimizer.step()  (base.py:151-153)"""
-        loss, parts, grad = self.loss_and_grad(pose2d, targets)
+        if self._graph is not None:
+            ops.raw_unary(ops.U_AFFINE, pose2d, 1.0, 0.0, out=self._x)
+            for k, v in targets.items():
+                ops.raw_unary(ops.U_AFFINE, v, 1.0, 0.0, out=self._tg[k])
+            self._graph.replay()
+            loss, parts, grad = self._out
+        else:
+            self.gen.begin_step()
+            loss, parts, grad = self.loss_and_grad(pose2d, targets)
         if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
             self.dist.all_reduce(grad)
             grad = ops.raw_unary(ops.U_AFFINE, grad, 1.0 / self.dist.get_world_size(), 0.0)

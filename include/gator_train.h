@@ -51,15 +51,19 @@ int gator_t_layernorm_bwd(const float* dy, const float* x, const float* mean, co
 int gator_t_softmax_fwd(const float* x, int64_t rows, int n, float* p, gator_stream stream);
 int gator_t_softmax_bwd(const float* p, const float* dp, int64_t rows, int n, float* dx, gator_stream stream);
 
-/* dropout: keep[i] = philox4x32-10(seed, offset; i) >= rate * 2^32; out = x * keep / (1 - rate); mask (uint8) is stored for
- * gator_t_mask_scale (the backward: out = x * mask * scale).  x == NULL writes the scaled mask itself (DropPath's per-sample factor). */
-int gator_t_dropout(const float* x, int64_t n, float rate, uint64_t seed, uint64_t offset, float* out, uint8_t* mask,
-                    gator_stream stream);
+/* dropout: keep[i] = philox4x32-10(seed, offset'; i) >= rate * 2^32; out = x * keep / (1 - rate); mask (uint8) is stored for
+ * gator_t_mask_scale (the backward: out = x * mask * scale).  x == NULL writes the scaled mask itself (DropPath's per-sample factor).
+ * offset' = offset + 2^32 * step_counter[0] when step_counter (a DEVICE uint64) is given: a step captured in a hipGraph draws new
+ * masks on every replay.  gator_t_step_advance adds one to the counter (launch it once per step, inside the graph). */
+int gator_t_dropout(const float* x, int64_t n, float rate, uint64_t seed, uint64_t offset, const uint64_t* step_counter, float* out,
+                    uint8_t* mask, gator_stream stream);
+int gator_t_step_advance(uint64_t* step_counter, gator_stream stream);
 int gator_t_mask_scale(const float* x, const uint8_t* mask, int64_t n, float scale, float* out, gator_stream stream);
 
 /* torch.optim.Adam (lib/funcs_utils.py:91-95: lr only, betas 0.9/0.999, eps 1e-8, no weight decay) on one flat buffer */
 int gator_t_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                 float beta2, float eps, int step, gator_stream stream);
+                 float beta2, float eps, int step, const uint64_t* step_counter /* device; overrides `step` when given */,
+                 gator_stream stream);
 
 /* The mesh losses of lib/core/loss.py on device, value and gradient in one pass each.
  * coord (CoordLoss, loss.py:10-25):   mean |pred*valid - target*valid|; valid broadcast by strides (shape4 / element strides).
