@@ -138,7 +138,7 @@ def gat_forward(P, c, pose2d, gen, rates, training=True, p='pose_lifter.'):
         y, y0, y1 = ops.fork(y, 3)
         # Attention (modules.py:121-138)
         qkv = ops.linear(y, g(b + 'attn.qkv.weight'), g(b + 'attn.qkv.bias')).reshape(B, J, 3, C)
-        q, k, v = [ops.narrow(t, 2, n, 1).reshape(B, J, H, C // H).permute(0, 2, 1, 3) for n, t in enumerate(ops.fork(qkv, 3))]
+        q, k, v = [ops.reshape(ops.narrow(t, 2, n, 1), B, J, H, C // H).permute(0, 2, 1, 3) for n, t in enumerate(ops.fork(qkv, 3))]
         att = ops.add(ops.matmul(q, k.transpose(-2, -1), scale), biases[i])
         att = ops.dropout(ops.softmax(att), rates.gat_attn, gen, training)
         a = ops.contiguous(ops.matmul(att, v).transpose(1, 2)).reshape(B, J, C)
@@ -211,9 +211,9 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
         vf, res = ops.fork(vf)
         fz = ops.layernorm(ops.cat([vf, jfs[li]], 1), g(e + 'norm1.weight'), g(e + 'norm1.bias'), 1e-5, 0)
         fq, fk, fv = ops.fork(fz, 3)
-        q = ops.linear(ops.narrow(fq, 1, 0, V), g(e + 'attn.wq.weight')).reshape(B, V, Hh, d).permute(0, 2, 1, 3)
-        k = ops.linear(ops.narrow(fk, 1, V, J), g(e + 'attn.wk.weight')).reshape(B, J, Hh, d).permute(0, 2, 1, 3)
-        v = ops.linear(ops.narrow(fv, 1, V, J), g(e + 'attn.wv.weight')).reshape(B, J, Hh, d).permute(0, 2, 1, 3)
+        q = ops.reshape(ops.linear(ops.narrow(fq, 1, 0, V), g(e + 'attn.wq.weight')), B, V, Hh, d).permute(0, 2, 1, 3)
+        k = ops.reshape(ops.linear(ops.narrow(fk, 1, V, J), g(e + 'attn.wk.weight')), B, J, Hh, d).permute(0, 2, 1, 3)
+        v = ops.reshape(ops.linear(ops.narrow(fv, 1, V, J), g(e + 'attn.wv.weight')), B, J, Hh, d).permute(0, 2, 1, 3)
         att = ops.dropout(ops.softmax(ops.matmul(q, k.transpose(-2, -1), d ** -0.5)), rates.mdr_attn, gen, training)
         o = ops.contiguous(ops.matmul(att, v).transpose(1, 2)).reshape(B, V, E)
         o = ops.dropout(ops.linear(o, g(e + 'attn.proj.weight'), g(e + 'attn.proj.bias')), rates.mdr_drop, gen, training)
@@ -226,7 +226,7 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
         vf = ops.layernorm(vf, g('norm%s.a_2' % sfx), g('norm%s.b_2' % sfx), 1e-6, 1)          # vanilla_transformer_encoder.py:31-34
         sa = 'selfatt%s.linears.' % sfx
         vf, res, xq, xk = ops.fork(vf, 4)
-        qq, kk, vv = [ops.linear(t, g(sa + '%d.weight' % n), g(sa + '%d.bias' % n)).reshape(B, V, Hh, d).transpose(1, 2)
+        qq, kk, vv = [ops.reshape(ops.linear(t, g(sa + '%d.weight' % n), g(sa + '%d.bias' % n)), B, V, Hh, d).transpose(1, 2)
                       for n, t in enumerate((vf, xq, xk))]
         pa = ops.dropout(ops.softmax(ops.matmul(qq, kk.transpose(-2, -1), 1.0 / math.sqrt(d))), rates.mdr_self, gen, training)
         xo = ops.contiguous(ops.matmul(pa, vv).transpose(1, 2)).reshape(B, V, E)

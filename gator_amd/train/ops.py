@@ -541,11 +541,38 @@ def narrow(x, dim, start, length):
     return _Narrow.apply(x, dim % x.dim(), start, length)
 
 
+class _Reshape(torch.autograd.Function):
+    """x.reshape(shape) whose backward re-lays a non-contiguous gradient out with the library's copy kernel (autograd's own
+    reshape backward would call aten::clone for e.g. the head-split views of q, k, v)."""
+
+    @staticmethod
+    def forward(ctx, x, shape):
+        ctx.shape = x.shape
+        return _contig(x).reshape(shape) if not x.is_contiguous() and not _viewable(x, shape) else x.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _contig(g).reshape(ctx.shape), None
+
+
+def _viewable(x, shape):
+    try:
+        x.view(shape)
+        return True
+    except RuntimeError:
+        return False
+
+
+def reshape(x, *shape):
+    return _Reshape.apply(x, tuple(shape))
+
+
 class _Fork(torch.autograd.Function):
     """n aliases of x whose gradients are summed by the library (instead of autograd's own accumulation with aten adds)."""
 
     @staticmethod
     def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)                 # an alias used only detached has no gradient: do not zero-fill one
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod

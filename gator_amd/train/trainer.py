@@ -36,7 +36,8 @@ class Trainer:
         P = self.params.views()
         mesh, pose3d = M.gator_forward(P, self.consts, pose2d, self.gen, self.rates, training, self.params.buffers)
         loss, parts = self.losses.total(mesh, pose3d, targets, with_edge=self.epoch > self.edge_loss_start)
-        grad, = torch.autograd.grad(loss, self.params.flat)
+        one = ops.raw_unary(ops.U_AFFINE, loss.detach(), 0.0, 1.0)          # d loss / d loss (autograd's default would be an aten fill)
+        grad, = torch.autograd.grad(loss, self.params.flat, grad_outputs=one)
         return loss.detach(), {k: v.detach() for k, v in parts.items()}, grad
 
     def capture(self, pose2d, targets):

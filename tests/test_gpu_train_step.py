@@ -133,3 +133,22 @@ def test_dropout_training_step_is_reproducible_and_active():
     l0, _, g0 = tr0.loss_and_grad(x, tg)
     assert float((g1 - g0).abs().max()) > 0
     assert torch.isfinite(g1).all()
+
+
+def test_training_step_runs_only_library_kernels():
+    """torch is plumbing in the training row: over one whole step (forward, losses, backward, Adam) the only aten operators that
+    run are allocation / view metadata - every kernel on the data path comes from libgator_hip.so."""
+    from torch.profiler import ProfilerActivity, profile
+    z, m, tr, _ = make_trainer('h36m17_bn', rates=M.Rates(), seed=3)
+    tr.epoch = 16
+    x, tg = batch_of(z, 8, shift=4)
+    tr.step(x, tg)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        tr.step(x, tg)
+        torch.cuda.synchronize()
+    metadata = {'aten::empty', 'aten::view', 'aten::as_strided', 'aten::empty_like', 'aten::empty_strided', 'aten::reshape', 'aten::expand',
+                'aten::permute', 'aten::transpose', 'aten::narrow', 'aten::slice', 'aten::select', 'aten::detach', 'aten::alias',
+                'aten::_reshape_alias', 'aten::unsqueeze', 'aten::t', 'aten::view_as', 'aten::_unsafe_view', 'aten::squeeze', 'aten::result_type'}
+    foreign = sorted({e.key for e in prof.key_averages() if e.key.startswith('aten::') and e.key not in metadata})
+    assert foreign == [], foreign
