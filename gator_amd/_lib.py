@@ -56,7 +56,7 @@ SIGNATURES = {
     'gator_t_unary': (_I, [_I, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _P]),
     'gator_t_reduce_ws_bytes': (_L, [_P, _P]),
     'gator_t_reduce_sum': (_I, [_P, _P, _P, _P, _P, _I, _P, _P]),
-    'gator_t_gemm': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, ctypes.c_float, _I, _I, _P, _P]),
+    'gator_t_gemm': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, ctypes.c_float, _I, _I, _P, _P, _P]),
     'gator_t_layernorm_fwd': (_I, [_P, _L, _I, _P, _P, ctypes.c_float, _I, _P, _P, _P, _P]),
     'gator_t_layernorm_bwd': (_I, [_P, _P, _P, _P, _P, _L, _I, ctypes.c_float, _I, _P, _P, _P]),
     'gator_t_softmax_fwd': (_I, [_P, _L, _I, _P, _P]),

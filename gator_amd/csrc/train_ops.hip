@@ -148,14 +148,19 @@ __global__ __launch_bounds__(kThreads) void k_t_reduce_cols(const float* __restr
     }
 }
 
+// one wave per output: lanes stride over the slices, fixed-order butterfly
 __global__ __launch_bounds__(kThreads) void k_t_reduce_finish(const double* __restrict__ part, int nsplit, int64_t n_out, float* __restrict__ out,
                                                               int accumulate, float scale) {
-    const int64_t o = blockIdx.x * (int64_t)kThreads + threadIdx.x;
+    const int64_t o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (o >= n_out) return;
     double s = 0.0;
-    for (int i = 0; i < nsplit; ++i) s += part[o * nsplit + i];
-    const float r = (float)(s * (double)scale);
-    out[o] = accumulate ? out[o] + r : r;
+    for (int i = lane; i < nsplit; i += 64) s += part[o * nsplit + i];
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float r = (float)(s * (double)scale);
+        out[o] = accumulate ? out[o] + r : r;
+    }
 }
 
 struct ReducePlan {
@@ -221,6 +226,7 @@ struct GemmArgs {
     float alpha;
     int accumulate;
     int a_kfast, b_nfast;
+    float* rowsum;      // optional: out[m] = alpha * sum_k A[m][k] (a bias gradient riding on its weight-gradient GEMM)
 };
 
 // 64x64 output tile per workgroup, K in steps of 32 through LDS ([k][m] / [k][n] images: the MFMA operand fragments are
@@ -240,7 +246,10 @@ __global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
     f32x16t acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float ra[8], rb[8];
+    float ra[8], rb[8], rs[8];
+    const bool do_rowsum = g.rowsum != nullptr && tn == 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rs[i] = 0.f;
     // lanes run along whichever index is contiguous in memory: (k fast) k = t % 32, m = t / 32 + 8 i; (m fast) m = t % 64, k = t / 64 + 4 i
     auto fetch = [&](int k0) {
 #pragma unroll
@@ -261,6 +270,7 @@ __global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
             int m, k;
             if (g.a_kfast) { k = t & 31; m = (t >> 5) + 8 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
             As[buf][k][m] = ra[i];
+            rs[i] += ra[i];
             int n, kk;
             if (g.b_nfast) { n = t & 63; kk = (t >> 6) + 4 * i; } else { kk = t & 31; n = (t >> 5) + 8 * i; }
             Bs[buf][kk][n] = rb[i];
@@ -285,6 +295,25 @@ __global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
         __syncthreads();
         buf ^= 1;
     }
+    if (do_rowsum) {                                    // row sums of the A tile: per-thread partials -> LDS -> one fixed-order sum per row
+        float* S = &As[0][0][0];
+        if (g.a_kfast) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) S[((t >> 5) + 8 * i) * 33 + (t & 31)] = rs[i];
+        } else {
+            S[(t & 63) * 33 + (t >> 6)] = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
+        }
+        __syncthreads();
+        if (t < 64 && m0 + t < g.M) {
+            const int slots = g.a_kfast ? 32 : 4;
+            float v = 0.f;
+            for (int j = 0; j < slots; ++j) v += S[t * 33 + j];
+            if (g.ksplit > 1)
+                g.rowsum[(int64_t)blockIdx.z * g.M + m0 + t] = v;
+            else
+                g.rowsum[m0 + t] = g.alpha * v;
+        }
+    }
     float* C = g.C + bi1 * g.c1 + bi2 * g.c2 + (g.ksplit > 1 ? (int64_t)blockIdx.z * g.M * g.N : 0);
     const int col = n0 + wn * 32 + (lane & 31);
     if (col >= g.N) return;
@@ -301,14 +330,40 @@ __global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
     }
 }
 
+// 64 consecutive outputs per workgroup; the four waves take the slices k = w, w+4, ... with four loads in flight each, then combine
 __global__ __launch_bounds__(kThreads) void k_t_splitk_finish(const float* __restrict__ ws, int ksplit, int M, int N, float* __restrict__ C,
                                                               int64_t cm, int64_t cn, const float* __restrict__ bias, float alpha,
-                                                              int accumulate) {
-    const int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x;
-    if (i >= (int64_t)M * N) return;
+                                                              int accumulate, const float* __restrict__ ws_rowsum, float* __restrict__ rowsum) {
+    __shared__ float sh[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t MN = (int64_t)M * N;
+    const int64_t blocks_c = (MN + 63) / 64;
+    const bool is_rs = blockIdx.x >= blocks_c;                    // trailing workgroups finish the row sums
+    const int64_t i = (is_rs ? blockIdx.x - blocks_c : blockIdx.x) * 64 + tx;
+    const int64_t total = is_rs ? M : MN;
+    const float* src = is_rs ? ws_rowsum : ws;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < total) {
+        int k = ty;
+        for (; k + 12 < ksplit; k += 16) {
+            const float v0 = src[(int64_t)k * total + i], v1 = src[(int64_t)(k + 4) * total + i], v2 = src[(int64_t)(k + 8) * total + i],
+                        v3 = src[(int64_t)(k + 12) * total + i];
+            a0 += v0;
+            a1 += v1;
+            a2 += v2;
+            a3 += v3;
+        }
+        for (; k < ksplit; k += 4) a0 += src[(int64_t)k * total + i];
+    }
+    sh[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty != 0 || i >= total) return;
+    const float s = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+    if (is_rs) {
+        rowsum[i] = alpha * s;
+        return;
+    }
     const int m = (int)(i / N), n = (int)(i % N);
-    float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += ws[(int64_t)k * M * N + i];
     float v = alpha * s + (bias ? bias[n] : 0.f);
     float* c = C + (int64_t)m * cm + (int64_t)n * cn;
     if (accumulate) v += *c;
@@ -684,14 +739,15 @@ int gator_t_reduce_sum(const float* x, const int64_t* sx, const int64_t* shape, 
         hipLaunchKernelGGL(k_t_reduce, dim3((unsigned)p.n_out, p.nsplit), dim3(kThreads), 0, st, x, p.s, p.keep, p.red, p.R, p.nsplit, part, out, accumulate);
     }
     if (p.nsplit > 1)
-        hipLaunchKernelGGL(k_t_reduce_finish, dim3((unsigned)((p.n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part, p.nsplit, p.n_out, out,
+        hipLaunchKernelGGL(k_t_reduce_finish, dim3((unsigned)((p.n_out + 3) / 4)), dim3(kThreads), 0, st, part, p.nsplit, p.n_out, out,
                        accumulate, 1.0f);
     return check_launch("gator_t_reduce_sum");
 }
 
 int gator_t_gemm(const float* A, const float* B, float* C, int M, int N, int K, const int64_t* sa, const int64_t* sb, const int64_t* sc, int nb1,
                  int nb2, const int64_t* ba, const int64_t* bb, const int64_t* bc, const float* bias, float alpha, int accumulate, int ksplit,
-                 float* ws, gator_stream stream) {
+                 float* ws, float* a_rowsum, gator_stream stream) {
+    if (a_rowsum && (nb1 != 1 || nb2 != 1)) return fail(1, "gator_t_gemm: a_rowsum needs an unbatched product");
     if (!A || !B || !C || M <= 0 || N <= 0 || K < 0 || nb1 <= 0 || nb2 <= 0) return fail(1, "gator_t_gemm: bad argument");
     if (ksplit < 1) ksplit = 1;
     if (ksplit > 1 && (nb1 != 1 || nb2 != 1 || !ws)) return fail(1, "gator_t_gemm: split-K needs an unbatched product and a workspace");
@@ -704,14 +760,15 @@ int gator_t_gemm(const float* A, const float* B, float* C, int M, int N, int K, 
     g.a1 = ba[0]; g.a2 = ba[1]; g.b1 = bb[0]; g.b2 = bb[1]; g.c1 = bc[0]; g.c2 = bc[1];
     g.alpha = ksplit > 1 ? 1.f : alpha;
     g.accumulate = ksplit > 1 ? 0 : accumulate;
+    g.rowsum = a_rowsum ? (ksplit > 1 ? ws + (int64_t)ksplit * M * N : a_rowsum) : nullptr;
     g.a_kfast = (g.ak == 1 || g.am != 1) ? 1 : 0;       // lanes run along whichever index is contiguous in memory
     g.b_nfast = (g.bn == 1 || g.bk != 1) ? 1 : 0;
     const unsigned tiles = (unsigned)(((M + 63) / 64) * ((N + 63) / 64));
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_t_gemm, dim3(tiles, nb1 * nb2, ksplit), dim3(kThreads), 0, st, g);
     if (ksplit > 1)
-        hipLaunchKernelGGL(k_t_splitk_finish, dim3((unsigned)(((int64_t)M * N + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, ws, ksplit, M, N, C,
-                           sc[0], sc[1], bias, alpha, accumulate);
+        hipLaunchKernelGGL(k_t_splitk_finish, dim3((unsigned)(((int64_t)M * N + 63) / 64 + (a_rowsum ? (M + 63) / 64 : 0))), dim3(kThreads), 0, st, ws, ksplit, M, N, C,
+                           sc[0], sc[1], bias, alpha, accumulate, a_rowsum ? ws + (int64_t)ksplit * M * N : nullptr, a_rowsum);
     return check_launch("gator_t_gemm");
 }
 

@@ -102,8 +102,8 @@ def sum_to(g, shape):
     return raw_sum(g, dims, keepdim=True).reshape(shape)
 
 
-def raw_gemm(a, b, out=None, bias=None, alpha=1.0, accumulate=False):
-    """a [n1,n2,M,K] x b [n1,n2,K,N] (any strides, stride 0 = broadcast) -> out [n1,n2,M,N]."""
+def raw_gemm(a, b, out=None, bias=None, alpha=1.0, accumulate=False, a_rowsum=None):
+    """a [n1,n2,M,K] x b [n1,n2,K,N] (any strides, stride 0 = broadcast) -> out [n1,n2,M,N].  a_rowsum [M]: also alpha * a.sum(K)."""
     n1, n2, M, K = a.shape
     N = b.shape[3]
     if out is None:
@@ -112,12 +112,12 @@ def raw_gemm(a, b, out=None, bias=None, alpha=1.0, accumulate=False):
     ksplit, ws = 1, None
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     if n1 * n2 == 1 and K >= 512 and tiles < 256:          # few output tiles, long K: slices of >= 128 fill the chip
-        ksplit = max(1, min(256, K // 128, 1024 // tiles))
+        ksplit = max(1, min(64, K // 128, 1024 // tiles))
         if ksplit > 1:
-            ws = torch.empty(ksplit * M * N, device=a.device, dtype=torch.float32)
+            ws = torch.empty(ksplit * (M * N + M), device=a.device, dtype=torch.float32)
     _call('gator_t_gemm', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, _I64x2(sa[2], sa[3]), _I64x2(sb[2], sb[3]), _I64x2(so[2], so[3]),
           n1, n2, _I64x2(sa[0], sa[1]), _I64x2(sb[0], sb[1]), _I64x2(so[0], so[1]), bias.data_ptr() if bias is not None else None, float(alpha),
-          int(accumulate), ksplit, ws.data_ptr() if ws is not None else None, _stream(a))
+          int(accumulate), ksplit, ws.data_ptr() if ws is not None else None, a_rowsum.data_ptr() if a_rowsum is not None else None, _stream(a))
     return out
 
 
@@ -339,9 +339,11 @@ class _Linear(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = raw_gemm(g2, w4).reshape(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            gw = raw_gemm(g2.transpose(2, 3), x2).reshape(w4.shape[2], w4.shape[3])
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        need_b = ctx.has_b and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:                      # dW = dY^T X; the bias gradient (row sums of dY^T) rides on the same launch
+            gb = torch.empty(w4.shape[2], device=g.device, dtype=torch.float32) if need_b else None
+            gw = raw_gemm(g2.transpose(2, 3), x2, a_rowsum=gb).reshape(w4.shape[2], w4.shape[3])
+        elif need_b:
             gb = raw_sum(g2.reshape(-1, g2.shape[-1]), [0])
         return gx, gw, gb
 

@@ -32,11 +32,13 @@ int gator_t_reduce_sum(const float* x, const int64_t* stride_x, const int64_t* s
 
 /* C[b1,b2] = alpha * A[b1,b2] (M x K) . B[b1,b2] (K x N) (+ bias[n]) (+ C if accumulate), fp32-input MFMA (exact fp32 products).
  * strides in elements: A (m, k), B (k, n), C (m, n), and per batch level for each operand (0 broadcasts).
- * ksplit > 1 (needs nb1 == nb2 == 1): K is cut into ksplit slices summed in slice order through ws (ksplit*M*N floats). */
+ * ksplit > 1 (needs nb1 == nb2 == 1): K is cut into ksplit slices summed in slice order through ws (ksplit*(M*N+M) floats).
+ * a_rowsum != NULL (unbatched only): also a_rowsum[m] = alpha * sum_k A[m][k] from the tiles already in LDS - the bias gradient
+ * rides on its weight-gradient GEMM (A = dY^T) instead of a reduction pass of its own. */
 int gator_t_gemm(const float* A, const float* B, float* C, int M, int N, int K, const int64_t* stride_a2, const int64_t* stride_b2,
                  const int64_t* stride_c2, int nb1, int nb2, const int64_t* batch_a2, const int64_t* batch_b2,
                  const int64_t* batch_c2, const float* bias, float alpha, int accumulate, int ksplit, float* ws,
-                 gator_stream stream);
+                 float* a_rowsum, gator_stream stream);
 
 /* rows of n contiguous floats.  mode 0: nn.LayerNorm (biased variance, eps inside the root); mode 1: the MDR LayerNorm
  * (lib/models/vanilla_transformer_encoder.py:31-34: unbiased std, eps added to the std).  w, b may be NULL (no affine).
