@@ -138,16 +138,15 @@ def gat_forward(P, c, pose2d, gen, rates, training=True, p='pose_lifter.'):
         y, y0, y1 = ops.fork(y, 3)
         # Attention (modules.py:121-138)
         qkv = ops.linear(y, g(b + 'attn.qkv.weight'), g(b + 'attn.qkv.bias')).reshape(B, J, 3, C)
-        q, k, v = [ops.reshape(ops.narrow(t, 2, n, 1), B, J, H, C // H).permute(0, 2, 1, 3) for n, t in enumerate(ops.fork(qkv, 3))]
+        q, k, v = [ops.reshape(t, B, J, H, C // H).permute(0, 2, 1, 3) for t in ops.split(qkv, 2, (1, 1, 1))]
         att = ops.add(ops.matmul(q, k.transpose(-2, -1), scale), biases[i])
         att = ops.dropout(ops.softmax(att), rates.gat_attn, gen, training)
         a = ops.contiguous(ops.matmul(att, v).transpose(1, 2)).reshape(B, J, C)
         a = ops.dropout(ops.linear(a, g(b + 'attn.proj.weight'), g(b + 'attn.proj.bias')), rates.gat_proj, gen, training)
         # MGCN (modules.py:243-255)
-        W = g(b + 'gcn.W')
-        W0, W1 = ops.fork(W)
-        h0 = ops.matmul(y0, ops.narrow(W0, 0, 0, 1).reshape(C, C))
-        h1 = ops.matmul(y1, ops.narrow(W1, 0, 1, 1).reshape(C, C))
+        W0, W1 = ops.split(g(b + 'gcn.W'), 0, (1, 1))
+        h0 = ops.matmul(y0, W0.reshape(C, C))
+        h1 = ops.matmul(y1, W1.reshape(C, C))
         adj_a, adj_b = ops.fork(ops.add(c.A, g(b + 'gcn.adj2')))
         adj_d, adj_o = ops.fork(ops.affine(ops.add(adj_a.t(), adj_b), 0.5))
         M0, M1 = ops.fork(g(b + 'gcn.M'))
@@ -210,10 +209,11 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
         e = 'encoder%s.' % sfx
         vf, res = ops.fork(vf)
         fz = ops.layernorm(ops.cat([vf, jfs[li]], 1), g(e + 'norm1.weight'), g(e + 'norm1.bias'), 1e-5, 0)
-        fq, fk, fv = ops.fork(fz, 3)
-        q = ops.reshape(ops.linear(ops.narrow(fq, 1, 0, V), g(e + 'attn.wq.weight')), B, V, Hh, d).permute(0, 2, 1, 3)
-        k = ops.reshape(ops.linear(ops.narrow(fk, 1, V, J), g(e + 'attn.wk.weight')), B, J, Hh, d).permute(0, 2, 1, 3)
-        v = ops.reshape(ops.linear(ops.narrow(fv, 1, V, J), g(e + 'attn.wv.weight')), B, J, Hh, d).permute(0, 2, 1, 3)
+        fq, fj = ops.split(fz, 1, (V, J))
+        fk, fv = ops.fork(ops.contiguous(fj))
+        q = ops.reshape(ops.linear(fq, g(e + 'attn.wq.weight')), B, V, Hh, d).permute(0, 2, 1, 3)
+        k = ops.reshape(ops.linear(fk, g(e + 'attn.wk.weight')), B, J, Hh, d).permute(0, 2, 1, 3)
+        v = ops.reshape(ops.linear(fv, g(e + 'attn.wv.weight')), B, J, Hh, d).permute(0, 2, 1, 3)
         att = ops.dropout(ops.softmax(ops.matmul(q, k.transpose(-2, -1), d ** -0.5)), rates.mdr_attn, gen, training)
         o = ops.contiguous(ops.matmul(att, v).transpose(1, 2)).reshape(B, V, E)
         o = ops.dropout(ops.linear(o, g(e + 'attn.proj.weight'), g(e + 'attn.proj.bias')), rates.mdr_drop, gen, training)
@@ -235,8 +235,7 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
     # MDR head (MDR.py:156-168)
     va, vb, vs = ops.fork(vf, 3)
     ac = ops.linear(va, g('motion_linear.weight'), g('motion_linear.bias'))
-    ac, ac2 = ops.fork(ac)
-    mat_a, mat_c = ops.narrow(ac, 2, 0, 20), ops.narrow(ac2, 2, 20, 3)
+    mat_a, mat_c = ops.split(ac, 2, (20, 3))
     mat_b = ops.linear(vb, g('bias_linear.weight'), g('bias_linear.bias'))
     if c.alpha:
         mat_b = ops.layernorm(mat_b, g('bias_norm.weight'), g('bias_norm.bias'), 1e-5, 0)

@@ -121,6 +121,11 @@ def raw_gemm(a, b, out=None, bias=None, alpha=1.0, accumulate=False, a_rowsum=No
     return out
 
 
+def grad_slot(p):
+    """The slice of the flat gradient buffer that belongs to parameter view `p` (set by optim.FlatParams.views), or None."""
+    return getattr(p, '_gslot', None)
+
+
 def raw_copy(x):
     """Contiguous copy through the library's strided copy kernel."""
     if x.dim() > 4:
@@ -329,6 +334,7 @@ class _Linear(torch.autograd.Function):
         w4 = w.reshape(1, 1, w.shape[0], w.shape[1])
         ctx.save_for_backward(x2, w4)
         ctx.xshape, ctx.has_b = x.shape, b is not None
+        ctx.wslot, ctx.bslot = grad_slot(w), grad_slot(b) if b is not None else None
         y = raw_gemm(x2, w4.transpose(2, 3), bias=b)
         return y.reshape(list(x.shape[:-1]) + [w.shape[0]])
 
@@ -341,8 +347,9 @@ class _Linear(torch.autograd.Function):
             gx = raw_gemm(g2, w4).reshape(ctx.xshape)
         need_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:                      # dW = dY^T X; the bias gradient (row sums of dY^T) rides on the same launch
-            gb = torch.empty(w4.shape[2], device=g.device, dtype=torch.float32) if need_b else None
-            gw = raw_gemm(g2.transpose(2, 3), x2, a_rowsum=gb).reshape(w4.shape[2], w4.shape[3])
+            gb = (ctx.bslot if ctx.bslot is not None else torch.empty(w4.shape[2], device=g.device, dtype=torch.float32)) if need_b else None
+            gw = raw_gemm(g2.transpose(2, 3), x2, a_rowsum=gb, out=ctx.wslot.view(w4.shape) if ctx.wslot is not None else None)
+            gw = ctx.wslot if ctx.wslot is not None else gw.reshape(w4.shape[2], w4.shape[3])
         elif need_b:
             gb = raw_sum(g2.reshape(-1, g2.shape[-1]), [0])
         return gx, gw, gb
@@ -392,6 +399,7 @@ class _LayerNorm(torch.autograd.Function):
               float(eps), int(mode), y.data_ptr(), mean.data_ptr(), rinv.data_ptr(), _stream(x))
         ctx.save_for_backward(xc, mean, rinv, w)
         ctx.eps, ctx.mode, ctx.has_b = eps, mode, b is not None
+        ctx.wslot, ctx.bslot = grad_slot(w) if w is not None else None, grad_slot(b) if b is not None else None
         return y
 
     @staticmethod
@@ -405,8 +413,11 @@ class _LayerNorm(torch.autograd.Function):
         dyx = torch.empty_like(xc) if need_w else None
         _call('gator_t_layernorm_bwd', gc.data_ptr(), xc.data_ptr(), mean.data_ptr(), rinv.data_ptr(), w.data_ptr() if w is not None else None, rows, n,
               float(ctx.eps), int(ctx.mode), dx.data_ptr(), dyx.data_ptr() if need_w else None, _stream(xc))
-        gw = raw_sum(dyx.reshape(rows, n), [0]) if need_w else None
-        gb = raw_sum(gc.reshape(rows, n), [0]) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        gw = gb = None
+        if need_w:
+            gw = raw_sum(dyx.reshape(rows, n), [0], keepdim=True, out=ctx.wslot.view(1, n) if ctx.wslot is not None else None).reshape(n)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            gb = raw_sum(gc.reshape(rows, n), [0], keepdim=True, out=ctx.bslot.view(1, n) if ctx.bslot is not None else None).reshape(n)
         return dx, gw, gb, None, None
 
 
@@ -567,6 +578,39 @@ def _viewable(x, shape):
 
 def reshape(x, *shape):
     return _Reshape.apply(x, tuple(shape))
+
+
+class _Split(torch.autograd.Function):
+    """x split into consecutive pieces along `dim` (views); the backward lays the pieces' gradients side by side in ONE buffer
+    (a copy per piece - no zero-filled full-size tensors and no additions, unlike narrow + fork)."""
+
+    @staticmethod
+    def forward(ctx, x, dim, sizes):
+        ctx.set_materialize_grads(False)
+        ctx.shape, ctx.dim, ctx.sizes = x.shape, dim, sizes
+        outs, o = [], 0
+        for n in sizes:
+            outs.append(x.narrow(dim, o, n))
+            o += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        dev = next(g.device for g in gs if g is not None)
+        out = torch.empty(ctx.shape, device=dev, dtype=torch.float32)
+        o = 0
+        for g, n in zip(gs, ctx.sizes):
+            dst = out.narrow(ctx.dim, o, n)
+            if g is None:
+                raw_unary(U_GT, dst, float('inf'), 0.0, out=dst)
+            else:
+                raw_unary(U_AFFINE, g, 1.0, 0.0, out=dst)
+            o += n
+        return out, None, None
+
+
+def split(x, dim, sizes):
+    return _Split.apply(x, dim % x.dim(), tuple(sizes))
 
 
 class _Fork(torch.autograd.Function):

@@ -16,14 +16,15 @@ class _Unflatten(torch.autograd.Function):
     @staticmethod
     def forward(ctx, flat, owner):
         ctx.owner = owner
+        ctx.set_materialize_grads(False)
         return tuple(flat[a:b].view(shape) for (a, b, shape) in owner.slots)
 
     @staticmethod
     def backward(ctx, *gs):
         o = ctx.owner
-        out = ops.zeros((o.numel,), gs[0].device if gs[0] is not None else o.flat.device)
+        out = o.gflat
         for g, (a, b, shape) in zip(gs, o.slots):
-            if g is not None:
+            if g is not None and g.data_ptr() != out.data_ptr() + 4 * a:      # ops that know their slot wrote it in place (ops.grad_slot)
                 ops.raw_unary(ops.U_AFFINE, g, 1.0, 0.0, out=out[a:b].view(shape))
         return out, None
 
@@ -50,8 +51,13 @@ class FlatParams:
         self.flat = flat.to(device).requires_grad_(True)
 
     def views(self):
-        """name -> differentiable view of the flat buffer (call once per step, inside the graph)."""
-        return dict(zip(self.names, _Unflatten.apply(self.flat, self)))
+        """name -> differentiable view of the flat buffer (call once per step, inside the graph).  Every view carries its slice
+        of this step's flat gradient buffer (`_gslot`): linear / LayerNorm backward write weight gradients straight into it."""
+        self.gflat = ops.zeros((self.numel,), self.flat.device)
+        vs = _Unflatten.apply(self.flat, self)
+        for v, (a, b, shape) in zip(vs, self.slots):
+            v._gslot = self.gflat[a:b].view(shape)
+        return dict(zip(self.names, vs))
 
     def state_dict(self):
         sd = {k: self.flat.detach()[a:b].view(shape).clone() for k, (a, b, shape) in zip(self.names, self.slots)}
