@@ -152,3 +152,26 @@ def test_training_step_runs_only_library_kernels():
                 'aten::_reshape_alias', 'aten::unsqueeze', 'aten::t', 'aten::view_as', 'aten::_unsafe_view', 'aten::squeeze', 'aten::result_type'}
     foreign = sorted({e.key for e in prof.key_averages() if e.key.startswith('aten::') and e.key not in metadata})
     assert foreign == [], foreign
+
+
+def test_captured_step_replays_like_eager_and_draws_new_masks():
+    """Trainer.capture: the hipGraph replay of forward + losses + backward, with the optimiser outside, follows the eager step
+    (dropout off: same weights after three steps to rounding); with dropout on, every replay draws different masks because the
+    Philox offset's high word is read from the device step counter the graph itself advances."""
+    name = 'h36m17_bn'
+    z, m, eager, _ = make_trainer(name, lr=1e-5)
+    z, m, graph, _ = make_trainer(name, lr=1e-5)
+    x, tg = batch_of(z, 8, shift=6)
+    graph.capture(x, tg)
+    for it in range(3):
+        x2, tg2 = batch_of(z, 8, shift=6 + it)                        # new data every step through the static input buffers
+        le, _ = eager.step(x2, tg2)
+        lg, _ = graph.step(x2, tg2)
+        assert abs(float(le) - float(lg)) <= 1e-5 * abs(float(le)), it
+    d = float((eager.params.flat.detach() - graph.params.flat.detach()).abs().max())
+    assert d <= 2e-5, d                                               # Adam's sign-like first steps amplify rounding: a few lr
+    z, m, drop, _ = make_trainer(name, rates=M.Rates(), seed=11, lr=0.0)
+    drop.capture(x, tg)
+    losses = [float(drop.step(x, tg)[0]) for _ in range(4)]           # lr = 0: only the masks change between replays
+    assert len(set(losses)) == 4, losses
+    assert all(np.isfinite(losses))
