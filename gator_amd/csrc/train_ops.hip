@@ -506,7 +506,7 @@ __global__ void k_t_step_advance(uint64_t* c) {
 
 __global__ __launch_bounds__(kThreads) void k_t_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                      int64_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
-                                                     const uint64_t* __restrict__ step_counter) {
+                                                     const uint64_t* __restrict__ step_counter, float one_minus_b1, float one_minus_b2) {
     if (step_counter) {                                              // bias corrections of the step held on the device (graph replay)
         const double t = (double)step_counter[0];
         bc1 = (float)(1.0 - pow((double)b1, t));
@@ -514,8 +514,8 @@ __global__ __launch_bounds__(kThreads) void k_t_adam(float* __restrict__ p, cons
     }
     for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
         const float gi = g[i];
-        const float mi = m[i] + (gi - m[i]) * (1.f - b1);            // torch: exp_avg.lerp_(grad, 1 - beta1)
-        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        const float mi = m[i] + (gi - m[i]) * one_minus_b1;          // torch: exp_avg.lerp_(grad, 1 - beta1), 1 - beta formed in double
+        const float vi = v[i] * b2 + one_minus_b2 * (gi * gi);       //        exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
         m[i] = mi;
         v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
@@ -828,14 +828,14 @@ int gator_t_mask_scale(const float* x, const uint8_t* mask, int64_t n, float sca
     return check_launch("gator_t_mask_scale");
 }
 
-int gator_t_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+int gator_t_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
                  int step, const uint64_t* step_counter, gator_stream stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || (step < 1 && !step_counter)) return fail(1, "gator_t_adam: bad argument");
     if (step < 1) step = 1;
     if (n == 0) return 0;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(k_t_adam, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                       (float)bc1, (float)sqrt(bc2), step_counter);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);      // scalars in double, as torch forms them on the host
+    hipLaunchKernelGGL(k_t_adam, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, (float)lr, (float)beta1,
+                       (float)beta2, (float)eps, (float)bc1, (float)sqrt(bc2), step_counter, (float)(1.0 - beta1), (float)(1.0 - beta2));
     return check_launch("gator_t_adam");
 }
 

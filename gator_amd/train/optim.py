@@ -87,3 +87,38 @@ class Adam:
         _lib.check(_lib.load().gator_t_adam(f.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.p.numel,
                                             float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count,
                                             self.device_step.data_ptr() if self.device_step is not None else None, st), 'gator_t_adam')
+
+    # ---- checkpoint interchange with the reference (main/train.py:51-58 saves optimizer.state_dict(); base.py:73-77 loads it) ----
+    def state_dict(self):
+        """torch.optim.Adam.state_dict() layout: per-parameter {step, exp_avg, exp_avg_sq} in model.parameters() order."""
+        state = {}
+        for i, (a, b, shape) in enumerate(self.p.slots):
+            state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': self.exp_avg[a:b].view(shape).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[a:b].view(shape).clone()}
+        group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False, 'maximize': False,
+                 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None, 'initial_lr': self.base_lr,
+                 'params': list(range(len(self.p.slots)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        if len(sd['param_groups']) != 1 or len(sd['param_groups'][0]['params']) != len(self.p.slots):
+            raise ValueError('optimizer state does not match the parameter list (%d tensors expected)' % len(self.p.slots))
+        g = sd['param_groups'][0]
+        self.base_lr = float(g.get('initial_lr', g['lr']))
+        self.betas, self.eps = tuple(g['betas']), float(g['eps'])
+        steps = set()
+        for i, (a, b, shape) in enumerate(self.p.slots):
+            st = sd['state'].get(i)
+            if st is None:
+                continue
+            if tuple(st['exp_avg'].shape) != tuple(shape):
+                raise ValueError('optimizer state %d has shape %s, parameter %s has %s' % (i, tuple(st['exp_avg'].shape), self.p.names[i], shape))
+            dev = self.exp_avg.device
+            ops.raw_unary(ops.U_AFFINE, st['exp_avg'].to(dev).float(), 1.0, 0.0, out=self.exp_avg[a:b].view(shape))
+            ops.raw_unary(ops.U_AFFINE, st['exp_avg_sq'].to(dev).float(), 1.0, 0.0, out=self.exp_avg_sq[a:b].view(shape))
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError('per-parameter step counts differ: %s' % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+        if self.device_step is not None:
+            self.device_step.fill_(self.step_count)

@@ -85,3 +85,45 @@ class Trainer:
         self.optim.epoch = self.epoch
         self.optim.step(grad)
         return loss, parts
+
+
+class LiftTrainer:
+    """LiftTrainer.train (lib/core/base.py:260-300): the pose lifter alone - GAT forward in training mode, CoordLoss on the lifted
+    joints against `cam_joint` with `joint_valid`, backward, Adam.  Takes a gator_amd.models.GAT module (or any reference-layout
+    state_dict whose keys carry no `pose_lifter.` prefix)."""
+
+    def __init__(self, state_dict, consts, device='cuda', lr=1e-3, rates=None, seed=0):
+        self.params = FlatParams(state_dict, device)
+        self.consts = consts
+        self.optim = Adam(self.params, lr=lr)
+        self.rates = rates if rates is not None else M.Rates()
+        self.gen = ops.Generator(seed)
+        self.losses = L.MeshLosses([[0, 1, 2]], [[0.0]], device, num_verts=3)        # only CoordLoss is used (base.py:265)
+        self.epoch = 0
+
+    @classmethod
+    def from_module(cls, module, device='cuda', **kw):
+        sd = {k: v.detach().cpu() for k, v in module.state_dict().items()}
+        J = module.num_joint
+        z3 = torch.zeros(1, 3)
+        c = M.Consts(J, sd['graph_adj'].numpy(), module.spatial_pos, module.edge_input, z3.numpy(), z3.numpy(), [0], False, device)
+        return cls(sd, c, device, **kw)
+
+    def state_dict(self):
+        return self.params.state_dict()
+
+    def loss_and_grad(self, img_joint, cam_joint, joint_valid, training=True):
+        P = self.params.views()
+        B, J = img_joint.shape[0], self.consts.J
+        x_out, _ = M.gat_forward(P, self.consts, img_joint.reshape(B, J, 2), self.gen, self.rates, training, p='')
+        loss = self.losses.coord(x_out.reshape(B, J, 3), cam_joint, joint_valid)
+        one = ops.raw_unary(ops.U_AFFINE, loss.detach(), 0.0, 1.0)
+        grad, = torch.autograd.grad(loss, self.params.flat, grad_outputs=one)
+        return loss.detach(), grad
+
+    def step(self, img_joint, cam_joint, joint_valid):
+        self.gen.begin_step()
+        loss, grad = self.loss_and_grad(img_joint, cam_joint, joint_valid)
+        self.optim.epoch = self.epoch
+        self.optim.step(grad)
+        return loss

@@ -63,8 +63,8 @@ int gator_t_step_advance(uint64_t* step_counter, gator_stream stream);
 int gator_t_mask_scale(const float* x, const uint8_t* mask, int64_t n, float scale, float* out, gator_stream stream);
 
 /* torch.optim.Adam (lib/funcs_utils.py:91-95: lr only, betas 0.9/0.999, eps 1e-8, no weight decay) on one flat buffer */
-int gator_t_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                 float beta2, float eps, int step, const uint64_t* step_counter /* device; overrides `step` when given */,
+int gator_t_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                 double beta2, double eps, int step, const uint64_t* step_counter /* device; overrides `step` when given */,
                  gator_stream stream);
 
 /* The mesh losses of lib/core/loss.py on device, value and gradient in one pass each.

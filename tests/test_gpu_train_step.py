@@ -175,3 +175,60 @@ def test_captured_step_replays_like_eager_and_draws_new_masks():
     losses = [float(drop.step(x, tg)[0]) for _ in range(4)]           # lr = 0: only the masks change between replays
     assert len(set(losses)) == 4, losses
     assert all(np.isfinite(losses))
+
+
+def test_lift_trainer_matches_oracle_autograd():
+    """LiftTrainer (lib/core/base.py:260-300): GAT alone, CoordLoss on the lifted joints - gradients against torch-CPU float64
+    autograd over the oracle's gat_forward."""
+    from gator_amd.train.trainer import LiftTrainer
+    from oracle import gator_oracle as go
+    from tests.helpers import oracle_setup
+    name, B = 'coco19_alpha', 5
+    zz, m = build_model(name, 'fused')
+    lt = LiftTrainer.from_module(m.pose_lifter, rates=M.Rates(0.0))
+    J = 19
+    x = torch.from_numpy(synthetic.synthetic_pose2d(B, J, 21))
+    cam = torch.from_numpy(np.random.RandomState(3).randn(B, J, 3).astype(np.float32) * 250)
+    valid = torch.ones(B, J, 1)
+    valid[2] = 0
+    loss, grad = lt.loss_and_grad(x.cuda().reshape(B, -1), cam.cuda(), valid.cuda())
+    z, c, sd = oracle_setup(name)
+    P = {k: (v.double().requires_grad_(True) if (v.is_floating_point() and not M.is_buffer(k)) else v) for k, v in sd.items() if k.startswith('pose_lifter.')}
+    x_out, _ = go.gat_forward(P, c, x.reshape(B, -1), torch.float64)
+    oloss = go.coord_loss(x_out.reshape(B, J, 3), cam.double(), valid.double())
+    assert abs(float(loss) - float(oloss.detach())) <= 1e-5 * float(oloss.detach())
+    g = grad.cpu().double()
+    for k, (a, b, shape) in zip(lt.params.names, lt.params.slots):
+        og, = torch.autograd.grad(oloss, P['pose_lifter.' + k], retain_graph=True, allow_unused=True)
+        og = torch.zeros(shape, dtype=torch.float64) if og is None else og
+        scale = float(og.abs().max())
+        err = float((g[a:b].view(shape) - og).abs().max())
+        assert err <= 1e-4 * scale + 1e-9, (k, err, scale)
+    before = lt.params.flat.detach().clone()
+    lt.step(x.cuda().reshape(B, -1), cam.cuda(), valid.cuda())
+    assert float((lt.params.flat.detach() - before).abs().max()) > 0
+
+
+def test_optimizer_state_interchanges_with_torch_adam():
+    """main/train.py:51-58 / lib/core/base.py:73-77: the checkpoint's optim_state_dict is torch.optim.Adam's.  Ours loads into a
+    torch Adam over the same parameters (and back) and both continue identically."""
+    z, m, tr, _ = make_trainer('h36m17_bn', lr=1e-4)
+    x, tg = batch_of(z, 4, shift=8)
+    for _ in range(2):
+        tr.step(x, tg)
+    sd = tr.optim.state_dict()
+    cpu_params = [tr.params.flat.detach()[a:b].view(s).cpu().clone().requires_grad_(True) for a, b, s in tr.params.slots]
+    opt = torch.optim.Adam(cpu_params, lr=1e-4)
+    opt.load_state_dict(sd)                                             # torch accepts our layout
+    _, _, grad = tr.loss_and_grad(x, tg)
+    for p, (a, b, s) in zip(cpu_params, tr.params.slots):
+        p.grad = grad[a:b].view(s).cpu().clone()
+    opt.step()
+    tr.optim.step(grad)
+    worst = max(float((p.detach() - tr.params.flat.detach()[a:b].view(s).cpu()).abs().max()) for p, (a, b, s) in zip(cpu_params, tr.params.slots))
+    assert worst <= 2.4e-7, worst
+    z2, m2, tr2, _ = make_trainer('h36m17_bn', lr=1e-4)
+    tr2.optim.load_state_dict(opt.state_dict())                         # and torch's state loads into ours
+    assert tr2.optim.step_count == 3
+    assert float((tr2.optim.exp_avg - tr.optim.exp_avg).abs().max()) <= 1e-6 * float(tr.optim.exp_avg.abs().max())   # CPU lerp vs ours: ulps
+    assert float((tr2.optim.exp_avg_sq - tr.optim.exp_avg_sq).abs().max()) <= 1e-6 * float(tr.optim.exp_avg_sq.abs().max())
