@@ -39,6 +39,7 @@ struct GatArgs {
     float* jkv;
     const float *jf5, *jf_p, *jf_b, *posj_T;       // get_joint_feature: columns 0..4 as [5][64], columns 5..132 packed [2][4], bias
     const float *j_n1w[3], *j_n1b[3], *j_wk_p[3], *j_wv_p[3];
+    int pf_share, pf_n, pf_block;   // L2 warm-up of the next block's weights: bytes per workgroup, workgroups per XCD, bytes per block (0: off)
     int tapB;                       // batch stride of blk_tap (the whole batch of the call)
     float* blk_tap;                 // gator_enable_block_taps: residual stream after every GATBlock, [depth][B][J][128] (else nullptr)
 #ifdef GATOR_DIAG
@@ -194,6 +195,16 @@ __device__ __forceinline__ f32x16 lin4l(Grp<true>& g, const float* T, int lane, 
 }
 
 // TAIL = false: the kernel ends with `feat`; the lifter and the MDR joint tokens run as batched launches (gat_tail.hip)
+constexpr int kGatLdsFloatsX3 = 4 * kTile + 16 * kTileX3 + 2048;
+
+// LDS-DMA through inline asm (hipcc drains the builtin form with vmcnt(0) before the next LDS access, see gat_tiled.hip)
+__device__ __forceinline__ void glds16(const float* gsrc, const float* lds_dst) {
+    unsigned keep;
+    const unsigned dst = (unsigned)(unsigned long long)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
 template <bool X3K, bool TAIL>
 __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -270,10 +281,27 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
     // GATOR_PIN keeps the compiler from sinking a prefetch back down to its first use.
     Grp<X3K> G = ldg4<X3K>(a.blk[0].qkv, wave * 4, lane);
     GATOR_PIN();
+    // L2 warm-up.  All workgroups of an XCD walk the same 1.6 MB of weights per block in step, so every 4-tile group is an L2 miss
+    // for all of them at once and arrives with Infinity-Cache latency; with 96 KB in flight per CU that caps the stream near
+    // 45 GB/s per CU.  Each of the XCD's workgroups therefore pulls 1/n-th of the NEXT block's weights into the XCD's L2 one block
+    // ahead (LDS-DMA into a dummy 4 KB window: no registers; one burst at the top of a block, so the in-order vmcnt delays only
+    // the first group wait behind it).  Measured on one box: k_gat 235.8 -> 228.9 us (-3 %): the stream is NOT what holds the
+    // phases at twice their MFMA time - that is the wave's own MFMA -> VALU -> LDS-exchange dependency chain.
+    auto l2_warm = [&](const float* first) {
+        if (!X3K || a.pf_share == 0) return;
+        const int rank = (b >> 3) % a.pf_n;
+        const char* src = reinterpret_cast<const char*>(first) + (size_t)rank * a.pf_share;
+        const int left = a.pf_block - rank * a.pf_share;
+        float* dummy = lds + kGatLdsFloatsX3;
+        for (int off = 0; off < a.pf_share; off += 4096)
+            if (off + t * 16 < left) glds16(reinterpret_cast<const float*>(src + off + t * 16), dummy + wave * 256);   // (M0 = the wave's 1 KB window)
+    };
+    l2_warm(a.blk[0].qkv);
 
     for (int bi = 0; bi < kDepth; ++bi) {
         const GatBlockP& w = a.blk[bi];
         const GatBlockP& wn = a.blk[bi + 1 < kDepth ? bi + 1 : bi];     // next block (prefetch target; harmless re-load at the end)
+        if (bi + 1 < kDepth) l2_warm(wn.qkv);
         f32x16 g_out;
         f32x4 vn0, vn1;
         {
@@ -628,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void k_gat(const GatArgs a) {
 }  // namespace
 
 constexpr size_t kGatLds = (20 * kTile + 2048) * sizeof(float);                   // 88 KB
-constexpr size_t kGatLdsX3 = (4 * kTile + 16 * kTileX3 + 2048) * sizeof(float);   // 120 KB
+constexpr size_t kGatLdsX3 = (kGatLdsFloatsX3 + 1024) * sizeof(float);            // 120 KB + the 4 KB landing window of the L2 warm-up
 
 // Dynamic-LDS opt-in of the kernels, per DEVICE: called from fused_create_gat with the ctx's device current (a function
 // attribute set on one device does not carry to another, and a process may hold contexts on several).
@@ -673,6 +701,13 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
         (void)r;
     }
     a.x_out = x_out; a.feat = feat;
+    a.pf_share = a.pf_n = a.pf_block = 0;
+    static const bool l2warm = [] { const char* e = getenv("GATOR_GAT_L2WARM"); return !(e && atoi(e) == 0); }();     // default on; =0 for A/B
+    if (f->gat_x3 && l2warm) {
+        a.pf_block = (int)((a.blk[1].qkv - a.blk[0].qkv) * sizeof(float));
+        a.pf_n = std::min(32, (B + 7) / 8);
+        a.pf_share = ((a.pf_block + a.pf_n - 1) / a.pf_n + 4095) / 4096 * 4096;
+    }
     a.jkv = nullptr;
     if (joint_epilogue) {
         a.jkv = f->jkv; a.jf5 = f->jfeat5; a.jf_p = f->jfeat128_p; a.jf_b = w.jfeat_b; a.posj_T = f->posj_T;
