@@ -17,6 +17,14 @@ class GatorTensor(ctypes.Structure):
                 ('shape', ctypes.c_int64 * 4), ('is_host', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
+class GemmProblem(ctypes.Structure):            # include/gator_train.h: gator_gemm_problem
+    _fields_ = [('A', ctypes.c_void_p), ('B', ctypes.c_void_p), ('C', ctypes.c_void_p), ('a_rowsum', ctypes.c_void_p),
+                ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('ksplit', ctypes.c_int32),
+                ('stride_a', ctypes.c_int64 * 2), ('stride_b', ctypes.c_int64 * 2), ('stride_c', ctypes.c_int64 * 2),
+                ('alpha', ctypes.c_float), ('accumulate', ctypes.c_int32), ('wg_begin', ctypes.c_int32), ('fin_begin', ctypes.c_int32),
+                ('ws_off', ctypes.c_int64), ('total_wgs', ctypes.c_int32), ('total_fin', ctypes.c_int32)]
+
+
 class GatorConfig(ctypes.Structure):
     _fields_ = [('num_joint', ctypes.c_int32), ('alpha', ctypes.c_int32), ('impl', ctypes.c_int32),
                 ('max_batch', ctypes.c_int32), ('parts', ctypes.c_int32), ('subbatch_streams', ctypes.c_int32)]
@@ -57,6 +65,8 @@ SIGNATURES = {
     'gator_t_reduce_ws_bytes': (_L, [_P, _P]),
     'gator_t_reduce_sum': (_I, [_P, _P, _P, _P, _P, _I, _P, _P]),
     'gator_t_gemm': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, ctypes.c_float, _I, _I, _P, _P, _P]),
+    'gator_t_gemm_grouped_prepare': (_L, [_P, _I]),
+    'gator_t_gemm_grouped': (_I, [_P, _I, _P, _P, _P]),
     'gator_t_layernorm_fwd': (_I, [_P, _L, _I, _P, _P, ctypes.c_float, _I, _P, _P, _P, _P]),
     'gator_t_layernorm_bwd': (_I, [_P, _P, _P, _P, _P, _L, _I, ctypes.c_float, _I, _P, _P, _P]),
     'gator_t_softmax_fwd': (_I, [_P, _L, _I, _P, _P]),

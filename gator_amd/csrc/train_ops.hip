@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 
 #include "gator_train.h"
 #include "internal.h"
@@ -231,18 +232,19 @@ struct GemmArgs {
 
 // 64x64 output tile per workgroup, K in steps of 32 through LDS ([k][m] / [k][n] images: the MFMA operand fragments are
 // conflict-free row reads); wave w owns the 32x32 quadrant (w>>1, w&1); v_mfma_f32_32x32x2_f32 keeps fp32 products exact.
-__global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
-    constexpr int BK = 32;
-    __shared__ float As[2][BK][65], Bs[2][BK][65];
+constexpr int kGemmBK = 32;
+
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, float (&As)[2][kGemmBK][65], float (&Bs)[2][kGemmBK][65], int tile, int batch, int zslice) {
+    constexpr int BK = kGemmBK;
     const int tiles_n = (g.N + 63) / 64;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-    const int bi1 = blockIdx.y / g.nb2, bi2 = blockIdx.y % g.nb2;
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int bi1 = batch / g.nb2, bi2 = batch % g.nb2;
     const float* A = g.A + bi1 * g.a1 + bi2 * g.a2;
     const float* B = g.B + bi1 * g.b1 + bi2 * g.b2;
     const int m0 = tm * 64, n0 = tn * 64;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
     const int kper = ((g.K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK;
-    const int kbeg = blockIdx.z * kper, kend = kbeg + kper < g.K ? kbeg + kper : g.K;
+    const int kbeg = zslice * kper, kend = kbeg + kper < g.K ? kbeg + kper : g.K;
     f32x16t acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -309,12 +311,12 @@ __global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
             float v = 0.f;
             for (int j = 0; j < slots; ++j) v += S[t * 33 + j];
             if (g.ksplit > 1)
-                g.rowsum[(int64_t)blockIdx.z * g.M + m0 + t] = v;
+                g.rowsum[(int64_t)zslice * g.M + m0 + t] = v;
             else
                 g.rowsum[m0 + t] = g.alpha * v;
         }
     }
-    float* C = g.C + bi1 * g.c1 + bi2 * g.c2 + (g.ksplit > 1 ? (int64_t)blockIdx.z * g.M * g.N : 0);
+    float* C = g.C + bi1 * g.c1 + bi2 * g.c2 + (g.ksplit > 1 ? (int64_t)zslice * g.M * g.N : 0);
     const int col = n0 + wn * 32 + (lane & 31);
     if (col >= g.N) return;
     const float bias = (g.bias && g.ksplit == 1) ? g.bias[col] : 0.f;
@@ -330,16 +332,65 @@ __global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
     }
 }
 
+__global__ __launch_bounds__(kThreads) void k_t_gemm(GemmArgs g) {
+    __shared__ float As[2][kGemmBK][65], Bs[2][kGemmBK][65];
+    gemm_tile(g, As, Bs, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped form: ONE launch runs a list of independent unbatched products (the weight gradients of a whole backward pass, which
+// nothing consumes before the optimiser).  Workgroup -> (problem, tile, K slice) through the table's running workgroup count.
+struct GroupedProblem {
+    const float *A, *B;
+    float *C, *rowsum;                 // final destinations
+    int M, N, K, ksplit;
+    int64_t am, ak, bk, bn, cm, cn;
+    float alpha;
+    int accumulate;
+    int wg_begin, fin_begin;           // first workgroup of this problem in the product launch / in the finish launch
+    int64_t ws_off;                    // floats into the shared split-K workspace
+    int total_wgs, total_fin;          // (entry 0: launch sizes; keeps the layout of gator_gemm_problem)
+};
+
+__device__ __forceinline__ int find_problem(const GroupedProblem* __restrict__ tab, int n, int wg, bool fin) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((fin ? tab[mid].fin_begin : tab[mid].wg_begin) <= wg) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_gemm_grouped(const GroupedProblem* __restrict__ tab, int n, float* __restrict__ ws) {
+    __shared__ float As[2][kGemmBK][65], Bs[2][kGemmBK][65];
+    const int pi = find_problem(tab, n, blockIdx.x, false);
+    const GroupedProblem p = tab[pi];
+    const int local = blockIdx.x - p.wg_begin, tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+    GemmArgs g;
+    g.A = p.A; g.B = p.B; g.bias = nullptr;
+    g.M = p.M; g.N = p.N; g.K = p.K; g.nb2 = 1; g.ksplit = p.ksplit;
+    g.am = p.am; g.ak = p.ak; g.bk = p.bk; g.bn = p.bn;
+    g.a1 = g.a2 = g.b1 = g.b2 = g.c1 = g.c2 = 0;
+    if (p.ksplit > 1) {
+        g.C = ws + p.ws_off; g.cm = p.N; g.cn = 1; g.alpha = 1.f; g.accumulate = 0;
+        g.rowsum = p.rowsum ? ws + p.ws_off + (int64_t)p.ksplit * p.M * p.N : nullptr;
+    } else {
+        g.C = p.C; g.cm = p.cm; g.cn = p.cn; g.alpha = p.alpha; g.accumulate = p.accumulate;
+        g.rowsum = p.rowsum;
+    }
+    g.a_kfast = (g.ak == 1 || g.am != 1) ? 1 : 0;
+    g.b_nfast = (g.bn == 1 || g.bk != 1) ? 1 : 0;
+    gemm_tile(g, As, Bs, local % tiles, 0, local / tiles);
+}
+
 // 64 consecutive outputs per workgroup; the four waves take the slices k = w, w+4, ... with four loads in flight each, then combine
-__global__ __launch_bounds__(kThreads) void k_t_splitk_finish(const float* __restrict__ ws, int ksplit, int M, int N, float* __restrict__ C,
-                                                              int64_t cm, int64_t cn, const float* __restrict__ bias, float alpha,
-                                                              int accumulate, const float* __restrict__ ws_rowsum, float* __restrict__ rowsum) {
-    __shared__ float sh[4][64];
+__device__ __forceinline__ void splitk_finish_block(float (&sh)[4][64], int64_t block, const float* __restrict__ ws, int ksplit, int M, int N,
+                                                    float* __restrict__ C, int64_t cm, int64_t cn, const float* __restrict__ bias, float alpha,
+                                                    int accumulate, const float* __restrict__ ws_rowsum, float* __restrict__ rowsum) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t MN = (int64_t)M * N;
     const int64_t blocks_c = (MN + 63) / 64;
-    const bool is_rs = blockIdx.x >= blocks_c;                    // trailing workgroups finish the row sums
-    const int64_t i = (is_rs ? blockIdx.x - blocks_c : blockIdx.x) * 64 + tx;
+    const bool is_rs = block >= blocks_c;                         // trailing workgroups finish the row sums
+    const int64_t i = (is_rs ? block - blocks_c : block) * 64 + tx;
     const int64_t total = is_rs ? M : MN;
     const float* src = is_rs ? ws_rowsum : ws;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -368,6 +419,23 @@ __global__ __launch_bounds__(kThreads) void k_t_splitk_finish(const float* __res
     float* c = C + (int64_t)m * cm + (int64_t)n * cn;
     if (accumulate) v += *c;
     *c = v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_splitk_finish(const float* __restrict__ ws, int ksplit, int M, int N, float* __restrict__ C,
+                                                              int64_t cm, int64_t cn, const float* __restrict__ bias, float alpha,
+                                                              int accumulate, const float* __restrict__ ws_rowsum, float* __restrict__ rowsum) {
+    __shared__ float sh[4][64];
+    splitk_finish_block(sh, blockIdx.x, ws, ksplit, M, N, C, cm, cn, bias, alpha, accumulate, ws_rowsum, rowsum);
+}
+
+__global__ __launch_bounds__(kThreads) void k_t_splitk_finish_grouped(const GroupedProblem* __restrict__ tab, int n, const float* __restrict__ ws) {
+    __shared__ float sh[4][64];
+    const int pi = find_problem(tab, n, blockIdx.x, true);
+    const GroupedProblem p = tab[pi];
+    if (p.ksplit <= 1) return;                                   // (problems without split-K own no finish workgroups; defensive)
+    const float* w = ws + p.ws_off;
+    splitk_finish_block(sh, blockIdx.x - p.fin_begin, w, p.ksplit, p.M, p.N, p.C, p.cm, p.cn, nullptr, p.alpha, p.accumulate,
+                        p.rowsum ? w + (int64_t)p.ksplit * p.M * p.N : nullptr, p.rowsum);
 }
 
 // ------------------------------------------------------------------------------------------------------------ row kernels
@@ -770,6 +838,43 @@ int gator_t_gemm(const float* A, const float* B, float* C, int M, int N, int K, 
         hipLaunchKernelGGL(k_t_splitk_finish, dim3((unsigned)(((int64_t)M * N + 63) / 64 + (a_rowsum ? (M + 63) / 64 : 0))), dim3(kThreads), 0, st, ws, ksplit, M, N, C,
                            sc[0], sc[1], bias, alpha, accumulate, a_rowsum ? ws + (int64_t)ksplit * M * N : nullptr, a_rowsum);
     return check_launch("gator_t_gemm");
+}
+
+int64_t gator_t_gemm_grouped_prepare(gator_gemm_problem* pr, int n) {
+    if (!pr || n <= 0) return -1;
+    int64_t ws = 0;
+    int wg = 0, fin = 0;
+    for (int i = 0; i < n; ++i) {
+        gator_gemm_problem& p = pr[i];
+        if (p.M <= 0 || p.N <= 0 || p.K < 0 || p.ksplit < 1) return -1;
+        const int tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+        p.wg_begin = wg;
+        p.fin_begin = fin;
+        p.ws_off = ws;
+        wg += tiles * p.ksplit;
+        if (p.ksplit > 1) {
+            fin += (int)(((int64_t)p.M * p.N + 63) / 64) + (p.a_rowsum ? (p.M + 63) / 64 : 0);
+            ws += (int64_t)p.ksplit * ((int64_t)p.M * p.N + p.M);
+        }
+    }
+    pr[0].total_wgs = wg;
+    pr[0].total_fin = fin;
+    return ws;
+}
+
+int gator_t_gemm_grouped(const gator_gemm_problem* table_host, int n, void* table_dev, float* ws, gator_stream stream) {
+    if (!table_host || !table_dev || n <= 0) return fail(1, "gator_t_gemm_grouped: bad argument");
+    static_assert(sizeof(gator_gemm_problem) == sizeof(GroupedProblem) && offsetof(gator_gemm_problem, ws_off) == offsetof(GroupedProblem, ws_off), "host / device problem layouts");
+    hipStream_t st = (hipStream_t)stream;
+    const int wgs = table_host[0].total_wgs, fin = table_host[0].total_fin;
+    if (wgs <= 0) return fail(1, "gator_t_gemm_grouped: call gator_t_gemm_grouped_prepare first");
+    if (fin > 0 && !ws) return fail(1, "gator_t_gemm_grouped: split-K problems need the workspace");
+    const hipError_t e = hipMemcpyAsync(table_dev, table_host, (size_t)n * sizeof(gator_gemm_problem), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return fail((int)e, "gator_t_gemm_grouped: table upload: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_t_gemm_grouped, dim3(wgs), dim3(kThreads), 0, st, static_cast<const GroupedProblem*>(table_dev), n, ws);
+    if (fin > 0)
+        hipLaunchKernelGGL(k_t_splitk_finish_grouped, dim3(fin), dim3(kThreads), 0, st, static_cast<const GroupedProblem*>(table_dev), n, ws);
+    return check_launch("gator_t_gemm_grouped");
 }
 
 int gator_t_layernorm_fwd(const float* x, int64_t rows, int n, const float* w, const float* b, float eps, int mode, float* y, float* mean,

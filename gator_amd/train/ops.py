@@ -137,6 +137,59 @@ def _contig(x):
     return x if x.is_contiguous() else raw_copy(x)
 
 
+# ------------------------------------------------------------------------------------------------ deferred weight gradients
+class Deferred:
+    """Weight / bias gradients are LEAVES of the backward graph: nothing reads them before the optimiser.  Backward nodes queue
+    them here instead of launching each between two links of the dependent activation-gradient chain, and `flush()` - called by
+    the last backward node, the parameter scatter - runs the whole list as ONE grouped GEMM launch (+ one split-K finish):
+    ~70 small products that fill the chip together instead of ~230 latency-bound launches on the critical path."""
+    enabled = True
+    queue = []
+    pool = None        # pinned host memory for the problem tables of CAPTURED steps (a replayed graph re-reads its table); allocated
+    pool_used = 0      # outside any capture (page-locking is not capturable) and carved up without reuse
+
+    @staticmethod
+    def add(a4, b4, out4, rowsum):
+        Deferred.queue.append((a4, b4, out4, rowsum))
+
+    @staticmethod
+    def flush(dev):
+        q = Deferred.queue
+        if not q:
+            return
+        n = len(q)
+        nbytes = n * ctypes.sizeof(_lib.GemmProblem)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if Deferred.pool is None and not capturing:
+            Deferred.pool = torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True)
+        if capturing:
+            if Deferred.pool is None or Deferred.pool_used + nbytes > Deferred.pool.numel():
+                raise RuntimeError('gator_amd.train: run one eager step before capturing (pinned table pool) / pool exhausted')
+            arr = (_lib.GemmProblem * n).from_address(Deferred.pool.data_ptr() + Deferred.pool_used)
+            Deferred.pool_used += (nbytes + 255) // 256 * 256
+        else:
+            arr = (_lib.GemmProblem * n)()             # pageable: the upload is staged before the call returns
+        for p, (a4, b4, out4, rowsum) in zip(arr, q):
+            M, K, N = a4.shape[2], a4.shape[3], b4.shape[3]
+            tiles = ((M + 63) // 64) * ((N + 63) // 64)
+            p.A, p.B, p.C = a4.data_ptr(), b4.data_ptr(), out4.data_ptr()
+            p.a_rowsum = rowsum.data_ptr() if rowsum is not None else None
+            p.M, p.N, p.K = M, N, K
+            p.ksplit = max(1, min(64, K // 128, 1024 // tiles)) if (K >= 512 and tiles < 256) else 1
+            p.stride_a[0], p.stride_a[1] = a4.stride(2), a4.stride(3)
+            p.stride_b[0], p.stride_b[1] = b4.stride(2), b4.stride(3)
+            p.stride_c[0], p.stride_c[1] = out4.stride(2), out4.stride(3)
+            p.alpha, p.accumulate = 1.0, 0
+        lib = _lib.load()
+        ws_floats = int(lib.gator_t_gemm_grouped_prepare(arr, n))
+        if ws_floats < 0:
+            raise RuntimeError('gator_t_gemm_grouped_prepare rejected the problem list')
+        ws = torch.empty(max(ws_floats, 1), device=dev, dtype=torch.float32)
+        table = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        _call('gator_t_gemm_grouped', arr, n, table.data_ptr(), ws.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        q.clear()
+
+
 # ------------------------------------------------------------------------------------------------ differentiable ops
 class _Binary(torch.autograd.Function):
     @staticmethod
@@ -348,8 +401,12 @@ class _Linear(torch.autograd.Function):
         need_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:                      # dW = dY^T X; the bias gradient (row sums of dY^T) rides on the same launch
             gb = (ctx.bslot if ctx.bslot is not None else torch.empty(w4.shape[2], device=g.device, dtype=torch.float32)) if need_b else None
-            gw = raw_gemm(g2.transpose(2, 3), x2, a_rowsum=gb, out=ctx.wslot.view(w4.shape) if ctx.wslot is not None else None)
-            gw = ctx.wslot if ctx.wslot is not None else gw.reshape(w4.shape[2], w4.shape[3])
+            if Deferred.enabled and ctx.wslot is not None and (gb is None or ctx.bslot is not None):
+                Deferred.add(g2.transpose(2, 3), x2, ctx.wslot.view(w4.shape), gb)       # lands in the flat gradient buffer: grouped launch
+                gw = ctx.wslot
+            else:
+                gw = raw_gemm(g2.transpose(2, 3), x2, a_rowsum=gb, out=ctx.wslot.view(w4.shape) if ctx.wslot is not None else None)
+                gw = ctx.wslot if ctx.wslot is not None else gw.reshape(w4.shape[2], w4.shape[3])
         elif need_b:
             gb = raw_sum(g2.reshape(-1, g2.shape[-1]), [0])
         return gx, gw, gb

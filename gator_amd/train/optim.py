@@ -22,6 +22,7 @@ class _Unflatten(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         o = ctx.owner
+        ops.Deferred.flush(o.flat.device)                  # the queued weight gradients: one grouped GEMM launch
         out = o.gflat
         for g, (a, b, shape) in zip(gs, o.slots):
             if g is not None and g.data_ptr() != out.data_ptr() + 4 * a:      # ops that know their slot wrote it in place (ops.grad_slot)

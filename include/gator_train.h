@@ -40,6 +40,25 @@ int gator_t_gemm(const float* A, const float* B, float* C, int M, int N, int K, 
                  const int64_t* batch_c2, const float* bias, float alpha, int accumulate, int ksplit, float* ws,
                  float* a_rowsum, gator_stream stream);
 
+/* Grouped form: ONE launch for a list of independent unbatched products C_i = alpha_i * A_i . B_i (+ a_rowsum_i), each split over K as
+ * its ksplit says (+ one launch that sums the slices).  The weight gradients of a backward pass are such a list: nothing reads them
+ * before the optimiser, so they leave the dependent chain of activation gradients and fill the chip together.
+ * gator_t_gemm_grouped_prepare fills the bookkeeping fields and returns the workspace size in floats (-1: bad problem);
+ * table_host must stay unchanged until the upload has run (for a captured stream: as long as the graph is replayed). */
+typedef struct gator_gemm_problem {
+    const float *A, *B;
+    float *C, *a_rowsum;
+    int32_t M, N, K, ksplit;
+    int64_t stride_a[2], stride_b[2], stride_c[2];   /* (m,k) (k,n) (m,n), elements */
+    float alpha;
+    int32_t accumulate;
+    int32_t wg_begin, fin_begin;                     /* filled by _prepare */
+    int64_t ws_off;                                  /* filled by _prepare */
+    int32_t total_wgs, total_fin;                    /* filled by _prepare in entry 0 */
+} gator_gemm_problem;
+int64_t gator_t_gemm_grouped_prepare(gator_gemm_problem* problems, int n);
+int gator_t_gemm_grouped(const gator_gemm_problem* table_host, int n, void* table_dev, float* ws, gator_stream stream);
+
 /* rows of n contiguous floats.  mode 0: nn.LayerNorm (biased variance, eps inside the root); mode 1: the MDR LayerNorm
  * (lib/models/vanilla_transformer_encoder.py:31-34: unbiased std, eps added to the std).  w, b may be NULL (no affine).
  * forward saves mean[rows] and rinv[rows] (1/sqrt(var+eps) resp. 1/(std+eps)); backward writes dx and, if dy_xhat != NULL,
