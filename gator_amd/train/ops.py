@@ -138,6 +138,17 @@ def _contig(x):
 
 
 # ------------------------------------------------------------------------------------------------ deferred weight gradients
+_ONES = {}
+
+
+def _one(dev):
+    """A device scalar 1.0, used with stride 0 as the all-ones operand that turns a column sum into a row of a grouped GEMM."""
+    t = _ONES.get(dev)
+    if t is None:
+        t = _ONES[dev] = raw_unary(U_AFFINE, zeros((1,), dev), 0.0, 1.0)
+    return t
+
+
 class Deferred:
     """Weight / bias gradients are LEAVES of the backward graph: nothing reads them before the optimiser.  Backward nodes queue
     them here instead of launching each between two links of the dependent activation-gradient chain, and `flush()` - called by
@@ -471,10 +482,20 @@ class _LayerNorm(torch.autograd.Function):
         _call('gator_t_layernorm_bwd', gc.data_ptr(), xc.data_ptr(), mean.data_ptr(), rinv.data_ptr(), w.data_ptr() if w is not None else None, rows, n,
               float(ctx.eps), int(ctx.mode), dx.data_ptr(), dyx.data_ptr() if need_w else None, _stream(xc))
         gw = gb = None
+        grouped = Deferred.enabled
+        ones = _one(xc.device).as_strided((1, 1, 1, rows), (0, 0, 0, 0)) if grouped else None      # column sums as 1 x rows products
         if need_w:
-            gw = raw_sum(dyx.reshape(rows, n), [0], keepdim=True, out=ctx.wslot.view(1, n) if ctx.wslot is not None else None).reshape(n)
+            if grouped and ctx.wslot is not None:
+                Deferred.add(ones, dyx.view(1, 1, rows, n), ctx.wslot.view(1, 1, 1, n), None)
+                gw = ctx.wslot
+            else:
+                gw = raw_sum(dyx.reshape(rows, n), [0], keepdim=True, out=ctx.wslot.view(1, n) if ctx.wslot is not None else None).reshape(n)
         if ctx.has_b and ctx.needs_input_grad[2]:
-            gb = raw_sum(gc.reshape(rows, n), [0], keepdim=True, out=ctx.bslot.view(1, n) if ctx.bslot is not None else None).reshape(n)
+            if grouped and ctx.bslot is not None:
+                Deferred.add(ones, gc.view(1, 1, rows, n), ctx.bslot.view(1, 1, 1, n), None)
+                gb = ctx.bslot
+            else:
+                gb = raw_sum(gc.reshape(rows, n), [0], keepdim=True, out=ctx.bslot.view(1, n) if ctx.bslot is not None else None).reshape(n)
         return dx, gw, gb, None, None
 
 
