@@ -54,6 +54,7 @@ class FlatParams:
     def views(self):
         """name -> differentiable view of the flat buffer (call once per step, inside the graph).  Every view carries its slice
         of this step's flat gradient buffer (`_gslot`): linear / LayerNorm backward write weight gradients straight into it."""
+        ops.Deferred.queue.clear()                         # (a backward that raised may have left entries behind)
         self.gflat = ops.zeros((self.numel,), self.flat.device)
         vs = _Unflatten.apply(self.flat, self)
         for v, (a, b, shape) in zip(vs, self.slots):
