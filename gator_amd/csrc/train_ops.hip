@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <cstring>
 
 #include "gator_train.h"
 #include "internal.h"
@@ -742,6 +743,8 @@ int face_loss(bool normal, const float* pred, const float* target, const int32_t
     return check_launch(normal ? "gator_t_normal_loss" : "gator_t_edge_loss");
 }
 
+#include "train_gat.inc"
+
 }  // namespace
 }  // namespace gator
 
@@ -942,6 +945,28 @@ int gator_t_adam(float* param, const float* grad, float* exp_avg, float* exp_avg
     hipLaunchKernelGGL(k_t_adam, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, (float)lr, (float)beta1,
                        (float)beta2, (float)eps, (float)bc1, (float)sqrt(bc2), step_counter, (float)(1.0 - beta1), (float)(1.0 - beta2));
     return check_launch("gator_t_adam");
+}
+
+static int gat_block_check(const gator_gat_block* a, const char* what) {
+    static_assert(sizeof(gator_gat_block) == sizeof(GatBlkArgs), "gator_gat_block / GatBlkArgs layouts");
+    if (!a || a->B <= 0 || a->J < 2 || a->J > 32) { fail(1, "%s: bad argument", what); return 1; }
+    return 0;
+}
+
+int gator_t_gat_block_fwd(const gator_gat_block* a, gator_stream stream) {
+    if (gat_block_check(a, "gator_t_gat_block_fwd")) return 1;
+    GatBlkArgs k;
+    memcpy(&k, a, sizeof(k));
+    hipLaunchKernelGGL(k_t_gat_block_fwd, dim3(a->B), dim3(kThreads), 0, (hipStream_t)stream, k);
+    return check_launch("gator_t_gat_block_fwd");
+}
+
+int gator_t_gat_block_bwd(const gator_gat_block* a, gator_stream stream) {
+    if (gat_block_check(a, "gator_t_gat_block_bwd")) return 1;
+    GatBlkArgs k;
+    memcpy(&k, a, sizeof(k));
+    hipLaunchKernelGGL(k_t_gat_block_bwd, dim3(a->B), dim3(kThreads), 0, (hipStream_t)stream, k);
+    return check_launch("gator_t_gat_block_bwd");
 }
 
 int64_t gator_t_loss_ws_bytes(int64_t B, int64_t F) { return 65536 + B * F * 9 * (int64_t)sizeof(float); }

@@ -116,6 +116,59 @@ def hop_path_bias(P, c, p='pose_lifter.get_hop_path_encoding.'):
     return ops.add(spb, ops.mul(eb, c.inv_spatial))
 
 
+import os
+
+# GATOR_TRAIN_FUSED_GAT=1: one launch per GATBlock and direction (train/fused.py) instead of the block composed from primitives.
+# Measured: the per-sample kernels are correct and cut the step's launches from 1 210 to 570, but their ~45 dependent
+# products per block run serially on one CU per sample - 11.5 vs 10.5 ms at B=64, equal at B=256 - so the composed block stays the default.
+FUSED_GAT_BLOCKS = os.environ.get('GATOR_TRAIN_FUSED_GAT', '0')
+
+
+def gat_block(P, c, x, bias, i, gen, rates, training=True, p='pose_lifter.'):
+    """GATBlock.forward (lib/models/GAT.py:33-43) composed from the primitives: x [B,J,128] -> [B,J,128]."""
+    g = lambda k: P[p + k]
+    B, J, H, C = x.shape[0], c.J, NUM_HEADS, EMBED
+    scale = (C // H) ** -0.5
+    b = 'blocks.%d.' % i
+    x, res = ops.fork(x)
+    y = ops.layernorm(x, g(b + 'norm1.weight'), g(b + 'norm1.bias'), 1e-5, 0)
+    y, y0, y1 = ops.fork(y, 3)
+    # Attention (modules.py:121-138)
+    qkv = ops.linear(y, g(b + 'attn.qkv.weight'), g(b + 'attn.qkv.bias')).reshape(B, J, 3, C)
+    q, k, v = [ops.reshape(t, B, J, H, C // H).permute(0, 2, 1, 3) for t in ops.split(qkv, 2, (1, 1, 1))]
+    att = ops.add(ops.matmul(q, k.transpose(-2, -1), scale), bias)
+    att = ops.dropout(ops.softmax(att), rates.gat_attn, gen, training)
+    a = ops.contiguous(ops.matmul(att, v).transpose(1, 2)).reshape(B, J, C)
+    a = ops.dropout(ops.linear(a, g(b + 'attn.proj.weight'), g(b + 'attn.proj.bias')), rates.gat_proj, gen, training)
+    # MGCN (modules.py:243-255)
+    W0, W1 = ops.split(g(b + 'gcn.W'), 0, (1, 1))
+    h0 = ops.matmul(y0, W0.reshape(C, C))
+    h1 = ops.matmul(y1, W1.reshape(C, C))
+    adj_d, adj_o = ops.fork(sym_adjacency(c, g(b + 'gcn.adj2')))
+    M0, M1 = ops.fork(g(b + 'gcn.M'))
+    gout = ops.add(ops.add(ops.matmul(ops.mul(adj_d, c.E), ops.mul(M0, h0)), ops.matmul(ops.mul(adj_o, c.notE), ops.mul(M1, h1))),
+                   g(b + 'gcn.bias').reshape(1, 1, -1))
+    s = ops.drop_path(ops.add(a, gout), rates.gat_path[i], gen, training)
+    # X_Feat (modules.py:158-177)
+    s0, s1 = ops.fork(s)
+    f0 = ops.matmul(c.m1, ops.linear(s0, g(b + 'x_feat.linears.0.weight'), g(b + 'x_feat.linears.0.bias')))
+    f1 = ops.matmul(c.m2, ops.linear(s1, g(b + 'x_feat.linears.1.weight'), g(b + 'x_feat.linears.1.bias')))
+    xf = ops.linear(ops.cat([f0, f1], 2), g(b + 'x_feat.linearback.weight'), g(b + 'x_feat.linearback.bias'))
+    x = ops.add(res, xf)
+    # MLP (modules.py:188-196)
+    x, res = ops.fork(x)
+    y2 = ops.layernorm(x, g(b + 'norm2.weight'), g(b + 'norm2.bias'), 1e-5, 0)
+    hdn = ops.dropout(ops.gelu(ops.linear(y2, g(b + 'mlp.fc1.weight'), g(b + 'mlp.fc1.bias'))), rates.gat_mlp, gen, training)
+    m = ops.dropout(ops.linear(hdn, g(b + 'mlp.fc2.weight'), g(b + 'mlp.fc2.bias')), rates.gat_mlp, gen, training)
+    return ops.add(res, ops.drop_path(m, rates.gat_path[i], gen, training))
+
+
+def sym_adjacency(c, adj2):
+    """MGCN's adjacency (modules.py:247-248): ((A + adj2)^T + (A + adj2)) / 2"""
+    adj_a, adj_b = ops.fork(ops.add(c.A, adj2))
+    return ops.affine(ops.add(adj_a.t(), adj_b), 0.5)
+
+
 def gat_forward(P, c, pose2d, gen, rates, training=True, p='pose_lifter.'):
     """GAT.forward (lib/models/GAT.py:133-152) in training mode.  pose2d [B,J,2] -> (x_out [B,3J] mm, feat [B,J,128])."""
     g = lambda k: P[p + k]
@@ -130,41 +183,12 @@ def gat_forward(P, c, pose2d, gen, rates, training=True, p='pose_lifter.'):
     x = ops.add(x, ops.narrow(g('pos_id_embed.weight'), 0, 1, J))
     x = ops.add(x, ops.matmul(c.deg_onehot, g('pos_num_embed.weight')))
     biases = ops.fork(hop_path_bias(P, c, p + 'get_hop_path_encoding.'), DEPTH)
-    scale = (C // H) ** -0.5
     for i in range(DEPTH):
-        b = 'blocks.%d.' % i
-        x, res = ops.fork(x)
-        y = ops.layernorm(x, g(b + 'norm1.weight'), g(b + 'norm1.bias'), 1e-5, 0)
-        y, y0, y1 = ops.fork(y, 3)
-        # Attention (modules.py:121-138)
-        qkv = ops.linear(y, g(b + 'attn.qkv.weight'), g(b + 'attn.qkv.bias')).reshape(B, J, 3, C)
-        q, k, v = [ops.reshape(t, B, J, H, C // H).permute(0, 2, 1, 3) for t in ops.split(qkv, 2, (1, 1, 1))]
-        att = ops.add(ops.matmul(q, k.transpose(-2, -1), scale), biases[i])
-        att = ops.dropout(ops.softmax(att), rates.gat_attn, gen, training)
-        a = ops.contiguous(ops.matmul(att, v).transpose(1, 2)).reshape(B, J, C)
-        a = ops.dropout(ops.linear(a, g(b + 'attn.proj.weight'), g(b + 'attn.proj.bias')), rates.gat_proj, gen, training)
-        # MGCN (modules.py:243-255)
-        W0, W1 = ops.split(g(b + 'gcn.W'), 0, (1, 1))
-        h0 = ops.matmul(y0, W0.reshape(C, C))
-        h1 = ops.matmul(y1, W1.reshape(C, C))
-        adj_a, adj_b = ops.fork(ops.add(c.A, g(b + 'gcn.adj2')))
-        adj_d, adj_o = ops.fork(ops.affine(ops.add(adj_a.t(), adj_b), 0.5))
-        M0, M1 = ops.fork(g(b + 'gcn.M'))
-        gout = ops.add(ops.add(ops.matmul(ops.mul(adj_d, c.E), ops.mul(M0, h0)), ops.matmul(ops.mul(adj_o, c.notE), ops.mul(M1, h1))),
-                       g(b + 'gcn.bias').reshape(1, 1, -1))
-        s = ops.drop_path(ops.add(a, gout), rates.gat_path[i], gen, training)
-        # X_Feat (modules.py:158-177)
-        s0, s1 = ops.fork(s)
-        f0 = ops.matmul(c.m1, ops.linear(s0, g(b + 'x_feat.linears.0.weight'), g(b + 'x_feat.linears.0.bias')))
-        f1 = ops.matmul(c.m2, ops.linear(s1, g(b + 'x_feat.linears.1.weight'), g(b + 'x_feat.linears.1.bias')))
-        xf = ops.linear(ops.cat([f0, f1], 2), g(b + 'x_feat.linearback.weight'), g(b + 'x_feat.linearback.bias'))
-        x = ops.add(res, xf)
-        # MLP (modules.py:188-196)
-        x, res = ops.fork(x)
-        y2 = ops.layernorm(x, g(b + 'norm2.weight'), g(b + 'norm2.bias'), 1e-5, 0)
-        hdn = ops.dropout(ops.gelu(ops.linear(y2, g(b + 'mlp.fc1.weight'), g(b + 'mlp.fc1.bias'))), rates.gat_mlp, gen, training)
-        m = ops.dropout(ops.linear(hdn, g(b + 'mlp.fc2.weight'), g(b + 'mlp.fc2.bias')), rates.gat_mlp, gen, training)
-        x = ops.add(res, ops.drop_path(m, rates.gat_path[i], gen, training))
+        if FUSED_GAT_BLOCKS == '1':
+            from . import fused
+            x = fused.gat_block(P, c, x, biases[i], i, gen, rates, training, p)
+        else:
+            x = gat_block(P, c, x, biases[i], i, gen, rates, training, p)
     feat = ops.gelu(ops.layernorm(x, g('norm.weight'), g('norm.bias'), 1e-5, 0))
     feat, f2 = ops.fork(feat)
     x_out = ops.linear(f2.reshape(B, J * C), g('lifter.weight'), g('lifter.bias'))
