@@ -253,30 +253,32 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, float (&As)[2][kGem
     const bool do_rowsum = g.rowsum != nullptr && tn == 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) rs[i] = 0.f;
-    // lanes run along whichever index is contiguous in memory: (k fast) k = t % 32, m = t / 32 + 8 i; (m fast) m = t % 64, k = t / 64 + 4 i
+    // lanes run along whichever index is contiguous in memory: (k fast) k = t % 32, m = t / 32 + 8 i; (m fast) m = t % 64, k = t / 64 + 4 i.
+    // The element offsets are formed once (row part, 64-bit) and advanced by a per-step scalar; only the k bound is tested per step.
+    int ak_[8], bk_[8], am_[8], bn_[8];
+    int64_t aoff[8], boff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (g.a_kfast) { ak_[i] = t & 31; am_[i] = (t >> 5) + 8 * i; } else { am_[i] = t & 63; ak_[i] = (t >> 6) + 4 * i; }
+        if (g.b_nfast) { bn_[i] = t & 63; bk_[i] = (t >> 6) + 4 * i; } else { bk_[i] = t & 31; bn_[i] = (t >> 5) + 8 * i; }
+        const bool okm = (m0 + am_[i]) < g.M, okn = (n0 + bn_[i]) < g.N;
+        aoff[i] = okm ? (int64_t)(m0 + am_[i]) * g.am + (int64_t)ak_[i] * g.ak : -1;
+        boff[i] = okn ? (int64_t)(n0 + bn_[i]) * g.bn + (int64_t)bk_[i] * g.bk : -1;
+    }
     auto fetch = [&](int k0) {
+        const int64_t ka = (int64_t)k0 * g.ak, kb = (int64_t)k0 * g.bk;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            int m, k;
-            if (g.a_kfast) { k = t & 31; m = (t >> 5) + 8 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
-            const bool ok = (m0 + m) < g.M && (k0 + k) < kend;
-            ra[i] = ok ? A[(int64_t)(m0 + m) * g.am + (int64_t)(k0 + k) * g.ak] : 0.f;
-            int n, kk;
-            if (g.b_nfast) { n = t & 63; kk = (t >> 6) + 4 * i; } else { kk = t & 31; n = (t >> 5) + 8 * i; }
-            const bool okb = (n0 + n) < g.N && (k0 + kk) < kend;
-            rb[i] = okb ? B[(int64_t)(k0 + kk) * g.bk + (int64_t)(n0 + n) * g.bn] : 0.f;
+            ra[i] = (aoff[i] >= 0 && k0 + ak_[i] < kend) ? A[aoff[i] + ka] : 0.f;
+            rb[i] = (boff[i] >= 0 && k0 + bk_[i] < kend) ? B[boff[i] + kb] : 0.f;
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            int m, k;
-            if (g.a_kfast) { k = t & 31; m = (t >> 5) + 8 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
-            As[buf][k][m] = ra[i];
+            As[buf][ak_[i]][am_[i]] = ra[i];
             rs[i] += ra[i];
-            int n, kk;
-            if (g.b_nfast) { n = t & 63; kk = (t >> 6) + 4 * i; } else { kk = t & 31; n = (t >> 5) + 8 * i; }
-            Bs[buf][kk][n] = rb[i];
+            Bs[buf][bk_[i]][bn_[i]] = rb[i];
         }
     };
     int buf = 0;
