@@ -122,6 +122,7 @@ import os
 # Measured: the per-sample kernels are correct and cut the step's launches from 1 210 to 570, but their ~45 dependent
 # products per block run serially on one CU per sample - 11.5 vs 10.5 ms at B=64, equal at B=256 - so the composed block stays the default.
 FUSED_GAT_BLOCKS = os.environ.get('GATOR_TRAIN_FUSED_GAT', '0')
+FUSED_SELF_ATTENTION = os.environ.get('GATOR_TRAIN_FUSED_ATTN', '1') != '0'
 
 
 def gat_block(P, c, x, bias, i, gen, rates, training=True, p='pose_lifter.'):
@@ -250,10 +251,13 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
         vf = ops.layernorm(vf, g('norm%s.a_2' % sfx), g('norm%s.b_2' % sfx), 1e-6, 1)          # vanilla_transformer_encoder.py:31-34
         sa = 'selfatt%s.linears.' % sfx
         vf, res, xq, xk = ops.fork(vf, 4)
-        qq, kk, vv = [ops.reshape(ops.linear(t, g(sa + '%d.weight' % n), g(sa + '%d.bias' % n)), B, V, Hh, d).transpose(1, 2)
-                      for n, t in enumerate((vf, xq, xk))]
-        pa = ops.dropout(ops.softmax(ops.matmul(qq, kk.transpose(-2, -1), 1.0 / math.sqrt(d))), rates.mdr_self, gen, training)
-        xo = ops.contiguous(ops.matmul(pa, vv).transpose(1, 2)).reshape(B, V, E)
+        qq, kk, vv = [ops.linear(t, g(sa + '%d.weight' % n), g(sa + '%d.bias' % n)) for n, t in enumerate((vf, xq, xk))]     # [B,431,64]
+        if FUSED_SELF_ATTENTION:        # one launch forward / three backward, no [B,2,431,431] tensor (csrc/train_attn.inc)
+            xo = ops.attention(qq, kk, vv, Hh, 1.0 / math.sqrt(d), rates.mdr_self, gen, training)
+        else:                           # the same core composed from the primitives (the cross-check of tests/test_gpu_train_fused.py)
+            qh, kh, vh = [ops.reshape(t, B, V, Hh, d).transpose(1, 2) for t in (qq, kk, vv)]
+            pa = ops.dropout(ops.softmax(ops.matmul(qh, kh.transpose(-2, -1), 1.0 / math.sqrt(d))), rates.mdr_self, gen, training)
+            xo = ops.contiguous(ops.matmul(pa, vh).transpose(1, 2)).reshape(B, V, E)
         xo = ops.linear(xo, g(sa + '3.weight'), g(sa + '3.bias'))
         vf = ops.add(res, ops.dropout(xo, rates.mdr_self, gen, training))                       # MDR.py:143
     # MDR head (MDR.py:156-168)

@@ -62,3 +62,28 @@ def test_fused_block_gradients_match_composed(name, rates):
         a, b = res['fused'][0][s0:s1], res['composed'][0][s0:s1]
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-7, k
+
+
+@pytest.mark.parametrize('B,T,rate', [(3, 431, 0.0), (5, 431, 0.1), (2, 77, 0.3)])
+def test_fused_attention_matches_composed(B, T, rate):
+    """ops.attention (one launch forward, three backward, no [B,H,T,T] tensor) against softmax -> dropout -> matmul composed from the
+    primitives with the same generator state: output and dq, dk, dv."""
+    rs = np.random.RandomState(B * 1000 + T)
+    H, D = 2, 32
+    q, k, v = [torch.from_numpy(rs.randn(B, T, H * D).astype(np.float32)).cuda().requires_grad_(True) for _ in range(3)]
+    w = torch.from_numpy(rs.randn(B, T, H * D).astype(np.float32)).cuda()
+    scale = 1.0 / np.sqrt(D)
+
+    def composed(q, k, v, gen):
+        qq, kk, vv = [ops.reshape(t, B, T, H, D).transpose(1, 2) for t in (q, k, v)]
+        pa = ops.dropout(ops.softmax(ops.matmul(qq, kk.transpose(-2, -1), scale)), rate, gen, True)
+        return ops.contiguous(ops.matmul(pa, vv).transpose(1, 2)).reshape(B, T, H * D)
+
+    want = composed(q, k, v, ops.Generator(3))
+    gw = torch.autograd.grad(want, [q, k, v], grad_outputs=w)
+    got = ops.attention(q, k, v, H, scale, rate, ops.Generator(3), True)
+    gg = torch.autograd.grad(got, [q, k, v], grad_outputs=w)
+    for nm, a, b in [('o', got, want)] + [('d' + n, x, y) for n, x, y in zip('qkv', gg, gw)]:
+        err, sc = float((a - b).abs().max()), float(b.abs().max())
+        print('%s: max|fused - composed| %.2e (scale %.2e)' % (nm, err, sc))
+        assert err <= 2e-5 * sc, nm

@@ -61,9 +61,9 @@ def test_training_step_matches_reference_recording(name):
         err = np.abs(got - z['grad_f64'][i][:n]).max()
         # (the key bias of a softmax attention has an exactly-zero gradient: its noise floor is set by its weight's gradient)
         sibling = float(absmax.get(k[:-4] + 'weight', 0.0)) if k.endswith('.bias') else 0.0
-        tol = 4.0 * noise + 2e-5 * scale + 1e-6 * sibling + 1e-12
+        tol = 4.0 * noise + 2e-5 * scale + 3e-6 * sibling + 1e-12
         assert err <= tol, '%s: err %.3e tol %.3e (max|g| %.3e, ref fp32 noise %.3e)' % (k, err, tol, scale, noise)
-        assert abs(np.abs(g[a:b]).max() - scale) <= 4.0 * noise + 1e-4 * scale + 1e-6 * sibling + 1e-12, k
+        assert abs(np.abs(g[a:b]).max() - scale) <= 4.0 * noise + 1e-4 * scale + 3e-6 * sibling + 1e-12, k
         if scale > 1e-9 and err / scale > worst:
             worst, worst_k = err / scale, k
     print('[%s] %d parameter tensors; worst probe error / max|g| = %.2e (%s)' % (name, len(names), worst, worst_k))
@@ -87,7 +87,7 @@ def test_training_step_matches_oracle_autograd_other_batch():
         sib = ograds.get(k[:-4] + 'weight') if k.endswith('.bias') else None          # exactly-zero gradients: see above
         sibling = float(sib.abs().max()) if sib is not None else 0.0
         err = float((g[a:b].view(shape) - og).abs().max())
-        assert err <= 1e-4 * scale + 1e-6 * sibling + 1e-9, '%s: %.3e vs max|g| %.3e' % (k, err, scale)
+        assert err <= 1e-4 * scale + 3e-6 * sibling + 1e-9, '%s: %.3e vs max|g| %.3e' % (k, err, scale)
 
 
 def test_adam_matches_torch_and_weights_return_to_inference_kernels():
