@@ -236,11 +236,13 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
         fz = ops.layernorm(ops.cat([vf, jfs[li]], 1), g(e + 'norm1.weight'), g(e + 'norm1.bias'), 1e-5, 0)
         fq, fj = ops.split(fz, 1, (V, J))
         fk, fv = ops.fork(ops.contiguous(fj))
-        q = ops.reshape(ops.linear(fq, g(e + 'attn.wq.weight')), B, V, Hh, d).permute(0, 2, 1, 3)
-        k = ops.reshape(ops.linear(fk, g(e + 'attn.wk.weight')), B, J, Hh, d).permute(0, 2, 1, 3)
-        v = ops.reshape(ops.linear(fv, g(e + 'attn.wv.weight')), B, J, Hh, d).permute(0, 2, 1, 3)
-        att = ops.dropout(ops.softmax(ops.matmul(q, k.transpose(-2, -1), d ** -0.5)), rates.mdr_attn, gen, training)
-        o = ops.contiguous(ops.matmul(att, v).transpose(1, 2)).reshape(B, V, E)
+        q, k, v = ops.linear(fq, g(e + 'attn.wq.weight')), ops.linear(fk, g(e + 'attn.wk.weight')), ops.linear(fv, g(e + 'attn.wv.weight'))
+        if FUSED_SELF_ATTENTION:        # vertex queries on joint keys through the same fused core (Tk = J)
+            o = ops.attention(q, k, v, Hh, d ** -0.5, rates.mdr_attn, gen, training)
+        else:
+            qh, kh, vh = [ops.reshape(t, B, t.shape[1], Hh, d).permute(0, 2, 1, 3) for t in (q, k, v)]
+            att = ops.dropout(ops.softmax(ops.matmul(qh, kh.transpose(-2, -1), d ** -0.5)), rates.mdr_attn, gen, training)
+            o = ops.contiguous(ops.matmul(att, vh).transpose(1, 2)).reshape(B, V, E)
         o = ops.dropout(ops.linear(o, g(e + 'attn.proj.weight'), g(e + 'attn.proj.bias')), rates.mdr_drop, gen, training)
         vf = ops.add(res, ops.drop_path(o, rates.mdr_path, gen, training))                      # MDR.py:66
         vf, res = ops.fork(vf)

@@ -582,7 +582,7 @@ class _Attention(torch.autograd.Function):
         B, T, HD = q.shape
         o = torch.empty_like(q)
         lse = torch.empty((B, heads, T), device=q.device, dtype=torch.float32)
-        _call('gator_t_attn_fwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, heads, T, HD // heads, float(scale),
+        _call('gator_t_attn_fwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, heads, T, k.shape[1], HD // heads, float(scale),
               float(rate), ctypes.c_uint64(seed), ctypes.c_uint64(offset), counter, _stream(q))
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.cfg = (heads, scale, rate, seed, offset, counter)
@@ -594,16 +594,16 @@ class _Attention(torch.autograd.Function):
         heads, scale, rate, seed, offset, counter = ctx.cfg
         B, T, HD = q.shape
         gc = _contig(g)
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         dsum = torch.empty_like(lse)
         _call('gator_t_attn_bwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), gc.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-              dv.data_ptr(), dsum.data_ptr(), B, heads, T, HD // heads, float(scale), float(rate), ctypes.c_uint64(seed), ctypes.c_uint64(offset), counter,
+              dv.data_ptr(), dsum.data_ptr(), B, heads, T, k.shape[1], HD // heads, float(scale), float(rate), ctypes.c_uint64(seed), ctypes.c_uint64(offset), counter,
               _stream(q))
         return dq, dk, dv, None, None, None, None, None, None
 
 
 def attention(q, k, v, heads, scale, rate=0.0, gen=None, training=True):
-    """q, k, v [B, T, heads*32] -> [B, T, heads*32]"""
+    """q [B, T, heads*32], k, v [B, Tk, heads*32] -> [B, T, heads*32]"""
     on = training and rate > 0.0
     return _Attention.apply(q, k, v, int(heads), float(scale), float(rate) if on else 0.0, gen.seed if on else 0, gen.next_offset() if on else 0,
                             gen.counter_ptr() if on else None)

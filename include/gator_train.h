@@ -82,13 +82,14 @@ int gator_t_gat_block_fwd(const gator_gat_block* args, gator_stream stream);
 int gator_t_gat_block_bwd(const gator_gat_block* args, gator_stream stream);   /* dx, the nine dY, per-sample partials of the small gradients */
 
 /* Multi-head self-attention core with dropout on the probabilities (vanilla_transformer_encoder.py:36-46): o = dropout(softmax(scale q k^T)) v
- * for q, k, v, o of shape [B, T, H*D] (head h in columns D*h ..; D = 32), without materialising the [B,H,T,T] tensors; lse [B,H,T] is kept
+ * for q, o of shape [B, T, H*D] and k, v [B, Tk, H*D] (head h in columns D*h ..; D = 32; Tk = T: the 431-token self-attention, Tk = J: the
+ * cross-attention of vertex queries on joint keys, MDR.py:34-46), without materialising the [B,H,T,Tk] tensors; lse [B,H,T] is kept
  * for the backward, which recomputes the probabilities.  Masks: the Philox stream of gator_t_dropout at the flat index of a
- * contiguous [B,H,T,T] tensor (offset = 0 or rate = 0: no dropout).  dsum: scratch [B,H,T]. */
-int gator_t_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int H, int T, int D, float scale, float rate,
+ * contiguous [B,H,T,Tk] tensor (offset = 0 or rate = 0: no dropout).  dsum: scratch [B,H,T]. */
+int gator_t_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int H, int T, int Tk, int D, float scale, float rate,
                      uint64_t seed, uint64_t offset, const uint64_t* step_counter, gator_stream stream);
 int gator_t_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* lse, const float* d_o, float* dq, float* dk,
-                     float* dv, float* dsum, int B, int H, int T, int D, float scale, float rate, uint64_t seed, uint64_t offset,
+                     float* dv, float* dsum, int B, int H, int T, int Tk, int D, float scale, float rate, uint64_t seed, uint64_t offset,
                      const uint64_t* step_counter, gator_stream stream);
 
 /* rows of n contiguous floats.  mode 0: nn.LayerNorm (biased variance, eps inside the root); mode 1: the MDR LayerNorm

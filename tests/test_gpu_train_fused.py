@@ -64,18 +64,18 @@ def test_fused_block_gradients_match_composed(name, rates):
         assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-7, k
 
 
-@pytest.mark.parametrize('B,T,rate', [(3, 431, 0.0), (5, 431, 0.1), (2, 77, 0.3)])
-def test_fused_attention_matches_composed(B, T, rate):
+@pytest.mark.parametrize('B,T,Tk,rate', [(3, 431, 431, 0.0), (5, 431, 431, 0.1), (2, 77, 77, 0.3), (4, 431, 17, 0.2), (3, 431, 19, 0.0)])
+def test_fused_attention_matches_composed(B, T, Tk, rate):
     """ops.attention (one launch forward, three backward, no [B,H,T,T] tensor) against softmax -> dropout -> matmul composed from the
     primitives with the same generator state: output and dq, dk, dv."""
     rs = np.random.RandomState(B * 1000 + T)
     H, D = 2, 32
-    q, k, v = [torch.from_numpy(rs.randn(B, T, H * D).astype(np.float32)).cuda().requires_grad_(True) for _ in range(3)]
+    q, k, v = [torch.from_numpy(rs.randn(B, n, H * D).astype(np.float32)).cuda().requires_grad_(True) for n in (T, Tk, Tk)]
     w = torch.from_numpy(rs.randn(B, T, H * D).astype(np.float32)).cuda()
     scale = 1.0 / np.sqrt(D)
 
     def composed(q, k, v, gen):
-        qq, kk, vv = [ops.reshape(t, B, T, H, D).transpose(1, 2) for t in (q, k, v)]
+        qq, kk, vv = [ops.reshape(t, B, t.shape[1], H, D).transpose(1, 2) for t in (q, k, v)]
         pa = ops.dropout(ops.softmax(ops.matmul(qq, kk.transpose(-2, -1), scale)), rate, gen, True)
         return ops.contiguous(ops.matmul(pa, vv).transpose(1, 2)).reshape(B, T, H * D)
 
