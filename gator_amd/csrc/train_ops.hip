@@ -1082,6 +1082,34 @@ int gator_t_attn_bwd(const float* q, const float* k, const float* v, const float
     return check_launch("gator_t_attn_bwd");
 }
 
+static int attn_small_args(AttnSmallArgs& a, const float* qkv, const float* bias, float* o, float* P, int B, int H, int J, int D, float scale, float rate,
+                           uint64_t seed, uint64_t offset, const uint64_t* counter, const char* what) {
+    if (!qkv || !bias || !o || !P || B <= 0 || H <= 0 || J < 1 || J > 32) return fail(1, "%s: bad argument (J <= 32)", what);
+    if (D != kSD || rate < 0.f || rate >= 1.f) return fail(1, "%s: head dim %d (built for %d) / bad rate", what, D, kSD);
+    a.qkv = qkv; a.bias = bias; a.o = o; a.P = P; a.B = B; a.H = H; a.J = J; a.scale = scale;
+    a.seed = seed; a.off = offset; a.counter = reinterpret_cast<const unsigned long long*>(counter); a.rate = rate;
+    a.d_o = nullptr; a.dqkv = a.dS = nullptr;
+    return 0;
+}
+
+int gator_t_attn_small_fwd(const float* qkv, const float* bias, float* o, float* P, int B, int H, int J, int D, float scale, float rate, uint64_t seed,
+                           uint64_t offset, const uint64_t* counter, gator_stream stream) {
+    AttnSmallArgs a;
+    if (attn_small_args(a, qkv, bias, o, P, B, H, J, D, scale, rate, seed, offset, counter, "gator_t_attn_small_fwd")) return 1;
+    hipLaunchKernelGGL(k_t_attn_small_fwd, dim3((B * H + 3) / 4), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch("gator_t_attn_small_fwd");
+}
+
+int gator_t_attn_small_bwd(const float* qkv, const float* bias, const float* P, const float* d_o, float* dqkv, float* dS, int B, int H, int J, int D,
+                           float scale, float rate, uint64_t seed, uint64_t offset, const uint64_t* counter, gator_stream stream) {
+    AttnSmallArgs a;
+    if (attn_small_args(a, qkv, bias, dqkv, const_cast<float*>(P), B, H, J, D, scale, rate, seed, offset, counter, "gator_t_attn_small_bwd")) return 1;
+    if (!d_o || !dqkv || !dS) return fail(1, "gator_t_attn_small_bwd: null argument");
+    a.o = nullptr; a.d_o = d_o; a.dqkv = dqkv; a.dS = dS;
+    hipLaunchKernelGGL(k_t_attn_small_bwd, dim3((B * H + 3) / 4), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch("gator_t_attn_small_bwd");
+}
+
 static int gat_block_check(const gator_gat_block* a, const char* what) {
     static_assert(sizeof(gator_gat_block) == sizeof(GatBlkArgs), "gator_gat_block / GatBlkArgs layouts");
     if (!a || a->B <= 0 || a->J < 2 || a->J > 32) { fail(1, "%s: bad argument", what); return 1; }

@@ -135,11 +135,14 @@ def gat_block(P, c, x, bias, i, gen, rates, training=True, p='pose_lifter.'):
     y = ops.layernorm(x, g(b + 'norm1.weight'), g(b + 'norm1.bias'), 1e-5, 0)
     y, y0, y1 = ops.fork(y, 3)
     # Attention (modules.py:121-138)
-    qkv = ops.linear(y, g(b + 'attn.qkv.weight'), g(b + 'attn.qkv.bias')).reshape(B, J, 3, C)
-    q, k, v = [ops.reshape(t, B, J, H, C // H).permute(0, 2, 1, 3) for t in ops.split(qkv, 2, (1, 1, 1))]
-    att = ops.add(ops.matmul(q, k.transpose(-2, -1), scale), bias)
-    att = ops.dropout(ops.softmax(att), rates.gat_attn, gen, training)
-    a = ops.contiguous(ops.matmul(att, v).transpose(1, 2)).reshape(B, J, C)
+    qkv = ops.linear(y, g(b + 'attn.qkv.weight'), g(b + 'attn.qkv.bias'))
+    if FUSED_SELF_ATTENTION:            # one launch per direction, one wave per (sample, head) (csrc/train_attn.inc)
+        a = ops.attention_small(qkv, bias, H, scale, rates.gat_attn, gen, training)
+    else:
+        q, k, v = [ops.reshape(t, B, J, H, C // H).permute(0, 2, 1, 3) for t in ops.split(qkv.reshape(B, J, 3, C), 2, (1, 1, 1))]
+        att = ops.add(ops.matmul(q, k.transpose(-2, -1), scale), bias)
+        att = ops.dropout(ops.softmax(att), rates.gat_attn, gen, training)
+        a = ops.contiguous(ops.matmul(att, v).transpose(1, 2)).reshape(B, J, C)
     a = ops.dropout(ops.linear(a, g(b + 'attn.proj.weight'), g(b + 'attn.proj.bias')), rates.gat_proj, gen, training)
     # MGCN (modules.py:243-255)
     W0, W1 = ops.split(g(b + 'gcn.W'), 0, (1, 1))

@@ -609,6 +609,44 @@ def attention(q, k, v, heads, scale, rate=0.0, gen=None, training=True):
                             gen.counter_ptr() if on else None)
 
 
+class _AttentionSmall(torch.autograd.Function):
+    """The GAT encoder's attention (gator_t_attn_small_fwd / _bwd): qkv [B,J,3*H*16] and the additive bias [H,J,J] -> [B,J,H*16]."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, heads, scale, rate, seed, offset, counter):
+        _need_device(qkv, bias)
+        qkv, bias = _contig(qkv), _contig(bias)
+        B, J, C3 = qkv.shape
+        C = C3 // 3
+        o = torch.empty((B, J, C), device=qkv.device, dtype=torch.float32)
+        P = torch.empty((B, heads, J, J), device=qkv.device, dtype=torch.float32)
+        _call('gator_t_attn_small_fwd', qkv.data_ptr(), bias.data_ptr(), o.data_ptr(), P.data_ptr(), B, heads, J, C // heads, float(scale), float(rate),
+              ctypes.c_uint64(seed), ctypes.c_uint64(offset), counter, _stream(qkv))
+        ctx.save_for_backward(qkv, bias, P)
+        ctx.cfg = (heads, scale, rate, seed, offset, counter)
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, bias, P = ctx.saved_tensors
+        heads, scale, rate, seed, offset, counter = ctx.cfg
+        B, J, C3 = qkv.shape
+        gc = _contig(g)
+        dqkv = torch.empty_like(qkv)
+        dS = torch.empty_like(P)
+        _call('gator_t_attn_small_bwd', qkv.data_ptr(), bias.data_ptr(), P.data_ptr(), gc.data_ptr(), dqkv.data_ptr(), dS.data_ptr(), B, heads, J,
+              C3 // 3 // heads, float(scale), float(rate), ctypes.c_uint64(seed), ctypes.c_uint64(offset), counter, _stream(qkv))
+        dbias = raw_sum(dS, [0]) if ctx.needs_input_grad[1] else None
+        return dqkv, dbias, None, None, None, None, None, None
+
+
+def attention_small(qkv, bias, heads, scale, rate=0.0, gen=None, training=True):
+    """qkv [B,J,3*heads*16] (the GAT in-projection's output), bias [heads,J,J] -> attention output [B,J,heads*16]"""
+    on = training and rate > 0.0
+    return _AttentionSmall.apply(qkv, bias, int(heads), float(scale), float(rate) if on else 0.0, gen.seed if on else 0, gen.next_offset() if on else 0,
+                                 gen.counter_ptr() if on else None)
+
+
 class _Contig(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

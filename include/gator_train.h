@@ -92,6 +92,14 @@ int gator_t_attn_bwd(const float* q, const float* k, const float* v, const float
                      float* dv, float* dsum, int B, int H, int T, int Tk, int D, float scale, float rate, uint64_t seed, uint64_t offset,
                      const uint64_t* step_counter, gator_stream stream);
 
+/* The GAT encoder's attention over J <= 32 joint tokens (modules.py:121-138): o = dropout(softmax(scale q k^T + bias)) v with q, k, v taken
+ * from the in-projection's output qkv [B,J,3,H,D] (D = 16), bias [H,J,J]; o [B,J,H*D] head-major; P [B,H,J,J] kept for the backward, which
+ * writes dqkv (layout of qkv) and dS [B,H,J,J] (its sum over the batch is the gradient of the bias).  One wave per (sample, head). */
+int gator_t_attn_small_fwd(const float* qkv, const float* bias, float* o, float* P, int B, int H, int J, int D, float scale, float rate,
+                           uint64_t seed, uint64_t offset, const uint64_t* step_counter, gator_stream stream);
+int gator_t_attn_small_bwd(const float* qkv, const float* bias, const float* P, const float* d_o, float* dqkv, float* dS, int B, int H, int J, int D,
+                           float scale, float rate, uint64_t seed, uint64_t offset, const uint64_t* step_counter, gator_stream stream);
+
 /* rows of n contiguous floats.  mode 0: nn.LayerNorm (biased variance, eps inside the root); mode 1: the MDR LayerNorm
  * (lib/models/vanilla_transformer_encoder.py:31-34: unbiased std, eps added to the std).  w, b may be NULL (no affine).
  * forward saves mean[rows] and rinv[rows] (1/sqrt(var+eps) resp. 1/(std+eps)); backward writes dx and, if dy_xhat != NULL,

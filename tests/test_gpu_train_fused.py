@@ -87,3 +87,28 @@ def test_fused_attention_matches_composed(B, T, Tk, rate):
         err, sc = float((a - b).abs().max()), float(b.abs().max())
         print('%s: max|fused - composed| %.2e (scale %.2e)' % (nm, err, sc))
         assert err <= 2e-5 * sc, nm
+
+
+@pytest.mark.parametrize('J,rate', [(17, 0.0), (19, 0.4)])
+def test_small_attention_matches_composed(J, rate):
+    """ops.attention_small (GAT encoder attention, one wave per (sample, head)) against matmul -> +bias -> softmax -> dropout -> matmul."""
+    rs = np.random.RandomState(J)
+    B, H, D = 7, 8, 16
+    C = H * D
+    qkv = torch.from_numpy(rs.randn(B, J, 3 * C).astype(np.float32)).cuda().requires_grad_(True)
+    bias = torch.from_numpy(rs.randn(H, J, J).astype(np.float32)).cuda().requires_grad_(True)
+    w = torch.from_numpy(rs.randn(B, J, C).astype(np.float32)).cuda()
+
+    def composed(qkv, bias, gen):
+        q, k, v = [ops.reshape(t, B, J, H, D).permute(0, 2, 1, 3) for t in ops.split(qkv.reshape(B, J, 3, C), 2, (1, 1, 1))]
+        att = ops.dropout(ops.softmax(ops.add(ops.matmul(q, k.transpose(-2, -1), 0.25), bias)), rate, gen, True)
+        return ops.contiguous(ops.matmul(att, v).transpose(1, 2)).reshape(B, J, C)
+
+    want = composed(qkv, bias, ops.Generator(9))
+    gw = torch.autograd.grad(want, [qkv, bias], grad_outputs=w)
+    got = ops.attention_small(qkv, bias, H, 0.25, rate, ops.Generator(9), True)
+    gg = torch.autograd.grad(got, [qkv, bias], grad_outputs=w)
+    for nm, a, b in (('o', got, want), ('dqkv', gg[0], gw[0]), ('dbias', gg[1], gw[1])):
+        err, sc = float((a - b).abs().max()), float(b.abs().max())
+        print('%s: max|fused - composed| %.2e (scale %.2e)' % (nm, err, sc))
+        assert err <= 2e-5 * sc, nm
