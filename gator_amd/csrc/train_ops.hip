@@ -1110,6 +1110,26 @@ int gator_t_attn_small_bwd(const float* qkv, const float* bias, const float* P, 
     return check_launch("gator_t_attn_small_bwd");
 }
 
+int gator_t_mgcn_fwd(const float* h0, const float* h1, const float* adj, const float* M, const float* bias, float* out, int B, int J, int C,
+                     gator_stream stream) {
+    if (!h0 || !h1 || !adj || !M || !bias || !out || B <= 0 || J <= 0 || C <= 0) return fail(1, "gator_t_mgcn_fwd: bad argument");
+    MgcnArgs a;
+    a.h0 = h0; a.h1 = h1; a.adj = adj; a.M = M; a.bias = bias; a.out = out; a.B = B; a.J = J; a.C = C;
+    a.d_out = nullptr; a.dh0 = a.dh1 = a.pm = a.dadj = nullptr;
+    hipLaunchKernelGGL(k_t_mgcn_fwd, dim3(B, (J * C + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch("gator_t_mgcn_fwd");
+}
+
+int gator_t_mgcn_bwd(const float* h0, const float* h1, const float* adj, const float* M, const float* d_out, float* dh0, float* dh1, float* pm,
+                     float* dadj, int B, int J, int C, gator_stream stream) {
+    if (!h0 || !h1 || !adj || !M || !d_out || !dh0 || !dh1 || !pm || !dadj || B <= 0 || J <= 0 || C <= 0) return fail(1, "gator_t_mgcn_bwd: bad argument");
+    MgcnArgs a;
+    a.h0 = h0; a.h1 = h1; a.adj = adj; a.M = M; a.bias = nullptr; a.out = nullptr; a.B = B; a.J = J; a.C = C;
+    a.d_out = d_out; a.dh0 = dh0; a.dh1 = dh1; a.pm = pm; a.dadj = dadj;
+    hipLaunchKernelGGL(k_t_mgcn_bwd, dim3(B, (J * C + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch("gator_t_mgcn_bwd");
+}
+
 static int gat_block_check(const gator_gat_block* a, const char* what) {
     static_assert(sizeof(gator_gat_block) == sizeof(GatBlkArgs), "gator_gat_block / GatBlkArgs layouts");
     if (!a || a->B <= 0 || a->J < 2 || a->J > 32) { fail(1, "%s: bad argument", what); return 1; }

@@ -122,6 +122,8 @@ import os
 # Measured: the per-sample kernels are correct and cut the step's launches from 1 210 to 570, but their ~45 dependent
 # products per block run serially on one CU per sample - 11.5 vs 10.5 ms at B=64, equal at B=256 - so the composed block stays the default.
 FUSED_GAT_BLOCKS = os.environ.get('GATOR_TRAIN_FUSED_GAT', '0')
+# GATOR_TRAIN_FUSED_ATTN=0: attention cores and the MGCN aggregation composed from the primitives (the cross-check form) instead of
+# their one-launch kernels
 FUSED_SELF_ATTENTION = os.environ.get('GATOR_TRAIN_FUSED_ATTN', '1') != '0'
 
 
@@ -148,10 +150,13 @@ def gat_block(P, c, x, bias, i, gen, rates, training=True, p='pose_lifter.'):
     W0, W1 = ops.split(g(b + 'gcn.W'), 0, (1, 1))
     h0 = ops.matmul(y0, W0.reshape(C, C))
     h1 = ops.matmul(y1, W1.reshape(C, C))
-    adj_d, adj_o = ops.fork(sym_adjacency(c, g(b + 'gcn.adj2')))
-    M0, M1 = ops.fork(g(b + 'gcn.M'))
-    gout = ops.add(ops.add(ops.matmul(ops.mul(adj_d, c.E), ops.mul(M0, h0)), ops.matmul(ops.mul(adj_o, c.notE), ops.mul(M1, h1))),
-                   g(b + 'gcn.bias').reshape(1, 1, -1))
+    if FUSED_SELF_ATTENTION:            # diag / off-diagonal aggregation, modulation and bias in one launch per direction
+        gout = ops.mgcn(h0, h1, sym_adjacency(c, g(b + 'gcn.adj2')), g(b + 'gcn.M'), g(b + 'gcn.bias'))
+    else:
+        adj_d, adj_o = ops.fork(sym_adjacency(c, g(b + 'gcn.adj2')))
+        M0, M1 = ops.fork(g(b + 'gcn.M'))
+        gout = ops.add(ops.add(ops.matmul(ops.mul(adj_d, c.E), ops.mul(M0, h0)), ops.matmul(ops.mul(adj_o, c.notE), ops.mul(M1, h1))),
+                       g(b + 'gcn.bias').reshape(1, 1, -1))
     s = ops.drop_path(ops.add(a, gout), rates.gat_path[i], gen, training)
     # X_Feat (modules.py:158-177)
     s0, s1 = ops.fork(s)

@@ -647,6 +647,47 @@ def attention_small(qkv, bias, heads, scale, rate=0.0, gen=None, training=True):
                                  gen.counter_ptr() if on else None)
 
 
+class _Mgcn(torch.autograd.Function):
+    """gator_t_mgcn_fwd / _bwd: (h0, h1 [B,J,C], adj [J,J], M [J,C], bias [C]) -> [B,J,C]"""
+
+    @staticmethod
+    def forward(ctx, h0, h1, adj, M, bias):
+        _need_device(h0, h1, adj, M, bias)
+        h0, h1, adj, Mc, bc = _contig(h0), _contig(h1), _contig(adj), _contig(M), _contig(bias)
+        B, J, C = h0.shape
+        out = torch.empty_like(h0)
+        _call('gator_t_mgcn_fwd', h0.data_ptr(), h1.data_ptr(), adj.data_ptr(), Mc.data_ptr(), bc.data_ptr(), out.data_ptr(), B, J, C, _stream(h0))
+        ctx.save_for_backward(h0, h1, adj, Mc)
+        ctx.mslot, ctx.bslot = grad_slot(M), grad_slot(bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h0, h1, adj, M = ctx.saved_tensors
+        B, J, C = h0.shape
+        gc = _contig(g)
+        dh0, dh1, pm = torch.empty_like(h0), torch.empty_like(h0), torch.empty_like(h0)
+        dadj = torch.empty((B, J, J), device=g.device, dtype=torch.float32)
+        _call('gator_t_mgcn_bwd', h0.data_ptr(), h1.data_ptr(), adj.data_ptr(), M.data_ptr(), gc.data_ptr(), dh0.data_ptr(), dh1.data_ptr(), pm.data_ptr(),
+              dadj.data_ptr(), B, J, C, _stream(g))
+        ones = lambda n: _one(g.device).as_strided((1, 1, 1, n), (0, 0, 0, 0))
+        if Deferred.enabled and ctx.mslot is not None:
+            Deferred.add(ones(B), pm.view(1, 1, B, J * C), ctx.mslot.view(1, 1, 1, J * C), None)
+            gM = ctx.mslot
+        else:
+            gM = raw_sum(pm, [0])
+        if Deferred.enabled and ctx.bslot is not None:
+            Deferred.add(ones(B * J), gc.view(1, 1, B * J, C), ctx.bslot.view(1, 1, 1, C), None)
+            gb = ctx.bslot
+        else:
+            gb = raw_sum(gc.reshape(B * J, C), [0])
+        return dh0, dh1, raw_sum(dadj, [0]), gM, gb
+
+
+def mgcn(h0, h1, adj, M, bias):
+    return _Mgcn.apply(h0, h1, adj, M, bias)
+
+
 class _Contig(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

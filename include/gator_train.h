@@ -100,6 +100,14 @@ int gator_t_attn_small_fwd(const float* qkv, const float* bias, float* o, float*
 int gator_t_attn_small_bwd(const float* qkv, const float* bias, const float* P, const float* d_o, float* dqkv, float* dS, int B, int H, int J, int D,
                            float scale, float rate, uint64_t seed, uint64_t offset, const uint64_t* step_counter, gator_stream stream);
 
+/* MGCN (modules.py:243-255) after its two products h0 = x W[0], h1 = x W[1]: out = diag(adj) (M . h0) + offdiag(adj) @ (M . h1) + bias with the
+ * symmetrised adjacency adj [J,J]; the backward writes d h0, d h1, the per-sample partials pm [B,J,C] (their sum over B is d M) and
+ * dadj [B,J,J] (sum over B: d adj); d bias = column sums of d_out. */
+int gator_t_mgcn_fwd(const float* h0, const float* h1, const float* adj, const float* M, const float* bias, float* out, int B, int J, int C,
+                     gator_stream stream);
+int gator_t_mgcn_bwd(const float* h0, const float* h1, const float* adj, const float* M, const float* d_out, float* dh0, float* dh1, float* pm,
+                     float* dadj, int B, int J, int C, gator_stream stream);
+
 /* rows of n contiguous floats.  mode 0: nn.LayerNorm (biased variance, eps inside the root); mode 1: the MDR LayerNorm
  * (lib/models/vanilla_transformer_encoder.py:31-34: unbiased std, eps added to the std).  w, b may be NULL (no affine).
  * forward saves mean[rows] and rinv[rows] (1/sqrt(var+eps) resp. 1/(std+eps)); backward writes dx and, if dy_xhat != NULL,

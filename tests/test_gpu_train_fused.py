@@ -112,3 +112,26 @@ def test_small_attention_matches_composed(J, rate):
         err, sc = float((a - b).abs().max()), float(b.abs().max())
         print('%s: max|fused - composed| %.2e (scale %.2e)' % (nm, err, sc))
         assert err <= 2e-5 * sc, nm
+
+
+def test_fused_mgcn_matches_composed():
+    rs = np.random.RandomState(4)
+    B, J, C = 6, 19, 128
+    t = lambda *s: torch.from_numpy(rs.randn(*s).astype(np.float32)).cuda().requires_grad_(True)
+    h0, h1, adj, Mm, bias = t(B, J, C), t(B, J, C), t(J, J), t(J, C), t(C)
+    w = torch.from_numpy(rs.randn(B, J, C).astype(np.float32)).cuda()
+    E = torch.eye(J, device='cuda')
+
+    def composed(h0, h1, adj, Mm, bias):
+        a1, a2 = ops.fork(adj)
+        m1, m2 = ops.fork(Mm)
+        return ops.add(ops.add(ops.matmul(ops.mul(a1, E), ops.mul(m1, h0)), ops.matmul(ops.mul(a2, 1.0 - E), ops.mul(m2, h1))), bias.reshape(1, 1, -1))
+
+    want = composed(h0, h1, adj, Mm, bias)
+    gw = torch.autograd.grad(want, [h0, h1, adj, Mm, bias], grad_outputs=w)
+    got = ops.mgcn(h0, h1, adj, Mm, bias)
+    gg = torch.autograd.grad(got, [h0, h1, adj, Mm, bias], grad_outputs=w)
+    for nm, a, b in [('out', got, want)] + list(zip(('dh0', 'dh1', 'dadj', 'dM', 'dbias'), gg, gw)):
+        err, sc = float((a - b).abs().max()), float(b.abs().max())
+        print('%s: max|fused - composed| %.2e (scale %.2e)' % (nm, err, sc))
+        assert err <= 2e-5 * sc, nm
