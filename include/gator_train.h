@@ -121,7 +121,7 @@ int gator_t_layernorm_bwd(const float* dy, const float* x, const float* mean, co
 int gator_t_softmax_fwd(const float* x, int64_t rows, int n, float* p, gator_stream stream);
 int gator_t_softmax_bwd(const float* p, const float* dp, int64_t rows, int n, float* dx, gator_stream stream);
 
-/* dropout: keep[i] = philox4x32-10(seed, offset'; i) >= rate * 2^32; out = x * keep / (1 - rate); mask (uint8) is stored for
+/* dropout: keep[i] = philox4x32-7(seed, offset'; i) >= rate * 2^32; out = x * keep / (1 - rate); mask (uint8) is stored for
  * gator_t_mask_scale (the backward: out = x * mask * scale).  x == NULL writes the scaled mask itself (DropPath's per-sample factor).
  * offset' = offset + 2^32 * step_counter[0] when step_counter (a DEVICE uint64) is given: a step captured in a hipGraph draws new
  * masks on every replay.  gator_t_step_advance adds one to the counter (launch it once per step, inside the graph). */
