@@ -79,7 +79,7 @@ SIGNATURES = {
     'gator_t_gemm_grouped_prepare': (_L, [_P, _I]),
     'gator_t_gemm_grouped': (_I, [_P, _I, _P, _P, _P]),
     'gator_t_attn_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
-    'gator_t_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
+    'gator_t_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _I, _P]),
     'gator_t_attn_small_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
     'gator_t_attn_small_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
     'gator_t_mgcn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

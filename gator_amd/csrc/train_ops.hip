@@ -1063,7 +1063,7 @@ static int attn_args(AttnArgs& a, const float* q, const float* k, const float* v
     a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse;
     a.B = B; a.H = H; a.T = T; a.Tk = Tk; a.scale = scale;
     a.seed = seed; a.off = offset; a.counter = reinterpret_cast<const unsigned long long*>(counter); a.rate = rate;
-    a.d_o = nullptr; a.dq = a.dk = a.dv = a.dsum = nullptr;
+    a.d_o = nullptr; a.dq = a.dk = a.dv = a.dsum = nullptr; a.qsplit = 1;
     return 0;
 }
 
@@ -1077,16 +1077,17 @@ int gator_t_attn_fwd(const float* q, const float* k, const float* v, float* o, f
 
 int gator_t_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* lse, const float* d_o, float* dq, float* dk,
                      float* dv, float* dsum, int B, int H, int T, int Tk, int D, float scale, float rate, uint64_t seed, uint64_t offset,
-                     const uint64_t* counter, gator_stream stream) {
+                     const uint64_t* counter, int qsplit, gator_stream stream) {
     AttnArgs a;
     if (attn_args(a, q, k, v, const_cast<float*>(o), const_cast<float*>(lse), B, H, T, Tk, D, scale, rate, seed, offset, counter, "gator_t_attn_bwd")) return 1;
     if (!d_o || !dq || !dk || !dv || !dsum) return fail(1, "gator_t_attn_bwd: null argument");
     a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv; a.dsum = dsum;
+    a.qsplit = qsplit < 1 ? 1 : qsplit;
     hipStream_t st = (hipStream_t)stream;
     const int64_t rows = (int64_t)B * H * T;
     hipLaunchKernelGGL(k_t_attn_rowdot, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, a);
     hipLaunchKernelGGL(k_t_attn_bwd_dq, dim3((T + 127) / 128, B * H), dim3(kThreads), 0, st, a);
-    hipLaunchKernelGGL(k_t_attn_bwd_dkv, dim3((Tk + 127) / 128, B * H), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(k_t_attn_bwd_dkv, dim3((Tk + 127) / 128, B * H, a.qsplit), dim3(kThreads), 0, st, a);
     return check_launch("gator_t_attn_bwd");
 }
 

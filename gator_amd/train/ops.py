@@ -594,11 +594,20 @@ class _Attention(torch.autograd.Function):
         heads, scale, rate, seed, offset, counter = ctx.cfg
         B, T, HD = q.shape
         gc = _contig(g)
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        Tk = k.shape[1]
+        # few keys, many queries (the cross-attention): the key-owning waves would walk all query tiles alone - deal the tiles out
+        qsplit = min((T + 31) // 32, 16) if Tk <= 128 and T >= 4 * Tk else 1
+        dq = torch.empty_like(q)
+        dk = torch.empty((qsplit,) + tuple(k.shape), device=q.device, dtype=torch.float32)
+        dv = torch.empty((qsplit,) + tuple(v.shape), device=q.device, dtype=torch.float32)
         dsum = torch.empty_like(lse)
         _call('gator_t_attn_bwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), gc.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-              dv.data_ptr(), dsum.data_ptr(), B, heads, T, k.shape[1], HD // heads, float(scale), float(rate), ctypes.c_uint64(seed), ctypes.c_uint64(offset), counter,
-              _stream(q))
+              dv.data_ptr(), dsum.data_ptr(), B, heads, T, Tk, HD // heads, float(scale), float(rate), ctypes.c_uint64(seed), ctypes.c_uint64(offset), counter,
+              qsplit, _stream(q))
+        if qsplit > 1:
+            dk, dv = raw_sum(dk.view(qsplit, -1), [0]).view(k.shape), raw_sum(dv.view(qsplit, -1), [0]).view(v.shape)
+        else:
+            dk, dv = dk[0], dv[0]
         return dq, dk, dv, None, None, None, None, None, None
 
 

@@ -85,12 +85,13 @@ int gator_t_gat_block_bwd(const gator_gat_block* args, gator_stream stream);   /
  * for q, o of shape [B, T, H*D] and k, v [B, Tk, H*D] (head h in columns D*h ..; D = 32; Tk = T: the 431-token self-attention, Tk = J: the
  * cross-attention of vertex queries on joint keys, MDR.py:34-46), without materialising the [B,H,T,Tk] tensors; lse [B,H,T] is kept
  * for the backward, which recomputes the probabilities.  Masks: the Philox stream of gator_t_dropout at the flat index of a
- * contiguous [B,H,T,Tk] tensor (offset = 0 or rate = 0: no dropout).  dsum: scratch [B,H,T]. */
+ * contiguous [B,H,T,Tk] tensor (offset = 0 or rate = 0: no dropout).  dsum: scratch [B,H,T].  qsplit > 1 (few keys, many queries): dk / dv
+ * are [qsplit][B,Tk,H*D] partial sums over interleaved query tiles, to be added up by the caller. */
 int gator_t_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int H, int T, int Tk, int D, float scale, float rate,
                      uint64_t seed, uint64_t offset, const uint64_t* step_counter, gator_stream stream);
 int gator_t_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* lse, const float* d_o, float* dq, float* dk,
                      float* dv, float* dsum, int B, int H, int T, int Tk, int D, float scale, float rate, uint64_t seed, uint64_t offset,
-                     const uint64_t* step_counter, gator_stream stream);
+                     const uint64_t* step_counter, int qsplit, gator_stream stream);
 
 /* The GAT encoder's attention over J <= 32 joint tokens (modules.py:121-138): o = dropout(softmax(scale q k^T + bias)) v with q, k, v taken
  * from the in-projection's output qkv [B,J,3,H,D] (D = 16), bias [H,J,J]; o [B,J,H*D] head-major; P [B,H,J,J] kept for the backward, which
