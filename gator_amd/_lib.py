@@ -92,6 +92,8 @@ SIGNATURES = {
     'gator_t_softmax_bwd': (_I, [_P, _P, _L, _I, _P, _P]),
     'gator_t_dropout': (_I, [_P, _L, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P, _P, _P]),
     'gator_t_step_advance': (_I, [_P, _P]),
+    'gator_t_drop_fused': (_I, [_P, _P, _L, _L, _I, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_float, ctypes.c_uint64, _P, _P, _P, _P, _P]),
+    'gator_t_drop_fused_bwd': (_I, [_P, _P, _P, _P, _L, _L, _I, ctypes.c_float, _P, _P]),
     'gator_t_mask_scale': (_I, [_P, _P, _L, ctypes.c_float, _P, _P]),
     'gator_t_adam': (_I, [_P, _P, _P, _P, _L, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P, _P]),
     'gator_t_loss_ws_bytes': (_L, [_L, _L]),

@@ -622,6 +622,15 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2])
     k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
 }
 
+__device__ __forceinline__ bool philox_keep_raw(uint64_t seed, uint64_t offset, int64_t idx, uint32_t thresh) {
+    const int64_t q = idx >> 2;
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < GATOR_PHILOX_ROUNDS; ++r) philox_round(c, k);
+    return c[idx & 3] >= thresh;
+}
+
 __global__ __launch_bounds__(kThreads) void k_t_dropout(const float* __restrict__ x, int64_t n, uint32_t thresh, float scale, uint64_t seed,
                                                         uint64_t offset, const uint64_t* __restrict__ step_counter, float* __restrict__ out,
                                                         uint8_t* __restrict__ mask) {
@@ -640,6 +649,61 @@ __global__ __launch_bounds__(kThreads) void k_t_dropout(const float* __restrict_
             mask[i] = keep;
             out[i] = keep ? (x ? x[i] : 1.f) * scale : 0.f;
         }
+    }
+}
+
+// out = res + path[b] * dropout(act(x)): act = identity or GELU, dropout / DropPath / residual optional.  The stored byte mask carries the
+// element's keep decision; `fac` [B] the per-sample DropPath factor (0 or 1/(1-p)).  One launch for what the composed form does in up to 5.
+__global__ __launch_bounds__(kThreads) void k_t_drop_fused(const float* __restrict__ x, const float* __restrict__ res, int64_t n, int64_t per_sample,
+                                                           int gelu, uint32_t thresh, float scale, int drop_on, uint64_t seed, uint64_t offset,
+                                                           uint32_t pthresh, float pscale, int path_on, uint64_t poffset,
+                                                           const uint64_t* __restrict__ step_counter, float* __restrict__ out, uint8_t* __restrict__ mask,
+                                                           float* __restrict__ fac) {
+    const int64_t q = blockIdx.x * (int64_t)kThreads + threadIdx.x;
+    if (q * 4 >= n) return;
+    const uint64_t hi = step_counter ? (step_counter[0] << 32) : 0ull;
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)(offset + hi), (uint32_t)((offset + hi) >> 32)};
+    if (drop_on) {
+        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+        for (int r = 0; r < GATOR_PHILOX_ROUNDS; ++r) philox_round(c, k);
+    }
+    int64_t sb = -1;
+    float f = 1.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = q * 4 + j;
+        if (i >= n) break;
+        float v = x[i];
+        if (gelu) v = unary_apply(1, v, 0.f, 0.f);
+        if (drop_on) {
+            const uint8_t keep = c[j] >= thresh ? 1 : 0;
+            mask[i] = keep;
+            v = keep ? v * scale : 0.f;
+        }
+        if (path_on) {
+            const int64_t b = i / per_sample;
+            if (b != sb) {                              // (one generator call per thread unless its quad straddles two samples)
+                sb = b;
+                f = philox_keep_raw(seed, poffset + hi, b, pthresh) ? pscale : 0.f;
+            }
+            if (i == b * per_sample) fac[b] = f;
+            v *= f;
+        }
+        out[i] = res ? res[i] + v : v;
+    }
+}
+
+// its backward: dx = g * path[b] * mask * scale (* gelu'(x))
+__global__ __launch_bounds__(kThreads) void k_t_drop_fused_bwd(const float* __restrict__ g, const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                               const float* __restrict__ fac, int64_t n, int64_t per_sample, int gelu, float scale,
+                                                               float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        float v = g[i];
+        if (fac) v *= fac[i / per_sample];
+        if (mask) v = mask[i] ? v * scale : 0.f;
+        if (gelu) v *= unary_apply(2, x[i], 0.f, 0.f);
+        out[i] = v;
     }
 }
 
@@ -1035,6 +1099,33 @@ int gator_t_dropout(const float* x, int64_t n, float rate, uint64_t seed, uint64
     hipLaunchKernelGGL(k_t_dropout, dim3((unsigned)((quads + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream, x, n, thresh,
                        1.0f / (1.0f - rate), seed, offset, step_counter, out, mask);
     return check_launch("gator_t_dropout");
+}
+
+static uint32_t rate_thresh(float rate) {
+    const double t = (double)rate * 4294967296.0;
+    return t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+}
+
+int gator_t_drop_fused(const float* x, const float* res, int64_t n, int64_t per_sample, int gelu, float rate, uint64_t seed, uint64_t offset,
+                       float path_rate, uint64_t path_offset, const uint64_t* step_counter, float* out, uint8_t* mask, float* path_factor,
+                       gator_stream stream) {
+    const bool drop_on = rate > 0.f && offset != 0, path_on = path_rate > 0.f && path_offset != 0;
+    if (!x || !out || n <= 0 || per_sample <= 0 || rate < 0.f || rate >= 1.f || path_rate < 0.f || path_rate >= 1.f || (drop_on && !mask) ||
+        (path_on && !path_factor))
+        return fail(1, "gator_t_drop_fused: bad argument");
+    const int64_t quads = (n + 3) / 4;
+    hipLaunchKernelGGL(k_t_drop_fused, dim3((unsigned)((quads + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream, x, res, n, per_sample, gelu,
+                       rate_thresh(rate), 1.0f / (1.0f - rate), drop_on ? 1 : 0, seed, offset, rate_thresh(path_rate), 1.0f / (1.0f - path_rate),
+                       path_on ? 1 : 0, path_offset, step_counter, out, mask, path_factor);
+    return check_launch("gator_t_drop_fused");
+}
+
+int gator_t_drop_fused_bwd(const float* g, const float* x, const uint8_t* mask, const float* path_factor, int64_t n, int64_t per_sample, int gelu,
+                           float rate, float* out, gator_stream stream) {
+    if (!g || !out || n <= 0 || per_sample <= 0 || (gelu && !x)) return fail(1, "gator_t_drop_fused_bwd: bad argument");
+    hipLaunchKernelGGL(k_t_drop_fused_bwd, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, g, x, mask, path_factor, n, per_sample, gelu,
+                       1.0f / (1.0f - rate), out);
+    return check_launch("gator_t_drop_fused_bwd");
 }
 
 int gator_t_mask_scale(const float* x, const uint8_t* mask, int64_t n, float scale, float* out, gator_stream stream) {

@@ -167,6 +167,9 @@ def gat_block(P, c, x, bias, i, gen, rates, training=True, p='pose_lifter.'):
     # MLP (modules.py:188-196)
     x, res = ops.fork(x)
     y2 = ops.layernorm(x, g(b + 'norm2.weight'), g(b + 'norm2.bias'), 1e-5, 0)
+    if FUSED_SELF_ATTENTION:            # GELU + dropout, and dropout + DropPath + residual, one launch each
+        hdn = ops.drop_fused(ops.linear(y2, g(b + 'mlp.fc1.weight'), g(b + 'mlp.fc1.bias')), None, True, rates.gat_mlp, 0.0, gen, training)
+        return ops.drop_fused(ops.linear(hdn, g(b + 'mlp.fc2.weight'), g(b + 'mlp.fc2.bias')), res, False, rates.gat_mlp, rates.gat_path[i], gen, training)
     hdn = ops.dropout(ops.gelu(ops.linear(y2, g(b + 'mlp.fc1.weight'), g(b + 'mlp.fc1.bias'))), rates.gat_mlp, gen, training)
     m = ops.dropout(ops.linear(hdn, g(b + 'mlp.fc2.weight'), g(b + 'mlp.fc2.bias')), rates.gat_mlp, gen, training)
     return ops.add(res, ops.drop_path(m, rates.gat_path[i], gen, training))
@@ -251,13 +254,20 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
             qh, kh, vh = [ops.reshape(t, B, t.shape[1], Hh, d).permute(0, 2, 1, 3) for t in (q, k, v)]
             att = ops.dropout(ops.softmax(ops.matmul(qh, kh.transpose(-2, -1), d ** -0.5)), rates.mdr_attn, gen, training)
             o = ops.contiguous(ops.matmul(att, vh).transpose(1, 2)).reshape(B, V, E)
-        o = ops.dropout(ops.linear(o, g(e + 'attn.proj.weight'), g(e + 'attn.proj.bias')), rates.mdr_drop, gen, training)
-        vf = ops.add(res, ops.drop_path(o, rates.mdr_path, gen, training))                      # MDR.py:66
+        o = ops.linear(o, g(e + 'attn.proj.weight'), g(e + 'attn.proj.bias'))
+        if FUSED_SELF_ATTENTION:
+            vf = ops.drop_fused(o, res, False, rates.mdr_drop, rates.mdr_path, gen, training)           # MDR.py:66
+        else:
+            vf = ops.add(res, ops.drop_path(ops.dropout(o, rates.mdr_drop, gen, training), rates.mdr_path, gen, training))
         vf, res = ops.fork(vf)
         y = ops.layernorm(vf, g(e + 'norm2.weight'), g(e + 'norm2.bias'), 1e-5, 0)
-        h = ops.dropout(ops.gelu(ops.linear(y, g(e + 'mlp.fc1.weight'), g(e + 'mlp.fc1.bias'))), rates.mdr_drop, gen, training)   # timm Mlp
-        h = ops.dropout(ops.linear(h, g(e + 'mlp.fc2.weight'), g(e + 'mlp.fc2.bias')), rates.mdr_drop, gen, training)
-        vf = ops.add(res, ops.drop_path(h, rates.mdr_path, gen, training))
+        if FUSED_SELF_ATTENTION:                                                                         # timm Mlp
+            h = ops.drop_fused(ops.linear(y, g(e + 'mlp.fc1.weight'), g(e + 'mlp.fc1.bias')), None, True, rates.mdr_drop, 0.0, gen, training)
+            vf = ops.drop_fused(ops.linear(h, g(e + 'mlp.fc2.weight'), g(e + 'mlp.fc2.bias')), res, False, rates.mdr_drop, rates.mdr_path, gen, training)
+        else:
+            h = ops.dropout(ops.gelu(ops.linear(y, g(e + 'mlp.fc1.weight'), g(e + 'mlp.fc1.bias'))), rates.mdr_drop, gen, training)
+            h = ops.dropout(ops.linear(h, g(e + 'mlp.fc2.weight'), g(e + 'mlp.fc2.bias')), rates.mdr_drop, gen, training)
+            vf = ops.add(res, ops.drop_path(h, rates.mdr_path, gen, training))
         vf = ops.layernorm(vf, g('norm%s.a_2' % sfx), g('norm%s.b_2' % sfx), 1e-6, 1)          # vanilla_transformer_encoder.py:31-34
         sa = 'selfatt%s.linears.' % sfx
         vf, res, xq, xk = ops.fork(vf, 4)
@@ -269,7 +279,8 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
             pa = ops.dropout(ops.softmax(ops.matmul(qh, kh.transpose(-2, -1), 1.0 / math.sqrt(d))), rates.mdr_self, gen, training)
             xo = ops.contiguous(ops.matmul(pa, vh).transpose(1, 2)).reshape(B, V, E)
         xo = ops.linear(xo, g(sa + '3.weight'), g(sa + '3.bias'))
-        vf = ops.add(res, ops.dropout(xo, rates.mdr_self, gen, training))                       # MDR.py:143
+        vf = ops.drop_fused(xo, res, False, rates.mdr_self, 0.0, gen, training) if FUSED_SELF_ATTENTION else \
+            ops.add(res, ops.dropout(xo, rates.mdr_self, gen, training))                         # MDR.py:143
     # MDR head (MDR.py:156-168)
     va, vb, vs = ops.fork(vf, 3)
     ac = ops.linear(va, g('motion_linear.weight'), g('motion_linear.bias'))

@@ -697,6 +697,51 @@ def mgcn(h0, h1, adj, M, bias):
     return _Mgcn.apply(h0, h1, adj, M, bias)
 
 
+class _DropFused(torch.autograd.Function):
+    """out = res + DropPath(dropout(act(x))) in one launch per direction (gator_t_drop_fused): the tail of every residual branch."""
+
+    @staticmethod
+    def forward(ctx, x, res, gelu, rate, seed, offset, path_rate, path_offset, counter):
+        _need_device(x, res)
+        xc = _contig(x)
+        rc = _contig(res) if res is not None else None
+        n, per = xc.numel(), xc.numel() // xc.shape[0]
+        out = torch.empty_like(xc)
+        mask = torch.empty(xc.shape, device=x.device, dtype=torch.uint8) if (rate > 0 and offset) else None
+        fac = torch.empty(xc.shape[0], device=x.device, dtype=torch.float32) if (path_rate > 0 and path_offset) else None
+        _call('gator_t_drop_fused', xc.data_ptr(), rc.data_ptr() if rc is not None else None, n, per, int(gelu), float(rate), ctypes.c_uint64(seed),
+              ctypes.c_uint64(offset), float(path_rate), ctypes.c_uint64(path_offset), counter, out.data_ptr(), mask.data_ptr() if mask is not None else None,
+              fac.data_ptr() if fac is not None else None, _stream(x))
+        ctx.save_for_backward(xc if gelu else None, mask, fac)
+        ctx.cfg = (gelu, rate, res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mask, fac = ctx.saved_tensors
+        gelu, rate, has_res = ctx.cfg
+        gc = _contig(g)
+        if not gelu and mask is None and fac is None:
+            dx = gc
+        else:
+            dx = torch.empty_like(gc)
+            _call('gator_t_drop_fused_bwd', gc.data_ptr(), x.data_ptr() if x is not None else None, mask.data_ptr() if mask is not None else None,
+                  fac.data_ptr() if fac is not None else None, gc.numel(), gc.numel() // gc.shape[0], int(gelu), float(rate), dx.data_ptr(), _stream(gc))
+        return dx, (gc if has_res else None), None, None, None, None, None, None, None
+
+
+def drop_fused(x, res=None, gelu=False, rate=0.0, path_rate=0.0, gen=None, training=True):
+    """res + drop_path(dropout(gelu?(x), rate), path_rate) - offsets drawn in that order, as the composed chain draws them."""
+    d_on = training and rate > 0.0
+    p_on = training and path_rate > 0.0
+    off = gen.next_offset() if d_on else 0
+    poff = gen.next_offset() if p_on else 0
+    if not gelu and not d_on and not p_on:
+        return x if res is None else add(res, x)
+    return _DropFused.apply(x, res, bool(gelu), float(rate) if d_on else 0.0, gen.seed if (d_on or p_on) else 0, off, float(path_rate) if p_on else 0.0, poff,
+                            gen.counter_ptr() if (d_on or p_on) else None)
+
+
 class _Contig(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

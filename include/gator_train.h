@@ -131,6 +131,15 @@ int gator_t_dropout(const float* x, int64_t n, float rate, uint64_t seed, uint64
 int gator_t_step_advance(uint64_t* step_counter, gator_stream stream);
 int gator_t_mask_scale(const float* x, const uint8_t* mask, int64_t n, float scale, float* out, gator_stream stream);
 
+/* out = res + path[b] * dropout(act(x)) in one launch: act = GELU when gelu != 0; dropout as gator_t_dropout (rate / offset, same masks);
+ * DropPath as gator_t_dropout(x = NULL) over the B = n / per_sample samples (path_rate / path_offset; factor kept in path_factor [B]);
+ * res may be NULL; a rate of 0 or an offset of 0 switches that stage off.  _bwd: dx = g * path[b] * mask / (1 - rate) (* gelu'(x)). */
+int gator_t_drop_fused(const float* x, const float* res, int64_t n, int64_t per_sample, int gelu, float rate, uint64_t seed, uint64_t offset,
+                       float path_rate, uint64_t path_offset, const uint64_t* step_counter, float* out, uint8_t* mask, float* path_factor,
+                       gator_stream stream);
+int gator_t_drop_fused_bwd(const float* g, const float* x, const uint8_t* mask, const float* path_factor, int64_t n, int64_t per_sample, int gelu,
+                           float rate, float* out, gator_stream stream);
+
 /* torch.optim.Adam (lib/funcs_utils.py:91-95: lr only, betas 0.9/0.999, eps 1e-8, no weight decay) on one flat buffer */
 int gator_t_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
                  double beta2, double eps, int step, const uint64_t* step_counter /* device; overrides `step` when given */,

@@ -135,3 +135,25 @@ def test_fused_mgcn_matches_composed():
         err, sc = float((a - b).abs().max()), float(b.abs().max())
         print('%s: max|fused - composed| %.2e (scale %.2e)' % (nm, err, sc))
         assert err <= 2e-5 * sc, nm
+
+
+@pytest.mark.parametrize('gelu,rate,path,with_res', [(True, 0.1, 0.0, False), (False, 0.2, 0.2, True), (False, 0.0, 0.3, True), (True, 0.0, 0.0, False)])
+def test_drop_fused_matches_composed(gelu, rate, path, with_res):
+    rs = np.random.RandomState(8)
+    x = torch.from_numpy(rs.randn(9, 19, 128).astype(np.float32)).cuda().requires_grad_(True)
+    res = torch.from_numpy(rs.randn(9, 19, 128).astype(np.float32)).cuda().requires_grad_(True) if with_res else None
+    w = torch.from_numpy(rs.randn(9, 19, 128).astype(np.float32)).cuda()
+
+    def composed(gen):
+        v = ops.gelu(x) if gelu else x
+        v = ops.drop_path(ops.dropout(v, rate, gen, True), path, gen, True)
+        return ops.add(res, v) if with_res else v
+
+    want = composed(ops.Generator(2))
+    got = ops.drop_fused(x, res, gelu, rate, path, ops.Generator(2), True)
+    ins = [x] + ([res] if with_res else [])
+    gw = torch.autograd.grad(want, ins, grad_outputs=w)
+    gg = torch.autograd.grad(got, ins, grad_outputs=w)
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    for a, b in zip(gg, gw):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
