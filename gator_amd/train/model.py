@@ -100,7 +100,10 @@ def conv1d_k3(x, w, b):
     """F.conv1d(x [B,C,3], w [O,C,3], b, padding=1) -> [B,O,3]"""
     B, C, _ = x.shape
     u = _Unfold3.apply(x).reshape(B, 3, C * 3)
-    y = ops.linear(u, w.reshape(w.shape[0], C * 3), b)               # [B,3,O]
+    wr = w.reshape(w.shape[0], C * 3)
+    if ops.grad_slot(w) is not None:
+        wr._gslot = ops.grad_slot(w).reshape(w.shape[0], C * 3)      # the view keeps its slice of the flat gradient buffer
+    y = ops.linear(u, wr, b)                                         # [B,3,O]
     return y.transpose(1, 2)
 
 
@@ -147,9 +150,8 @@ def gat_block(P, c, x, bias, i, gen, rates, training=True, p='pose_lifter.'):
         a = ops.contiguous(ops.matmul(att, v).transpose(1, 2)).reshape(B, J, C)
     a = ops.dropout(ops.linear(a, g(b + 'attn.proj.weight'), g(b + 'attn.proj.bias')), rates.gat_proj, gen, training)
     # MGCN (modules.py:243-255)
-    W0, W1 = ops.split(g(b + 'gcn.W'), 0, (1, 1))
-    h0 = ops.matmul(y0, W0.reshape(C, C))
-    h1 = ops.matmul(y1, W1.reshape(C, C))
+    h0 = ops.xw(y0, g(b + 'gcn.W'), 0)
+    h1 = ops.xw(y1, g(b + 'gcn.W'), 1)
     if FUSED_SELF_ATTENTION:            # diag / off-diagonal aggregation, modulation and bias in one launch per direction
         gout = ops.mgcn(h0, h1, sym_adjacency(c, g(b + 'gcn.adj2')), g(b + 'gcn.M'), g(b + 'gcn.bias'))
     else:

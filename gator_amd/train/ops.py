@@ -427,6 +427,45 @@ def linear(x, w, b=None):
     return _Linear.apply(x, w, b)
 
 
+class _XW(torch.autograd.Function):
+    """x @ W[k] for a stacked weight W [n, C_in, C_out] (MGCN's `torch.matmul(input, self.W[k])`, modules.py:244-245).  The weight
+    gradient x^T dY lands in W's slice of the flat gradient buffer through the grouped launch (no split / copy chain).  A model
+    that uses W must use its slice 0 (the slot is reported to autograd by that use)."""
+
+    @staticmethod
+    def forward(ctx, x, W, k):
+        _need_device(x, W)
+        x2 = _contig(x).reshape(1, 1, -1, x.shape[-1])
+        wk = W.narrow(0, k, 1).reshape(1, 1, W.shape[1], W.shape[2])
+        ctx.save_for_backward(x2, wk)
+        ctx.xshape, ctx.k, ctx.wshape = x.shape, k, W.shape
+        sl = grad_slot(W)
+        ctx.wslot = sl.narrow(0, k, 1).view(1, 1, W.shape[1], W.shape[2]) if sl is not None else None
+        ctx.full = sl
+        return raw_gemm(x2, wk).reshape(list(x.shape[:-1]) + [W.shape[2]])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, wk = ctx.saved_tensors
+        g2 = _contig(g).reshape(1, 1, -1, g.shape[-1])
+        gx = raw_gemm(g2, wk.transpose(2, 3)).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        gW = None
+        if ctx.needs_input_grad[1]:
+            if Deferred.enabled and ctx.wslot is not None:
+                Deferred.add(x2.transpose(2, 3), g2, ctx.wslot, None)
+                # every slice writes into the SAME slot tensor: hand it to autograd once (slice 0), or the engine would add the
+                # tensor to itself for each further use of W
+                gW = ctx.full if ctx.k == 0 else None
+            else:
+                gW = zeros(ctx.wshape, g.device)
+                raw_gemm(x2.transpose(2, 3), g2, out=gW.narrow(0, ctx.k, 1).view(1, 1, ctx.wshape[1], ctx.wshape[2]))
+        return gx, gW, None
+
+
+def xw(x, W, k):
+    return _XW.apply(x, W, int(k))
+
+
 class _Softmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
