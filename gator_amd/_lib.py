@@ -87,7 +87,8 @@ SIGNATURES = {
     'gator_t_gat_block_fwd': (_I, [_P, _P]),
     'gator_t_gat_block_bwd': (_I, [_P, _P]),
     'gator_t_layernorm_fwd': (_I, [_P, _L, _I, _P, _P, ctypes.c_float, _I, _P, _P, _P, _P]),
-    'gator_t_layernorm_bwd': (_I, [_P, _P, _P, _P, _P, _L, _I, ctypes.c_float, _I, _P, _P, _P]),
+    'gator_t_layernorm_bwd': (_I, [_P, _P, _P, _P, _P, _L, _I, ctypes.c_float, _I, _P, _P, _P, _P]),
+    'gator_t_add_n': (_I, [_P, _P, _P, _P, _P, _L, _P]),
     'gator_t_softmax_fwd': (_I, [_P, _L, _I, _P, _P]),
     'gator_t_softmax_bwd': (_I, [_P, _P, _L, _I, _P, _P]),
     'gator_t_dropout': (_I, [_P, _L, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P, _P, _P]),

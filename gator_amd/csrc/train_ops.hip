@@ -81,6 +81,17 @@ __global__ __launch_bounds__(kThreads) void k_t_binary_flat(int op, const float*
     }
 }
 
+// out = a + b (+ c) (+ d) on dense tensors of one shape, summed left to right: the gradient of a value with several consumers
+__global__ __launch_bounds__(kThreads) void k_t_add_n(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                      const float* __restrict__ d, float* __restrict__ o, int64_t total) {
+    for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        float v = a[i] + b[i];
+        if (c) v += c[i];
+        if (d) v += d[i];
+        o[i] = v;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void k_t_binary32(int op, const float* __restrict__ a, Str4 sa, const float* __restrict__ b, Str4 sb,
                                                          float* __restrict__ o, Str4 so, Idx4 n, uint32_t total) {
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < total; i += gridDim.x * kThreads) {
@@ -552,7 +563,8 @@ __global__ __launch_bounds__(kThreads) void k_t_ln_fwd(const float* __restrict__
 
 __global__ __launch_bounds__(kThreads) void k_t_ln_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ rinv, const float* __restrict__ w, int64_t rows, int n,
-                                                       float eps, int mode, float* __restrict__ dx, float* __restrict__ dyx) {
+                                                       float eps, int mode, float* __restrict__ dx, float* __restrict__ dyx,
+                                                       const float* __restrict__ add) {
     const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(kThreads) void k_t_ln_bwd(const float* __restrict__
         const float m2 = t2 / n;
         for (int i = lane; i < n; i += 64) {
             const float xh = (xr[i] - mu) * ri, g = dr[i] * (w ? w[i] : 1.f);
-            dx[row * n + i] = ri * (g - m1 - xh * m2);
+            dx[row * n + i] = ri * (g - m1 - xh * m2) + (add ? add[row * n + i] : 0.f);
             if (dyx) dyx[row * n + i] = dr[i] * xh;
         }
     } else {
@@ -579,7 +591,7 @@ __global__ __launch_bounds__(kThreads) void k_t_ln_bwd(const float* __restrict__
         const float c2 = sigma > 0.f ? dsig / ((n - 1) * sigma) : 0.f;
         for (int i = lane; i < n; i += 64) {
             const float xc = xr[i] - mu, g = dr[i] * (w ? w[i] : 1.f);
-            dx[row * n + i] = ri * (g - m1) + c2 * xc;
+            dx[row * n + i] = ri * (g - m1) + c2 * xc + (add ? add[row * n + i] : 0.f);
             if (dyx) dyx[row * n + i] = dr[i] * xc * ri;
         }
     }
@@ -929,6 +941,13 @@ int gator_t_binary(int op, const float* a, const int64_t* sa, const float* b, co
     return check_launch("gator_t_binary");
 }
 
+int gator_t_add_n(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n, gator_stream stream) {
+    if (!a || !b || !out || (d && !c)) return fail(1, "gator_t_add_n: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_t_add_n, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, a, b, c, d, out, n);
+    return check_launch("gator_t_add_n");
+}
+
 int gator_t_unary(int op, const float* x, const int64_t* sx, float* out, const int64_t* so, const int64_t* shape, float p0, float p1,
                   gator_stream stream) {
     if (!x || !out || op < 0 || op > 11) return fail(1, "gator_t_unary: bad argument");
@@ -1061,11 +1080,11 @@ int gator_t_layernorm_fwd(const float* x, int64_t rows, int n, const float* w, c
 }
 
 int gator_t_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rinv, const float* w, int64_t rows, int n, float eps,
-                          int mode, float* dx, float* dy_xhat, gator_stream stream) {
+                          int mode, float* dx, float* dy_xhat, const float* add, gator_stream stream) {
     if (!dy || !x || !mean || !rinv || !dx) return fail(1, "gator_t_layernorm_bwd: null argument");
     if (rows == 0) return 0;
     hipLaunchKernelGGL(k_t_ln_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, dy, x, mean, rinv, w, rows, n, eps, mode, dx,
-                       dy_xhat);
+                       dy_xhat, add);
     return check_launch("gator_t_layernorm_bwd");
 }
 

@@ -136,8 +136,7 @@ def gat_block(P, c, x, bias, i, gen, rates, training=True, p='pose_lifter.'):
     B, J, H, C = x.shape[0], c.J, NUM_HEADS, EMBED
     scale = (C // H) ** -0.5
     b = 'blocks.%d.' % i
-    x, res = ops.fork(x)
-    y = ops.layernorm(x, g(b + 'norm1.weight'), g(b + 'norm1.bias'), 1e-5, 0)
+    y, res = ops.layernorm_skip(x, g(b + 'norm1.weight'), g(b + 'norm1.bias'), 1e-5, 0)
     y, y0, y1 = ops.fork(y, 3)
     # Attention (modules.py:121-138)
     qkv = ops.linear(y, g(b + 'attn.qkv.weight'), g(b + 'attn.qkv.bias'))
@@ -167,8 +166,7 @@ def gat_block(P, c, x, bias, i, gen, rates, training=True, p='pose_lifter.'):
     xf = ops.linear(ops.cat([f0, f1], 2), g(b + 'x_feat.linearback.weight'), g(b + 'x_feat.linearback.bias'))
     x = ops.add(res, xf)
     # MLP (modules.py:188-196)
-    x, res = ops.fork(x)
-    y2 = ops.layernorm(x, g(b + 'norm2.weight'), g(b + 'norm2.bias'), 1e-5, 0)
+    y2, res = ops.layernorm_skip(x, g(b + 'norm2.weight'), g(b + 'norm2.bias'), 1e-5, 0)
     if FUSED_SELF_ATTENTION:            # GELU + dropout, and dropout + DropPath + residual, one launch each
         hdn = ops.drop_fused(ops.linear(y2, g(b + 'mlp.fc1.weight'), g(b + 'mlp.fc1.bias')), None, True, rates.gat_mlp, 0.0, gen, training)
         return ops.drop_fused(ops.linear(hdn, g(b + 'mlp.fc2.weight'), g(b + 'mlp.fc2.bias')), res, False, rates.gat_mlp, rates.gat_path[i], gen, training)
@@ -261,8 +259,7 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
             vf = ops.drop_fused(o, res, False, rates.mdr_drop, rates.mdr_path, gen, training)           # MDR.py:66
         else:
             vf = ops.add(res, ops.drop_path(ops.dropout(o, rates.mdr_drop, gen, training), rates.mdr_path, gen, training))
-        vf, res = ops.fork(vf)
-        y = ops.layernorm(vf, g(e + 'norm2.weight'), g(e + 'norm2.bias'), 1e-5, 0)
+        y, res = ops.layernorm_skip(vf, g(e + 'norm2.weight'), g(e + 'norm2.bias'), 1e-5, 0)
         if FUSED_SELF_ATTENTION:                                                                         # timm Mlp
             h = ops.drop_fused(ops.linear(y, g(e + 'mlp.fc1.weight'), g(e + 'mlp.fc1.bias')), None, True, rates.mdr_drop, 0.0, gen, training)
             vf = ops.drop_fused(ops.linear(h, g(e + 'mlp.fc2.weight'), g(e + 'mlp.fc2.bias')), res, False, rates.mdr_drop, rates.mdr_path, gen, training)

@@ -493,8 +493,11 @@ def softmax(x):
 
 
 class _LayerNorm(torch.autograd.Function):
+    """y = LN(x) and, with residual=True, a second output that IS x (the skip connection): the backward then forms
+    d x = LN-backward(d y) + d skip in the LayerNorm kernel itself instead of a fork + add launch."""
+
     @staticmethod
-    def forward(ctx, x, w, b, eps, mode):
+    def forward(ctx, x, w, b, eps, mode, residual=False):
         _need_device(x, w, b)
         xc = _contig(x)
         n = xc.shape[-1]
@@ -507,19 +510,26 @@ class _LayerNorm(torch.autograd.Function):
         ctx.save_for_backward(xc, mean, rinv, w)
         ctx.eps, ctx.mode, ctx.has_b = eps, mode, b is not None
         ctx.wslot, ctx.bslot = grad_slot(w) if w is not None else None, grad_slot(b) if b is not None else None
+        ctx.residual = residual
+        if residual:
+            ctx.set_materialize_grads(False)
+            return y, xc.view_as(xc)
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, gres=None):
         xc, mean, rinv, w = ctx.saved_tensors
+        if g is None:                                      # only the skip connection carried a gradient
+            return (gres, None, None, None, None, None)
         gc = _contig(g)
+        add = _contig(gres) if gres is not None else None
         n = xc.shape[-1]
         rows = xc.numel() // n
         dx = torch.empty_like(xc)
         need_w = w is not None and ctx.needs_input_grad[1]
         dyx = torch.empty_like(xc) if need_w else None
         _call('gator_t_layernorm_bwd', gc.data_ptr(), xc.data_ptr(), mean.data_ptr(), rinv.data_ptr(), w.data_ptr() if w is not None else None, rows, n,
-              float(ctx.eps), int(ctx.mode), dx.data_ptr(), dyx.data_ptr() if need_w else None, _stream(xc))
+              float(ctx.eps), int(ctx.mode), dx.data_ptr(), dyx.data_ptr() if need_w else None, add.data_ptr() if add is not None else None, _stream(xc))
         gw = gb = None
         grouped = Deferred.enabled
         ones = _one(xc.device).as_strided((1, 1, 1, rows), (0, 0, 0, 0)) if grouped else None      # column sums as 1 x rows products
@@ -535,12 +545,17 @@ class _LayerNorm(torch.autograd.Function):
                 gb = ctx.bslot
             else:
                 gb = raw_sum(gc.reshape(rows, n), [0], keepdim=True, out=ctx.bslot.view(1, n) if ctx.bslot is not None else None).reshape(n)
-        return dx, gw, gb, None, None
+        return dx, gw, gb, None, None, None
 
 
 def layernorm(x, w=None, b=None, eps=1e-5, mode=0):
     """mode 0: nn.LayerNorm over the last dim; mode 1: lib/models/vanilla_transformer_encoder.py:31-34 (unbiased std, eps on the std)."""
     return _LayerNorm.apply(x, w, b, float(eps), int(mode))
+
+
+def layernorm_skip(x, w=None, b=None, eps=1e-5, mode=0):
+    """(LN(x), x): the pre-norm residual pattern `res = x; y = norm(x)` with the two gradients of x summed inside the LayerNorm backward"""
+    return _LayerNorm.apply(x, w, b, float(eps), int(mode), True)
 
 
 class Generator:
@@ -913,8 +928,17 @@ class _Fork(torch.autograd.Function):
     def backward(ctx, *gs):
         gs = [g for g in gs if g is not None]
         acc = gs[0]
-        for g in gs[1:]:
-            acc = raw_binary(ADD, acc, g)
+        rest = gs[1:]
+        while rest:                                      # up to four gradients per launch, summed left to right
+            take, rest = rest[:3], rest[3:]
+            if all(t.is_contiguous() and t.shape == acc.shape for t in take) and acc.is_contiguous():
+                out = torch.empty_like(acc)
+                ptr = [t.data_ptr() for t in take] + [None] * (3 - len(take))
+                _call('gator_t_add_n', acc.data_ptr(), ptr[0], ptr[1], ptr[2], out.data_ptr(), acc.numel(), _stream(acc))
+                acc = out
+            else:
+                for t in take:
+                    acc = raw_binary(ADD, acc, t)
         return acc, None
 
 

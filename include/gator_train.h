@@ -19,6 +19,9 @@ typedef void* gator_stream;   /* hipStream_t */
 int gator_t_binary(int op, const float* a, const int64_t* stride_a, const float* b, const int64_t* stride_b, float* out,
                    const int64_t* stride_out, const int64_t* shape4, gator_stream stream);
 
+/* out = a + b (+ c) (+ d), dense tensors of n elements: the gradient of a value with several consumers in one launch */
+int gator_t_add_n(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n, gator_stream stream);
+
 /* elementwise: out = f(x; p0, p1).  op: 0 p0*x+p1, 1 gelu (erf form, torch F.gelu), 2 d gelu/dx, 3 exp, 4 rsqrt, 5 sqrt, 6 1/x,
  * 7 |x|, 8 sign, 9 p0**x, 10 x*x, 11 (x > p0 ? 1 : 0) */
 int gator_t_unary(int op, const float* x, const int64_t* stride_x, float* out, const int64_t* stride_out, const int64_t* shape4,
@@ -116,7 +119,8 @@ int gator_t_mgcn_bwd(const float* h0, const float* h1, const float* adj, const f
 int gator_t_layernorm_fwd(const float* x, int64_t rows, int n, const float* w, const float* b, float eps, int mode, float* y,
                           float* mean, float* rinv, gator_stream stream);
 int gator_t_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rinv, const float* w, int64_t rows,
-                          int n, float eps, int mode, float* dx, float* dy_xhat, gator_stream stream);
+                          int n, float eps, int mode, float* dx, float* dy_xhat, const float* add /* dx += add (the residual branch), or NULL */,
+                          gator_stream stream);
 
 /* softmax over rows of n contiguous floats, and its backward dx = p * (dp - sum(dp * p)) */
 int gator_t_softmax_fwd(const float* x, int64_t rows, int n, float* p, gator_stream stream);
