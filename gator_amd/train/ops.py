@@ -156,6 +156,7 @@ class Deferred:
     ~70 small products that fill the chip together instead of ~230 latency-bound launches on the critical path."""
     enabled = True
     queue = []
+    retired = []
     pool = None        # pinned host memory for the problem tables of CAPTURED steps (a replayed graph re-reads its table); allocated
     pool_used = 0      # outside any capture (page-locking is not capturable) and carved up without reuse
 
@@ -171,8 +172,10 @@ class Deferred:
         n = len(q)
         nbytes = n * ctypes.sizeof(_lib.GemmProblem)
         capturing = torch.cuda.is_current_stream_capturing()
-        if Deferred.pool is None and not capturing:
-            Deferred.pool = torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True)
+        if not capturing and (Deferred.pool is None or Deferred.pool_used + (64 << 10) > Deferred.pool.numel()):
+            if Deferred.pool is not None:
+                Deferred.retired.append(Deferred.pool)     # captured graphs still read their tables from it
+            Deferred.pool, Deferred.pool_used = torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True), 0
         if capturing:
             if Deferred.pool is None or Deferred.pool_used + nbytes > Deferred.pool.numel():
                 raise RuntimeError('gator_amd.train: run one eager step before capturing (pinned table pool) / pool exhausted')
