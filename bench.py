@@ -88,6 +88,7 @@ def launch_ranks(a):
     the GPU, and nothing is exec'd over a GPU-touched process), relay its output, return its exit code."""
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault('NCCL_DEBUG', 'WARN')                   # no version banner on stdout (the result line must be the last one)
     env.setdefault('OMP_NUM_THREADS', '8')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -240,6 +241,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        os.environ.setdefault('NCCL_DEBUG', 'WARN')        # keep RCCL's version banner off stdout (also when the driver launches the ranks)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # backend "nccl" == RCCL on ROCm
     from gator_amd import synthetic
     from gator_amd.parallel import ShardedForward
@@ -353,10 +355,21 @@ def main():
             line['subbatch_streams_2'] = {'value': round(B * a.steps / d2, 1), 'ms_per_step': round(d2 / a.steps * 1e3, 4)}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(model, base, alpha, J)
-        print(json.dumps(line), flush=True)
+        result = json.dumps(line)
+    else:
+        result = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if result is not None:
+        # RCCL writes its version banner to C stdio, which is flushed at exit - AFTER a Python print.  Flush it first so that the
+        # result is the LAST line on stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(result, flush=True)
 
 
 if __name__ == '__main__':
