@@ -22,7 +22,7 @@ class GemmProblem(ctypes.Structure):            # include/gator_train.h: gator_g
                 ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('ksplit', ctypes.c_int32),
                 ('stride_a', ctypes.c_int64 * 2), ('stride_b', ctypes.c_int64 * 2), ('stride_c', ctypes.c_int64 * 2),
                 ('alpha', ctypes.c_float), ('accumulate', ctypes.c_int32), ('wg_begin', ctypes.c_int32), ('fin_begin', ctypes.c_int32),
-                ('ws_off', ctypes.c_int64), ('total_wgs', ctypes.c_int32), ('total_fin', ctypes.c_int32)]
+                ('ws_off', ctypes.c_int64), ('total_wgs', ctypes.c_int32), ('total_fin', ctypes.c_int32), ('bias', ctypes.c_void_p)]
 
 
 class GatBlock(ctypes.Structure):               # include/gator_train.h: gator_gat_block

@@ -441,6 +441,7 @@ struct GroupedProblem {
     int wg_begin, fin_begin;           // first workgroup of this problem in the product launch / in the finish launch
     int64_t ws_off;                    // floats into the shared split-K workspace
     int total_wgs, total_fin;          // (entry 0: launch sizes; keeps the layout of gator_gemm_problem)
+    const float* bias;                 // optional [N], added to every row (forward linears run as a group)
 };
 
 __device__ __forceinline__ int find_problem(const GroupedProblem* __restrict__ tab, int n, int wg, bool fin) {
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(kThreads) void k_t_gemm_grouped(const GroupedProble
     const GroupedProblem p = tab[pi];
     const int local = blockIdx.x - p.wg_begin, tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64);
     GemmArgs g;
-    g.A = p.A; g.B = p.B; g.bias = nullptr;
+    g.A = p.A; g.B = p.B; g.bias = p.bias;
     g.M = p.M; g.N = p.N; g.K = p.K; g.nb2 = 1; g.ksplit = p.ksplit;
     g.am = p.am; g.ak = p.ak; g.bk = p.bk; g.bn = p.bn;
     g.a1 = g.a2 = g.b1 = g.b2 = g.c1 = g.c2 = 0;
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(kThreads) void k_t_splitk_finish_grouped(const Grou
     const GroupedProblem p = tab[pi];
     if (p.ksplit <= 1) return;                                   // (problems without split-K own no finish workgroups; defensive)
     const float* w = ws + p.ws_off;
-    splitk_finish_block(sh, blockIdx.x - p.fin_begin, w, p.ksplit, p.M, p.N, p.C, p.cm, p.cn, nullptr, p.alpha, p.accumulate,
+    splitk_finish_block(sh, blockIdx.x - p.fin_begin, w, p.ksplit, p.M, p.N, p.C, p.cm, p.cn, p.bias, p.alpha, p.accumulate,
                         p.rowsum ? w + (int64_t)p.ksplit * p.M * p.N : nullptr, p.rowsum);
 }
 

@@ -161,8 +161,9 @@ def gat_block(P, c, x, bias, i, gen, rates, training=True, p='pose_lifter.'):
     s = ops.drop_path(ops.add(a, gout), rates.gat_path[i], gen, training)
     # X_Feat (modules.py:158-177)
     s0, s1 = ops.fork(s)
-    f0 = ops.matmul(c.m1, ops.linear(s0, g(b + 'x_feat.linears.0.weight'), g(b + 'x_feat.linears.0.bias')))
-    f1 = ops.matmul(c.m2, ops.linear(s1, g(b + 'x_feat.linears.1.weight'), g(b + 'x_feat.linears.1.bias')))
+    l0, l1 = ops.linear_group([(s0, g(b + 'x_feat.linears.0.weight'), g(b + 'x_feat.linears.0.bias')),
+                               (s1, g(b + 'x_feat.linears.1.weight'), g(b + 'x_feat.linears.1.bias'))])
+    f0, f1 = ops.matmul(c.m1, l0), ops.matmul(c.m2, l1)
     xf = ops.linear(ops.cat([f0, f1], 2), g(b + 'x_feat.linearback.weight'), g(b + 'x_feat.linearback.bias'))
     x = ops.add(res, xf)
     # MLP (modules.py:188-196)
@@ -247,7 +248,7 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
         fz = ops.layernorm(ops.cat([vf, jfs[li]], 1), g(e + 'norm1.weight'), g(e + 'norm1.bias'), 1e-5, 0)
         fq, fj = ops.split(fz, 1, (V, J))
         fk, fv = ops.fork(ops.contiguous(fj))
-        q, k, v = ops.linear(fq, g(e + 'attn.wq.weight')), ops.linear(fk, g(e + 'attn.wk.weight')), ops.linear(fv, g(e + 'attn.wv.weight'))
+        q, k, v = ops.linear_group([(fq, g(e + 'attn.wq.weight'), None), (fk, g(e + 'attn.wk.weight'), None), (fv, g(e + 'attn.wv.weight'), None)])
         if FUSED_SELF_ATTENTION:        # vertex queries on joint keys through the same fused core (Tk = J)
             o = ops.attention(q, k, v, Hh, d ** -0.5, rates.mdr_attn, gen, training)
         else:
@@ -270,7 +271,7 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
         vf = ops.layernorm(vf, g('norm%s.a_2' % sfx), g('norm%s.b_2' % sfx), 1e-6, 1)          # vanilla_transformer_encoder.py:31-34
         sa = 'selfatt%s.linears.' % sfx
         vf, res, xq, xk = ops.fork(vf, 4)
-        qq, kk, vv = [ops.linear(t, g(sa + '%d.weight' % n), g(sa + '%d.bias' % n)) for n, t in enumerate((vf, xq, xk))]     # [B,431,64]
+        qq, kk, vv = ops.linear_group([(t, g(sa + '%d.weight' % n), g(sa + '%d.bias' % n)) for n, t in enumerate((vf, xq, xk))])   # [B,431,64] each, one launch
         if FUSED_SELF_ATTENTION:        # one launch forward / three backward, no [B,2,431,431] tensor (csrc/train_attn.inc)
             xo = ops.attention(qq, kk, vv, Hh, 1.0 / math.sqrt(d), rates.mdr_self, gen, training)
         else:                           # the same core composed from the primitives (the cross-check of tests/test_gpu_train_fused.py)

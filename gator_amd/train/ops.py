@@ -169,39 +169,47 @@ class Deferred:
         q = Deferred.queue
         if not q:
             return
-        n = len(q)
-        nbytes = n * ctypes.sizeof(_lib.GemmProblem)
-        capturing = torch.cuda.is_current_stream_capturing()
-        if not capturing and (Deferred.pool is None or Deferred.pool_used + (64 << 10) > Deferred.pool.numel()):
-            if Deferred.pool is not None:
-                Deferred.retired.append(Deferred.pool)     # captured graphs still read their tables from it
-            Deferred.pool, Deferred.pool_used = torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True), 0
-        if capturing:
-            if Deferred.pool is None or Deferred.pool_used + nbytes > Deferred.pool.numel():
-                raise RuntimeError('gator_amd.train: run one eager step before capturing (pinned table pool) / pool exhausted')
-            arr = (_lib.GemmProblem * n).from_address(Deferred.pool.data_ptr() + Deferred.pool_used)
-            Deferred.pool_used += (nbytes + 255) // 256 * 256
-        else:
-            arr = (_lib.GemmProblem * n)()             # pageable: the upload is staged before the call returns
-        for p, (a4, b4, out4, rowsum) in zip(arr, q):
-            M, K, N = a4.shape[2], a4.shape[3], b4.shape[3]
-            tiles = ((M + 63) // 64) * ((N + 63) // 64)
-            p.A, p.B, p.C = a4.data_ptr(), b4.data_ptr(), out4.data_ptr()
-            p.a_rowsum = rowsum.data_ptr() if rowsum is not None else None
-            p.M, p.N, p.K = M, N, K
-            p.ksplit = max(1, min(64, K // 128, 1024 // tiles)) if (K >= 512 and tiles < 256) else 1
-            p.stride_a[0], p.stride_a[1] = a4.stride(2), a4.stride(3)
-            p.stride_b[0], p.stride_b[1] = b4.stride(2), b4.stride(3)
-            p.stride_c[0], p.stride_c[1] = out4.stride(2), out4.stride(3)
-            p.alpha, p.accumulate = 1.0, 0
-        lib = _lib.load()
-        ws_floats = int(lib.gator_t_gemm_grouped_prepare(arr, n))
-        if ws_floats < 0:
-            raise RuntimeError('gator_t_gemm_grouped_prepare rejected the problem list')
-        ws = torch.empty(max(ws_floats, 1), device=dev, dtype=torch.float32)
-        table = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        _call('gator_t_gemm_grouped', arr, n, table.data_ptr(), ws.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        run_group([(a4, b4, out4, rowsum, None) for (a4, b4, out4, rowsum) in q], dev)
         q.clear()
+
+
+def run_group(problems, dev):
+    """One grouped GEMM launch (+ one split-K finish) for a list of independent unbatched products
+    (a4 [1,1,M,K], b4 [1,1,K,N], out4 [1,1,M,N], a_rowsum [M] or None, bias [N] or None)."""
+    n = len(problems)
+    nbytes = n * ctypes.sizeof(_lib.GemmProblem)
+    capturing = torch.cuda.is_current_stream_capturing()
+    D = Deferred
+    if not capturing and (D.pool is None or D.pool_used + (64 << 10) > D.pool.numel()):
+        if D.pool is not None:
+            D.retired.append(D.pool)                   # captured graphs still read their tables from it
+        D.pool, D.pool_used = torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True), 0
+    if capturing:
+        if D.pool is None or D.pool_used + nbytes > D.pool.numel():
+            raise RuntimeError('gator_amd.train: run one eager step before capturing (pinned table pool) / pool exhausted')
+        arr = (_lib.GemmProblem * n).from_address(D.pool.data_ptr() + D.pool_used)
+        D.pool_used += (nbytes + 255) // 256 * 256
+    else:
+        arr = (_lib.GemmProblem * n)()                 # pageable: the upload is staged before the call returns
+    for p, (a4, b4, out4, rowsum, bias) in zip(arr, problems):
+        M, K, N = a4.shape[2], a4.shape[3], b4.shape[3]
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        p.A, p.B, p.C = a4.data_ptr(), b4.data_ptr(), out4.data_ptr()
+        p.a_rowsum = rowsum.data_ptr() if rowsum is not None else None
+        p.bias = bias.data_ptr() if bias is not None else None
+        p.M, p.N, p.K = M, N, K
+        p.ksplit = max(1, min(64, K // 128, 1024 // tiles)) if (K >= 512 and tiles < 256) else 1
+        p.stride_a[0], p.stride_a[1] = a4.stride(2), a4.stride(3)
+        p.stride_b[0], p.stride_b[1] = b4.stride(2), b4.stride(3)
+        p.stride_c[0], p.stride_c[1] = out4.stride(2), out4.stride(3)
+        p.alpha, p.accumulate = 1.0, 0
+    lib = _lib.load()
+    ws_floats = int(lib.gator_t_gemm_grouped_prepare(arr, n))
+    if ws_floats < 0:
+        raise RuntimeError('gator_t_gemm_grouped_prepare rejected the problem list')
+    ws = torch.empty(max(ws_floats, 1), device=dev, dtype=torch.float32)
+    table = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    _call('gator_t_gemm_grouped', arr, n, table.data_ptr(), ws.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
 
 
 # ------------------------------------------------------------------------------------------------ differentiable ops
@@ -428,6 +436,60 @@ class _Linear(torch.autograd.Function):
 
 def linear(x, w, b=None):
     return _Linear.apply(x, w, b)
+
+
+class _LinearGroup(torch.autograd.Function):
+    """Several F.linear layers with independent inputs / weights in ONE grouped launch per direction (forward products; backward
+    activation gradients) - q / k / v projections, the two hop linears of X_Feat ...  Weight gradients go to the deferred group."""
+
+    @staticmethod
+    def forward(ctx, n, *args):                           # args = x_0, w_0, b_0, x_1, w_1, b_1, ...
+        xs, ws, bs = args[0::3], args[1::3], args[2::3]
+        _need_device(*xs)
+        x2s = [_contig(x).reshape(1, 1, -1, x.shape[-1]) for x in xs]
+        w4s = [w.reshape(1, 1, w.shape[0], w.shape[1]) for w in ws]
+        outs = [torch.empty((1, 1, x2.shape[2], w4.shape[2]), device=x2.device, dtype=torch.float32) for x2, w4 in zip(x2s, w4s)]
+        run_group([(x2, w4.transpose(2, 3), o, None, b) for x2, w4, o, b in zip(x2s, w4s, outs, bs)], x2s[0].device)
+        ctx.save_for_backward(*(x2s + w4s))
+        ctx.n, ctx.xshapes, ctx.has_b = n, [x.shape for x in xs], [b is not None for b in bs]
+        ctx.wslots = [grad_slot(w) for w in ws]
+        ctx.bslots = [grad_slot(b) if b is not None else None for b in bs]
+        return tuple(o.reshape(list(sh[:-1]) + [w4.shape[2]]) for o, sh, w4 in zip(outs, ctx.xshapes, w4s))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = ctx.n
+        x2s, w4s = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        g2s = [_contig(g).reshape(1, 1, -1, g.shape[-1]) for g in gs]
+        grads = [None] * (3 * n)
+        gxs = [torch.empty(x2.shape, device=x2.device, dtype=torch.float32) if ctx.needs_input_grad[1 + 3 * i] else None for i, x2 in enumerate(x2s)]
+        probs = [(g2s[i], w4s[i], gxs[i], None, None) for i in range(n) if gxs[i] is not None]
+        if probs:
+            run_group(probs, g2s[0].device)
+        for i in range(n):
+            if gxs[i] is not None:
+                grads[3 * i] = gxs[i].reshape(ctx.xshapes[i])
+            w4 = w4s[i]
+            need_b = ctx.has_b[i] and ctx.needs_input_grad[3 + 3 * i]
+            if ctx.needs_input_grad[2 + 3 * i]:
+                gb = (ctx.bslots[i] if ctx.bslots[i] is not None else torch.empty(w4.shape[2], device=w4.device, dtype=torch.float32)) if need_b else None
+                if Deferred.enabled and ctx.wslots[i] is not None and (gb is None or ctx.bslots[i] is not None):
+                    Deferred.add(g2s[i].transpose(2, 3), x2s[i], ctx.wslots[i].view(w4.shape), gb)
+                    grads[3 * i + 1] = ctx.wslots[i]
+                else:
+                    grads[3 * i + 1] = raw_gemm(g2s[i].transpose(2, 3), x2s[i], a_rowsum=gb).reshape(w4.shape[2], w4.shape[3])
+                grads[3 * i + 2] = gb
+            elif need_b:
+                grads[3 * i + 2] = raw_sum(g2s[i].reshape(-1, g2s[i].shape[-1]), [0])
+        return (None,) + tuple(grads)
+
+
+def linear_group(items):
+    """[(x, w, b or None), ...] -> [x_i W_i^T + b_i]: independent linears as one launch"""
+    flat = []
+    for x, w, b in items:
+        flat += [x, w, b]
+    return list(_LinearGroup.apply(len(items), *flat))
 
 
 class _XW(torch.autograd.Function):

@@ -58,6 +58,7 @@ typedef struct gator_gemm_problem {
     int32_t wg_begin, fin_begin;                     /* filled by _prepare */
     int64_t ws_off;                                  /* filled by _prepare */
     int32_t total_wgs, total_fin;                    /* filled by _prepare in entry 0 */
+    const float* bias;                               /* optional [N], added to every row */
 } gator_gemm_problem;
 int64_t gator_t_gemm_grouped_prepare(gator_gemm_problem* problems, int n);
 int gator_t_gemm_grouped(const gator_gemm_problem* table_host, int n, void* table_dev, float* ws, gator_stream stream);

@@ -136,3 +136,19 @@ def test_dropout_statistics_and_backward():
     per = z.reshape(4096, -1)
     assert torch.all((per == per[:, :1]).all(1))            # one decision per sample
     assert abs(float((per[:, 0] != 0).float().mean()) - 0.8) < 0.03
+
+
+def test_linear_group_matches_separate_linears():
+    xs = [_r(5, 431, 64, seed=30), _r(5, 17, 64, seed=31), _r(5, 17, 64, seed=32)]
+    ws = [_r(64, 64, seed=33), _r(64, 64, seed=34), _r(48, 64, seed=35)]
+    bs = [_r(64, seed=36), None, _r(48, seed=37)]
+    ins = xs + ws + [b for b in bs if b is not None]
+
+    def ours(x0, x1, x2, w0, w1, w2, b0, b2):
+        o = ops.linear_group([(x0, w0, b0), (x1, w1, None), (x2, w2, b2)])
+        return ops.cat([o[0].reshape(5, -1), o[1].reshape(5, -1), o[2].reshape(5, -1)], 1)
+
+    def ref(x0, x1, x2, w0, w1, w2, b0, b2):
+        return torch.cat([F.linear(x0, w0, b0).reshape(5, -1), F.linear(x1, w1).reshape(5, -1), F.linear(x2, w2, b2).reshape(5, -1)], 1)
+
+    _check(ours, ref, ins)
