@@ -1252,7 +1252,7 @@ int gator_t_mgcn_bwd(const float* h0, const float* h1, const float* adj, const f
 
 static int gat_block_check(const gator_gat_block* a, const char* what) {
     static_assert(sizeof(gator_gat_block) == sizeof(GatBlkArgs), "gator_gat_block / GatBlkArgs layouts");
-    if (!a || a->B <= 0 || a->J < 2 || a->J > 32) { fail(1, "%s: bad argument", what); return 1; }
+    if (!a || a->B <= 0 || a->J < 2 || a->J > 20) { fail(1, "%s: bad argument (2 <= J <= 20)", what); return 1; }
     return 0;
 }
 

@@ -122,8 +122,8 @@ def hop_path_bias(P, c, p='pose_lifter.get_hop_path_encoding.'):
 import os
 
 # GATOR_TRAIN_FUSED_GAT=1: one launch per GATBlock and direction (train/fused.py) instead of the block composed from primitives.
-# Measured: the per-sample kernels are correct and cut the step's launches from 1 210 to 570, but their ~45 dependent
-# products per block run serially on one CU per sample - 11.5 vs 10.5 ms at B=64, equal at B=256 - so the composed block stays the default.
+# Measured: the per-sample kernels are correct and remove ~640 launches per step, but their ~45 dependent products per
+# block run serially on one CU per sample - 7.95 vs 6.98 ms at B=64, 16.35 vs 15.95 at B=256 - so the composed block stays the default.
 FUSED_GAT_BLOCKS = os.environ.get('GATOR_TRAIN_FUSED_GAT', '0')
 # GATOR_TRAIN_FUSED_ATTN=0: attention cores and the MGCN aggregation composed from the primitives (the cross-check form) instead of
 # their one-launch kernels
