@@ -80,7 +80,10 @@ class Adam:
 
     @property
     def lr(self):
-        return self.base_lr * self.gamma ** sum(1 for m in self.milestones if self.epoch >= m)
+        """MultiStepLR as main/train.py drives it: `lr_scheduler.step()` after every epoch, epochs counted from begin_epoch = 1
+        (lib/core/config.py:71, main/train.py:36-39), so epoch e runs with gamma^(milestones <= e - 1): lr drops from epoch 31."""
+        done = max(0, self.epoch - 1)
+        return self.base_lr * self.gamma ** sum(1 for m in self.milestones if done >= m)
 
     def step(self, grad):
         self.step_count += 1
