@@ -1272,6 +1272,10 @@ int gator_t_gat_block_bwd(const gator_gat_block* a, gator_stream stream) {
     return check_launch("gator_t_gat_block_bwd");
 }
 
+int64_t gator_t_struct_size(int which) {
+    return which == 0 ? (int64_t)sizeof(gator_gemm_problem) : which == 1 ? (int64_t)sizeof(gator_gat_block) : -1;
+}
+
 int64_t gator_t_loss_ws_bytes(int64_t B, int64_t F) { return 65536 + B * F * 9 * (int64_t)sizeof(float); }
 
 int gator_t_coord_loss(const float* pred, const float* target, const float* valid, const int64_t* sv, const int64_t* shape, float weight,

@@ -113,6 +113,9 @@ int gator_t_mgcn_fwd(const float* h0, const float* h1, const float* adj, const f
 int gator_t_mgcn_bwd(const float* h0, const float* h1, const float* adj, const float* M, const float* d_out, float* dh0, float* dh1, float* pm,
                      float* dadj, int B, int J, int C, gator_stream stream);
 
+/* sizeof(gator_gemm_problem) (which = 0) / sizeof(gator_gat_block) (1): lets a binding check its mirror of the structs */
+int64_t gator_t_struct_size(int which);
+
 /* rows of n contiguous floats.  mode 0: nn.LayerNorm (biased variance, eps inside the root); mode 1: the MDR LayerNorm
  * (lib/models/vanilla_transformer_encoder.py:31-34: unbiased std, eps added to the std).  w, b may be NULL (no affine).
  * forward saves mean[rows] and rinv[rows] (1/sqrt(var+eps) resp. 1/(std+eps)); backward writes dx and, if dy_xhat != NULL,
