@@ -84,6 +84,8 @@ SIGNATURES = {
     'gator_t_attn_small_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
     'gator_t_mgcn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'gator_t_mgcn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'gator_t_batchnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),
+    'gator_t_batchnorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'gator_t_struct_size': (_L, [_I]),
     'gator_t_gat_block_fwd': (_I, [_P, _P]),
     'gator_t_gat_block_bwd': (_I, [_P, _P]),

@@ -1250,6 +1250,26 @@ int gator_t_mgcn_bwd(const float* h0, const float* h1, const float* adj, const f
     return check_launch("gator_t_mgcn_bwd");
 }
 
+int gator_t_batchnorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rinv, float* run_mean, float* run_var, int B,
+                          int C, int L, float eps, float momentum, gator_stream stream) {
+    if (!x || !w || !b || !y || !mean || !rinv || B <= 0 || C <= 0 || L <= 0 || (run_mean && !run_var)) return fail(1, "gator_t_batchnorm_fwd: bad argument");
+    BnArgs a;
+    a.x = x; a.w = w; a.b = b; a.y = y; a.mean = mean; a.rinv = rinv; a.run_mean = run_mean; a.run_var = run_var; a.B = B; a.C = C; a.L = L;
+    a.eps = eps; a.momentum = momentum; a.dy = nullptr; a.dx = a.dw = a.db = nullptr;
+    hipLaunchKernelGGL(k_t_bn_fwd, dim3(C), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch("gator_t_batchnorm_fwd");
+}
+
+int gator_t_batchnorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rinv, float* dx, float* dw, float* db, int B,
+                          int C, int L, gator_stream stream) {
+    if (!dy || !x || !w || !mean || !rinv || !dx || !dw || !db || B <= 0 || C <= 0 || L <= 0) return fail(1, "gator_t_batchnorm_bwd: bad argument");
+    BnArgs a;
+    a.x = x; a.w = w; a.b = nullptr; a.y = nullptr; a.mean = const_cast<float*>(mean); a.rinv = const_cast<float*>(rinv); a.run_mean = a.run_var = nullptr;
+    a.B = B; a.C = C; a.L = L; a.eps = 0.f; a.momentum = 0.f; a.dy = dy; a.dx = dx; a.dw = dw; a.db = db;
+    hipLaunchKernelGGL(k_t_bn_bwd, dim3(C), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return check_launch("gator_t_batchnorm_bwd");
+}
+
 static int gat_block_check(const gator_gat_block* a, const char* what) {
     static_assert(sizeof(gator_gat_block) == sizeof(GatBlkArgs), "gator_gat_block / GatBlkArgs layouts");
     if (!a || a->B <= 0 || a->J < 2 || a->J > 20) { fail(1, "%s: bad argument (2 <= J <= 20)", what); return 1; }

@@ -291,7 +291,10 @@ def mdr_forward(P, c, pc, gen, rates, training=True, buffers=None, p='pose2mesh.
     elif training:
         rm = buffers.get(p + 'bias_norm.running_mean') if buffers is not None else None
         rv = buffers.get(p + 'bias_norm.running_var') if buffers is not None else None
-        mat_b = _batchnorm_train(mat_b, g('bias_norm.weight'), g('bias_norm.bias'), rm, rv)
+        if FUSED_SELF_ATTENTION:        # one launch per direction, one workgroup per vertex channel
+            mat_b = ops.batchnorm_train(mat_b, g('bias_norm.weight'), g('bias_norm.bias'), rm, rv)
+        else:
+            mat_b = _batchnorm_train(mat_b, g('bias_norm.weight'), g('bias_norm.bias'), rm, rv)
     else:
         rm, rv = buffers[p + 'bias_norm.running_mean'].reshape(1, -1, 1), buffers[p + 'bias_norm.running_var'].reshape(1, -1, 1)
         xh = ops.mul(ops.sub(mat_b, rm), ops.raw_unary(ops.U_RSQRT, ops.raw_unary(ops.U_AFFINE, rv, 1.0, 1e-5)))

@@ -861,6 +861,41 @@ def drop_fused(x, res=None, gelu=False, rate=0.0, path_rate=0.0, gen=None, train
                             gen.counter_ptr() if (d_on or p_on) else None)
 
 
+class _BatchNormTrain(torch.autograd.Function):
+    """nn.BatchNorm1d(C) in training mode on x [B,C,L] (gator_t_batchnorm_fwd / _bwd); the running statistics are updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, run_mean, run_var, eps, momentum):
+        _need_device(x, w, b)
+        xc = _contig(x)
+        B, C, L = xc.shape
+        y = torch.empty_like(xc)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        rinv = torch.empty(C, device=x.device, dtype=torch.float32)
+        _call('gator_t_batchnorm_fwd', xc.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rinv.data_ptr(),
+              run_mean.data_ptr() if run_mean is not None else None, run_var.data_ptr() if run_var is not None else None, B, C, L, float(eps),
+              float(momentum), _stream(x))
+        ctx.save_for_backward(xc, w, mean, rinv)
+        ctx.wslot, ctx.bslot = grad_slot(w), grad_slot(b)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, w, mean, rinv = ctx.saved_tensors
+        B, C, L = xc.shape
+        gc = _contig(g)
+        dx = torch.empty_like(xc)
+        dw = ctx.wslot if ctx.wslot is not None else torch.empty(C, device=g.device, dtype=torch.float32)
+        db = ctx.bslot if ctx.bslot is not None else torch.empty(C, device=g.device, dtype=torch.float32)
+        _call('gator_t_batchnorm_bwd', gc.data_ptr(), xc.data_ptr(), w.data_ptr(), mean.data_ptr(), rinv.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+              db.data_ptr(), B, C, L, _stream(g))
+        return dx, dw, db, None, None, None, None
+
+
+def batchnorm_train(x, w, b, run_mean=None, run_var=None, eps=1e-5, momentum=0.1):
+    return _BatchNormTrain.apply(x, w, b, run_mean, run_var, float(eps), float(momentum))
+
+
 class _Contig(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

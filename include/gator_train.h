@@ -113,6 +113,14 @@ int gator_t_mgcn_fwd(const float* h0, const float* h1, const float* adj, const f
 int gator_t_mgcn_bwd(const float* h0, const float* h1, const float* adj, const float* M, const float* d_out, float* dh0, float* dh1, float* pm,
                      float* dadj, int B, int J, int C, gator_stream stream);
 
+/* nn.BatchNorm1d(C) in training mode on x [B,C,L] (the MDR head's BatchNorm1d(431) over [B,431,3], MDR.py:119,159): batch statistics over
+ * (B, L), biased variance in the normalisation; run_mean / run_var (or NULL) updated with `momentum` and the unbiased variance, as torch does.
+ * mean / rinv [C] are kept for the backward, which writes dx and the whole dw, db. */
+int gator_t_batchnorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rinv, float* run_mean, float* run_var, int B,
+                          int C, int L, float eps, float momentum, gator_stream stream);
+int gator_t_batchnorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rinv, float* dx, float* dw, float* db, int B,
+                          int C, int L, gator_stream stream);
+
 /* sizeof(gator_gemm_problem) (which = 0) / sizeof(gator_gat_block) (1): lets a binding check its mirror of the structs */
 int64_t gator_t_struct_size(int which);
 

@@ -157,3 +157,24 @@ def test_drop_fused_matches_composed(gelu, rate, path, with_res):
     assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
     for a, b in zip(gg, gw):
         assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+
+
+def test_fused_batchnorm_matches_torch_training_mode():
+    import torch.nn.functional as F
+    rs = np.random.RandomState(12)
+    B, C, L = 9, 431, 3
+    x = torch.from_numpy(rs.randn(B, C, L)).requires_grad_(True)
+    w, b = torch.from_numpy(rs.randn(C)).requires_grad_(True), torch.from_numpy(rs.randn(C)).requires_grad_(True)
+    rm0, rv0 = torch.from_numpy(rs.randn(C)), torch.from_numpy(rs.rand(C) + 0.5)
+    gw = torch.from_numpy(rs.randn(B, C, L))
+    rm, rv = rm0.clone(), rv0.clone()
+    want = F.batch_norm(x, rm, rv, w, b, True, 0.1, 1e-5)
+    gr = torch.autograd.grad(want, [x, w, b], grad_outputs=gw)
+    xd, wd, bd = [t.detach().float().cuda().requires_grad_(True) for t in (x, w, b)]
+    rmd, rvd = rm0.float().cuda(), rv0.float().cuda()
+    got = ops.batchnorm_train(xd, wd, bd, rmd, rvd)
+    gg = torch.autograd.grad(got, [xd, wd, bd], grad_outputs=gw.float().cuda())
+    assert float((got.detach().cpu().double() - want.detach()).abs().max()) <= 2e-5 * float(want.detach().abs().max())
+    for a, r in zip(gg, gr):
+        assert float((a.cpu().double() - r).abs().max()) <= 2e-5 * float(r.abs().max())
+    assert float((rmd.cpu().double() - rm).abs().max()) <= 1e-6 and float((rvd.cpu().double() - rv).abs().max()) <= 1e-5     # running statistics as torch updates them
