@@ -95,3 +95,35 @@ def test_errors_are_loud(built):
     name, impl, z, m = built
     with pytest.raises(RuntimeError):
         m(torch.from_numpy(z['pose2d']))          # CPU tensor: no CPU path
+
+
+@pytest.mark.parametrize('J,alpha', [(17, True), (19, False)])
+def test_crossed_variants_vs_oracle(J, alpha):
+    """`cfg.MODEL.alpha` (LayerNorm(3) + 1.1**scale head, MDR.py:115-119,162-165) is independent of the joint set: the two combinations
+    the goldens do not cover (17 joints with the alpha head, 19 joints with the BatchNorm head) against the fp64 oracle."""
+    import scipy.sparse as sps
+    from gator_amd import models, synthetic
+    from oracle import gator_oracle as go
+    from tests.helpers import _joint_setting
+    seed = 40 + J
+    base = synthetic.make_base_data(seed)
+    sk, fl = _joint_setting(J)
+    adj = np.zeros((J, J))
+    for a, b in tuple(sk) + tuple(fl):
+        adj[a, b] = adj[b, a] = 1
+    m = models.GATOR.get_model(J, 128, 6, [None, sps.csr_matrix(adj + np.eye(J))], 1, torch.Tensor(synthetic.model_j_regressor(J)), base_data=base,
+                               alpha=alpha)
+    sd = m.state_dict()
+    new = synthetic.seeded_state_dict(synthetic.shapes_of(sd), base['rs'])
+    sd.update({k: torch.from_numpy(v) for k, v in new.items()})
+    m.load_state_dict(sd)
+    m = m.to('cuda').eval()
+    x = synthetic.synthetic_pose2d(6, J, seed + 1)
+    verts, pose3d = m(torch.from_numpy(x).cuda())
+    c = go.Consts(J, synthetic.model_j_regressor(J), base, alpha)
+    osd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref_v, ref_p = go.gator_forward(osd, c, torch.from_numpy(x), torch.float64)
+    e = _mm(verts.cpu().numpy(), ref_v.numpy())
+    print('\n[J=%d alpha=%s] vs fp64 oracle: %.2e mm' % (J, alpha, e))
+    assert e <= TOL_MM
+    assert np.abs(pose3d.cpu().numpy() - ref_p.numpy()).max() <= TOL_MM
