@@ -63,6 +63,11 @@ def main():
         ms, loss = timed(tr)
         out['graph'] = {'ms_per_step': round(ms, 3), 'samples_per_s': round(a.batch / ms * 1e3, 1), 'last_loss': loss}
         out['value'] = out['graph']['samples_per_s']
+        # algorithmic work of a step: 3 x the forward's 4.10e8 / 4.18e8 FLOP per sample (backward = 2 x forward), priced
+        # against the fp32-input MFMA peak every product of the step runs on
+        flop = 3.0 * (4.10e8 if a.joints == 17 else 4.18e8)
+        out['roofline'] = {'bound': 'mfma', 'achieved': round(out['value'] * flop / 1e12, 2), 'peak': 157.3, 'unit': 'TFLOP/s',
+                           'frac': round(out['value'] * flop / 157.3e12, 4), 'flop_per_sample': flop, 'note': 'whole step, algorithmic FLOPs; launch-bound at B=64'}
     if not a.no_cpu_baseline:
         from oracle import gator_oracle as go
         from gator_amd.train.model import is_buffer
