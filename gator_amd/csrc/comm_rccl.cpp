@@ -67,7 +67,10 @@ static_assert(sizeof(ncclUniqueId) == GATOR_COMM_ID_BYTES, "gator_comm_unique_id
 extern "C" int gator_comm_unique_id(uint8_t* id) {
     if (!id) return gator::fail(GATOR_EINVAL, "gator_comm_unique_id: null id");
     Rccl* R = rccl();
-    if (!R) return gator::fail(GATOR_EUNSUPPORTED, "gator_comm_unique_id: librccl not found (%s)", dlerror() ? dlerror() : "no error");
+    if (!R) {
+        const char* why = dlerror();                  // (a second call would return NULL: the message is consumed by the first)
+        return gator::fail(GATOR_EUNSUPPORTED, "gator_comm_unique_id: librccl not found (%s)", why ? why : "no error");
+    }
     ncclUniqueId u;
     GATOR_NCCL_CHECK(R, R->GetUniqueId(&u));
     memcpy(id, &u, sizeof(u));

@@ -28,6 +28,17 @@ class _LossFn(torch.autograd.Function):
         if not pred.is_cuda:
             raise RuntimeError('gator_amd.train.losses: predictions must live on a HIP device (there is no CPU path)')
         p = pred if pred.is_contiguous() else ops.raw_copy(pred)
+        # the kernels read target / valid as device float32: anything else (a host tensor, a float64 / bool mask from a dataloader)
+        # would be a GPU fault or a silently wrong loss
+        for nm, tns in (('target', target), ('valid', valid)):
+            if tns is None:
+                continue
+            if not torch.is_tensor(tns) or not tns.is_cuda or tns.device != p.device:
+                raise RuntimeError('gator_amd.train.losses: %s must be a tensor on %s (got %s)' % (nm, p.device, getattr(tns, 'device', type(tns))))
+            if tns.dtype != torch.float32:
+                raise TypeError('gator_amd.train.losses: %s must be float32 (got %s); convert it once when the batch is staged' % (nm, tns.dtype))
+        if tuple(target.shape) != tuple(p.shape):
+            raise ValueError('gator_amd.train.losses: target %s does not match the prediction %s' % (tuple(target.shape), tuple(p.shape)))
         t = target.contiguous()
         out = torch.empty(1, device=p.device, dtype=torch.float32)
         need = ctx.needs_input_grad[0]
@@ -64,6 +75,8 @@ class MeshLosses:
 
     def __init__(self, faces, j_regressor, device, num_verts=6890, normal_weight=1e-1, edge_weight=20.0, joint_weight=1e-3):
         f = np.asarray(faces, np.int32).reshape(-1, 3)
+        if f.shape[0] < 1 or f.min() < 0 or f.max() >= num_verts:
+            raise ValueError('MeshLosses: faces must hold at least one triangle with vertex indices in [0, %d)' % num_verts)
         ptr, idx = vertex_incidence(f, num_verts)
         self.faces = torch.from_numpy(np.ascontiguousarray(f)).to(device)
         self.inc_ptr = torch.from_numpy(ptr).to(device)

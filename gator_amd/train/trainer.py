@@ -21,6 +21,7 @@ class Trainer:
         self.dist = dist
         self.epoch = 0
         self._graph = None
+        self._graphs = {}
 
     @classmethod
     def from_module(cls, module, faces, j_regressor, device='cuda', **kw):
@@ -32,50 +33,83 @@ class Trainer:
         inference kernels."""
         return self.params.state_dict()
 
-    def loss_and_grad(self, pose2d, targets, training=True):
+    def with_edge(self):
+        """EdgeLengthLoss joins the sum from the epoch after `edge_loss_start` on (lib/core/base.py:141-143)."""
+        return self.epoch > self.edge_loss_start
+
+    def loss_and_grad(self, pose2d, targets, training=True, with_edge=None):
         P = self.params.views()
         mesh, pose3d = M.gator_forward(P, self.consts, pose2d, self.gen, self.rates, training, self.params.buffers)
-        loss, parts = self.losses.total(mesh, pose3d, targets, with_edge=self.epoch > self.edge_loss_start)
+        loss, parts = self.losses.total(mesh, pose3d, targets, with_edge=self.with_edge() if with_edge is None else with_edge)
         one = ops.raw_unary(ops.U_AFFINE, loss.detach(), 0.0, 1.0)          # d loss / d loss (autograd's default would be an aten fill)
         grad, = torch.autograd.grad(loss, self.params.flat, grad_outputs=one)
         return loss.detach(), {k: v.detach() for k, v in parts.items()}, grad
 
     def capture(self, pose2d, targets):
-        """Capture forward + losses + backward of one step (this batch shape) into a hipGraph: the ~3 000 kernel launches of a step
+        """Capture forward + losses + backward of one step (this batch shape) into a hipGraph: the ~700 kernel launches of a step
         become one graph launch, the host only replays.  Dropout offsets and Adam's step index come from a device counter that the
-        graph itself advances, so every replay draws new masks.  The gradient all-reduce and the Adam launch stay outside the graph."""
+        graph itself advances, so every replay draws new masks.  The gradient all-reduce and the Adam launch stay outside the graph.
+
+        The set of losses is part of the captured graph, so one graph exists per value of `with_edge()`: the variant of the current
+        epoch is captured here, the other one by the first `step()` that needs it (on the same static input buffers).  Capturing
+        does not disturb the training state: the step counter continues from `optim.step_count` (capture after eager steps or after
+        `optim.load_state_dict`), and the BatchNorm running statistics that the warm-up passes touch are put back."""
         dev = self.params.flat.device
-        self.gen.device_steps(dev)
+        if self.gen.counter is None:
+            self.gen.device_steps(dev)
         self.optim.device_step = self.gen.counter
         self._x = pose2d.clone()
         self._tg = {k: v.clone() for k, v in targets.items()}
+        self._graphs = {}
+        self._capture_variant(self.with_edge())
+        return self
+
+    def _capture_variant(self, with_edge):
+        dev = self.params.flat.device
+        saved = {k: v.clone() for k, v in self.params.buffers.items()}
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):                        # warm-up off the capture: workspaces and the allocator's pools
             for _ in range(2):
-                self._body()
+                self._body(with_edge)
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.gen.counter.zero_()
-        self.optim.step_count = 0
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._out = self._body()
-        return self
+        for k, v in saved.items():                           # the warm-up is not a training step: running_mean / running_var /
+            self.params.buffers[k].copy_(v)                  # num_batches_tracked back to what the eager trainer would hold
+        self.gen.counter.fill_(self.optim.step_count)        # replay n + 1 is step optim.step_count + n + 1 (Adam bias correction, masks)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self._body(with_edge)
+        self._graphs[bool(with_edge)] = (graph, out)
+        self._graph = graph
 
-    def _body(self):
+    def _body(self, with_edge):
         self.gen.begin_step()
-        return self.loss_and_grad(self._x, self._tg)
+        return self.loss_and_grad(self._x, self._tg, with_edge=with_edge)
+
+    def _check_captured_batch(self, pose2d, targets):
+        if tuple(pose2d.shape) != tuple(self._x.shape):
+            raise ValueError('captured step expects pose2d %s, got %s: call capture() again for a new batch shape' % (tuple(self._x.shape), tuple(pose2d.shape)))
+        if set(targets) != set(self._tg):
+            raise ValueError('captured step expects target keys %s, got %s' % (sorted(self._tg), sorted(targets)))
+        for k, v in targets.items():
+            if tuple(v.shape) != tuple(self._tg[k].shape):
+                raise ValueError('captured step expects targets[%r] %s, got %s' % (k, tuple(self._tg[k].shape), tuple(v.shape)))
 
     def step(self, pose2d, targets):
         """optimizer.zero_grad(); loss.backward(); optimizer.step()  (base.py:151-153)"""
         if self._graph is not None:
+            self._check_captured_batch(pose2d, targets)
+            we = bool(self.with_edge())
+            if we not in self._graphs:                       # the epoch crossed edge_loss_start since capture(): second graph
+                self._capture_variant(we)
             ops.raw_unary(ops.U_AFFINE, pose2d, 1.0, 0.0, out=self._x)
             for k, v in targets.items():
                 ops.raw_unary(ops.U_AFFINE, v, 1.0, 0.0, out=self._tg[k])
-            self._graph.replay()
-            loss, parts, grad = self._out
+            graph, out = self._graphs[we]
+            graph.replay()
+            loss, parts, grad = out
         else:
             self.gen.begin_step()
             loss, parts, grad = self.loss_and_grad(pose2d, targets)

@@ -177,6 +177,43 @@ def test_captured_step_replays_like_eager_and_draws_new_masks():
     assert all(np.isfinite(losses))
 
 
+def test_captured_step_crosses_edge_loss_start_and_keeps_training_state():
+    """lib/core/base.py:141-143: EdgeLengthLoss joins the loss from the epoch after `edge_loss_start` on.  A step replayed from a
+    hipGraph must follow: the graph captured before the switch is not the graph replayed after it.  And capturing is not a
+    training step: after eager steps (or optim.load_state_dict) the captured trainer continues with Adam's step index, and the
+    BatchNorm running statistics are what the eager trainer holds (the warm-up passes of capture() leave no trace)."""
+    name = 'h36m17_bn'
+    z, m, eager, _ = make_trainer(name, lr=1e-5)
+    z, m, graph, _ = make_trainer(name, lr=1e-5)
+    for tr in (eager, graph):
+        tr.edge_loss_start = 1
+        tr.epoch = 1
+    x, tg = batch_of(z, 8, shift=3)
+    for it in range(2):                                                 # two eager steps on both, THEN capture one of them
+        eager.step(x, tg)
+        graph.step(x, tg)
+    graph.capture(x, tg)
+    assert graph.optim.step_count == 2 and int(graph.gen.counter.item()) == 2
+    for k, v in eager.params.buffers.items():                           # running_mean / running_var / num_batches_tracked untouched by capture
+        assert torch.equal(v, graph.params.buffers[k]), k
+    for epoch in (1, 1, 2, 2, 1):                                       # crosses edge_loss_start forth and back under replay
+        eager.epoch = graph.epoch = epoch
+        le, pe = eager.step(x, tg)
+        lg, pg = graph.step(x, tg)
+        assert ('edge' in pg) == (epoch > 1) == ('edge' in pe), (epoch, sorted(pg))
+        assert abs(float(le) - float(lg)) <= 1e-5 * abs(float(le)), (epoch, float(le), float(lg))
+    assert graph.optim.step_count == eager.optim.step_count == 7 and int(graph.gen.counter.item()) == 7
+    d = float((eager.params.flat.detach() - graph.params.flat.detach()).abs().max())
+    assert d <= 4e-5, d                                                 # same bias correction on both: a wrong t = 1 would move weights by ~lr per step
+    for k, v in eager.params.buffers.items():
+        if v.is_floating_point():
+            assert float((v - graph.params.buffers[k]).abs().max()) <= 1e-5 * (1.0 + float(v.abs().max())), k
+        else:
+            assert torch.equal(v, graph.params.buffers[k]), k
+    with pytest.raises(ValueError):                                     # another batch shape needs a new capture
+        graph.step(x[:4], {k: v[:4] for k, v in tg.items()})
+
+
 def test_lift_trainer_matches_oracle_autograd():
     """LiftTrainer (lib/core/base.py:260-300): GAT alone, CoordLoss on the lifted joints - gradients against torch-CPU float64
     autograd over the oracle's gat_forward."""
