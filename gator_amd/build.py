@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libgator_hip.so')
-SOURCES = ['api.hip', 'basic_kernels.hip', 'fused_api.hip', 'fused_pack.hip', 'upsample_fused.hip', 'mdr_fused.hip', 'gat_fused.hip', 'gat_tiled.hip', 'gat_tail.hip', 'upsample_bf16.hip', 'upsample_x3.hip', 'caller_kernels.hip', 'train_ops.hip',
+SOURCES = ['api.hip', 'basic_kernels.hip', 'fused_api.hip', 'fused_pack.hip', 'upsample_fused.hip', 'mdr_fused.hip', 'gat_fused.hip', 'gat_roles.hip', 'gat_tiled.hip', 'gat_tail.hip', 'upsample_bf16.hip', 'upsample_x3.hip', 'caller_kernels.hip', 'train_ops.hip',
            'graph_consts.cpp', 'comm_rccl.cpp']
 HEADERS = ['internal.h', os.path.join(ROOT, 'include', 'gator_hip.h'), os.path.join(ROOT, 'include', 'gator_train.h')]
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
@@ -17,7 +17,7 @@ FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=o
 # and adds 6-8 cycles.  Building the MFMA kernels without the packed forms (the flags below) was tried and is NOT used: the
 # VALU-bound parts (exact GELU, operand splits) lose more than the MFMA-adjacent parts gain (1.00 -> 1.03 ms per step).
 NO_PK = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-NO_PK_SOURCES = ()
+NO_PK_SOURCES = tuple(x for x in os.environ.get('GATOR_NO_PK', '').split(',') if x)
 
 
 def _stale(target, deps):

@@ -127,6 +127,14 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
             GATOR_HIP_CHECK(hipMalloc(&f->gxbuf, (size_t)ntiles * kTileX3 * sizeof(float)));
             int rc = fused_repack_x3(f->gblk[0].qkv, f->gxbuf, ntiles, stream);
             if (rc) return rc;
+            const char* g8 = getenv("GATOR_GAT8");
+            f->gat8 = !(g8 && atoi(g8) == 0);
+            if (f->gat8) {
+                rc = gat8_build_stream(f, stream);
+                if (rc) return rc;
+            }
+        } else {
+            f->gat8 = false;
         }
     }
     std::vector<float> bt(8 * kTile), mt(kTile);
@@ -167,6 +175,7 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
     {
         int rc = gat_prepare_device();
         if (rc == GATOR_OK) rc = gat_tiled_prepare_device();
+        if (rc == GATOR_OK) rc = gat8_prepare_device();
         if (rc) return rc;
         const char* tl = getenv("GATOR_GAT_TILED");
         f->gat_tiled = tl ? atoi(tl) : -1;
@@ -328,6 +337,7 @@ void fused_destroy(gator_ctx* c) {
     if (c->fused->wbuf) (void)hipFree(c->fused->wbuf);
     if (c->fused->gbuf) (void)hipFree(c->fused->gbuf);
     if (c->fused->gxbuf) (void)hipFree(c->fused->gxbuf);
+    if (c->fused->g8stream) (void)hipFree(c->fused->g8stream);
     if (c->fused->wxbuf) (void)hipFree(c->fused->wxbuf);
     if (c->fused->up_w16) (void)hipFree(c->fused->up_w16);
     if (c->fused->blk_tap) (void)hipFree(c->fused->blk_tap);

@@ -53,6 +53,8 @@ struct FusedState : FusedWs {
     bool gat_split_tail = true;         // full forward: lifter + joint tokens as batched launches (GATOR_GAT_TAIL=0: inside k_gat)
     bool gat_x3 = true;                 // GAT linears on split-precision bf16 MFMA (GATOR_GAT_X3=0: fp32-input MFMA)
     float* gxbuf = nullptr;             // X3 tiles of the GAT block weights, tile-for-tile image of gbuf from gblk[0].qkv on
+    float* g8stream = nullptr;          // the same tiles as four per-wave streams in consumption order (gat_roles.hip)
+    bool gat8 = true;                   // one-sample-per-workgroup encoder: the two-role kernel k_gat8 (GATOR_GAT8=0: k_gat)
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
     int mdr_x3 = 2;                     // GATOR_MDR_X3: 0 fp32-input MFMA; 1 exact bf16 x 3 split everywhere; 2 (default) that + the 431x431 attention on two fp16 planes
     bool x3 = true;                     // split-precision vertex regressor (GATOR_UPSAMPLE_X3=0: fp32-input MFMA kernel)
@@ -92,6 +94,10 @@ int gat_prepare_device();
 int gat_ensure_blk_tap(gator_ctx* c, FusedState* f, int B);
 int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue = false,
                int B_total = 0, int tap_row0 = 0);
+// gat_roles.hip
+int gat8_prepare_device();
+int gat8_build_stream(FusedState* f, void* stream);
+int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total = 0, int tap_row0 = 0);
 // gat_tiled.hip
 int gat_tiled_prepare_device();
 int gat_tiled_samples_per_wg(int J);

@@ -734,6 +734,12 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
     // (a launch that covers only part of a batch -- the remainder behind the sample-tiled kernel -- always leaves the tail to the
     // batched launches, which then run once over the whole batch)
     const bool split_tail = joint_epilogue && (f->gat_split_tail || (B_total > 0 && B_total != B));
+    if (split_tail && f->gat_x3 && f->gat8 && f->g8stream) {                             // the two-role form (gat_roles.hip)
+#ifdef GATOR_DIAG
+        if (d_st) GATOR_HIP_CHECK(hipFree(d_st));                                         // (it prints its own stamps)
+#endif
+        return launch_gat8(c, f, pose2d, B, feat, stream, B_total, tap_row0);
+    }
     if (split_tail) {
         if (f->gat_x3) k_gat<true, false><<<B, 256, kGatLdsX3, (hipStream_t)stream>>>(a);
         else k_gat<false, false><<<B, 256, kGatLds, (hipStream_t)stream>>>(a);

@@ -1,0 +1,751 @@
+// GAT graph-aware transformer encoder (lib/models/GAT.py:133-152, GATBlock :33-43), six blocks in ONE launch, one workgroup per
+// sample -- the form for one sample per CU (batches up to one round of the chip), built around what bounds that case.
+//
+// What bounds it (tools/microbench/wstream.hip, profiles/r03_microbench_weight_stream.txt).  A sample walks 1 560 operand tiles of
+// split-precision weights (9.4 MB) that nobody else on its CU can share.  Streamed alone they take 85 us (54 B/clk through the
+// CU's vector L1); with their 12 MFMAs each issued by the same four waves 101 us, provided those waves do nothing else.  k_gat
+// (gat_fused.hip) has each of its four waves alternate between that stream, the J x J attention, LayerNorms, GELUs and operand
+// splits, so the stream stops whenever the wave does anything else: 226 us.
+//
+// Two roles, eight waves (two per SIMD):
+//   waves 0-3  "product waves": ONLY the weight stream (five tiles in flight in registers, one contiguous per-wave stream in
+//              consumption order, packed at create), the bf16 MFMAs of the token-wise linears with the activation operand read
+//              from LDS, and the raw fp32 accumulator parked in LDS.  Wave w owns channel block w of every 128-wide layer.
+//   waves 4-7  "helper waves": everything else.  Helper w picks up product wave w's raw tile one step later and does bias,
+//              residual, LayerNorm, the J x J attention of heads 2w / 2w+1 (fp32-input MFMA, scores and probabilities in
+//              registers), the MGCN adjacency product, the hop-1 / hop-2 aggregations, GELU and the exact hi/mid/lo split into
+//              the next operand tile.
+// One workgroup barrier per step, 22 steps per block; in 16 of them a product wave streams one 4-tile unit (a 32-channel output
+// block over K = 128) while the helper finishes the previous unit, six are helper-only (SB, the hop aggregations, residual +
+// LayerNorm twice).  Both roles live in disjoint branches of one kernel so that neither pays the other's registers; the barriers
+// are numbered GAT8_BAR(n) in both and tests/test_host_cpu.py checks that the two sequences are identical.
+//
+// LDS (144 KiB): A = 4 operand tiles (Y = LN1(x) | Y2 = LN2(x) | hidden blocks 4w+3), B = 12 operand tiles (AT | SB | FB, later
+// hidden blocks 4w+j, j < 3), R0 / R1 = 2 x 4 raw tiles (product wave w writes R[step & 1][w], helper w reads it in the next
+// step), X = the residual stream as 4 fp32 tiles (for the LayerNorm statistics; between LayerNorms it carries the four partial
+// hop-2 linears).  Arithmetic, operand formats and summation structure are k_gat's (x3_common.h: exact three-way bf16 split, six
+// partial products, fp32 accumulation); the results agree with it to fp32 rounding (the MLP's four partial sums group the hidden
+// blocks differently), not bit for bit.
+#include "fused_common.h"
+#include "fused_state.h"
+#include "x3_common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+namespace gator {
+namespace {
+
+constexpr float kLog2e8 = 1.4426950408889634f;
+constexpr int kNT = 5;                                  // weight tiles in flight per product wave (65 tiles per block = 13 x 5)
+constexpr int kBlkTiles = 65;                           // q k v h0 h1 proj lin0 (4 each) + lin1 (1) + back (4) + fc1 (16) + fc2 (16)
+constexpr int kWaveTiles = kBlkTiles * kDepth;          // 390 per product wave
+constexpr int kStreamFloats = (4 * kWaveTiles + kNT) * kTileX3;
+
+// offsets into a block's vector table (fused_api.hip packs them in this order, 2048 floats per block)
+enum { V_N1W = 0, V_N1B = 128, V_QKVB = 256, V_PROJB = 640, V_GCNB = 768, V_LIN0B = 896, V_BACKB = 1024, V_N2W = 1152,
+       V_N2B = 1280, V_FC1B = 1408, V_FC2B = 1920 };
+
+struct Gat8Blk { const float *back32, *mc, *mdT, *aoffT, *f1b, *vecs; };
+
+struct Gat8Args {
+    int B, J;
+    const float* pose2d;
+    const float *gl0_W, *gl0_b, *gn_w, *gn_b, *gl3_p, *gl3_b, *posT;
+    const float *biasT, *m1T, *m2T;
+    const float *norm_w, *norm_b;
+    const float* wstream;            // [4 product waves][390 tiles][kTileX3] (+ kNT tiles of slack behind the last wave)
+    Gat8Blk blk[kDepth];
+    float* feat;
+    int tapB;
+    float* blk_tap;
+    int pf_n, pf_loads;              // L2 warm-up of the next block's weights: workgroups per XCD that share it, 8 KiB touches per helper wave (0: off)
+#ifdef GATOR_DIAG
+    unsigned long long* stamps;      // [2 roles][kDepth][23 steps][work, wait]
+    int dbg;                         // GATOR_GAT8_DBG: 1 = helpers only keep the barriers (what do the product waves cost alone?)
+#endif
+};
+
+// LDS map (floats)
+constexpr int kA = 0;                                   // 4 operand tiles
+constexpr int kBq = kA + 4 * kTileX3;                   // 12 operand tiles
+constexpr int kR = kBq + 12 * kTileX3;                  // R0 (4 raw tiles) | R1 (4 raw tiles)
+constexpr int kXo = kR + 8 * kTile;                     // 4 fp32 tiles
+constexpr int kDummy = kXo + 4 * kTile;                 // 4 x 1 KiB landing window of the L2 warm-up (never read)
+constexpr int kGat8LdsFloats = kDummy + 1024;           // 37 888 floats = 148 KiB
+
+#ifdef GATOR_DIAG
+// diagnostic library only (python -m gator_amd.build --diag; GATOR_GAT_STAMPS=1): per role, block and step the cycles spent working
+// (from leaving the previous barrier to arriving at this one) and waiting in the barrier, of workgroup 0's waves 0 and 4
+#define GAT8_BAR(n)                                                                                      \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        const unsigned long long t_arr_ = __builtin_amdgcn_s_memtime();                                  \
+        __syncthreads();                                                                                 \
+        const unsigned long long t_go_ = __builtin_amdgcn_s_memtime();                                   \
+        if (st_out) { st_out[((size_t)bi_ * 23 + (n)) * 2] = t_arr_ - st_last; st_out[((size_t)bi_ * 23 + (n)) * 2 + 1] = t_go_ - t_arr_; } \
+        st_last = t_go_;                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#define GAT8_SUB(k)                                                                                     \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (st_out) st_out[(size_t)kDepth * 23 * 2 + bi_ * 8 + (k)] = __builtin_amdgcn_s_memtime() - st_last;              \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#else
+#define GAT8_BAR(n) __syncthreads()
+#define GAT8_SUB(k)
+#endif
+
+// A helper wave is alone with its own dependency chains (its SIMD partner issues MFMAs, nobody fills its latency slots), so the
+// reductions are trees of independent partial sums and the GELU walks its polynomial level by level over all eight register pairs.
+__device__ __forceinline__ float rsum128(const f32x16 (&x)[4]) {
+    float p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        p[q] = 0.f;
+#pragma unroll
+        for (int r = 4 * q; r < 4 * q + 4; ++r) p[q] += (x[0][r] + x[1][r]) + (x[2][r] + x[3][r]);
+    }
+    const float s = (p[0] + p[1]) + (p[2] + p[3]);
+    return s + xhalf(s);
+}
+
+// gelu_f2 (fused_common.h) over a whole register tile, the eight pairs advanced together: same operations per element, so the same
+// bits; only the instruction order differs (one pair after the other is a chain of 12 dependent packed operations, 8 times)
+__device__ __forceinline__ void gelu_tile8(f32x16& v) {
+    f32x2 x[8], t[8], r[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        x[p][0] = v[2 * p]; x[p][1] = v[2 * p + 1];
+        const f32x2 a = x[p] * 0.70710678118654752440f;
+        t[p][0] = fminf(fabsf(a[0]), 4.3f);
+        t[p][1] = fminf(fabsf(a[1]), 4.3f);
+    }
+    const float c[8] = {4.369443071e-04f, -1.460381877e-03f, -8.251648338e-04f, 2.830188636e-02f, -1.485066472e-01f, -9.184098145e-01f,
+                        -1.627909326e+00f, -9.999999783e-01f};
+#pragma unroll
+    for (int p = 0; p < 8; ++p) r[p] = pk_fma(f32x2(-4.435285315e-05f), t[p], f32x2(c[0]));
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) r[p] = pk_fma(r[p], t[p], f32x2(c[k]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        r[p][0] = __builtin_amdgcn_exp2f(r[p][0]);
+        r[p][1] = __builtin_amdgcn_exp2f(r[p][1]);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const f32x2 up = 1.0f - r[p];
+        f32x2 phi;
+        phi[0] = x[p][0] < 0.f ? r[p][0] : up[0];
+        phi[1] = x[p][1] < 0.f ? r[p][1] : up[1];
+        const f32x2 y = x[p] * phi;
+        v[2 * p] = y[0]; v[2 * p + 1] = y[1];
+    }
+}
+
+// nn.LayerNorm(128) of the residual stream X (4 fp32 tiles in LDS): statistics over all four tiles, result for this wave's own
+// channel block only (xw = its registers, the same values as X[w]); same operation order as k_gat's layernorm128
+__device__ __forceinline__ f32x16 ln_own(const float* X, const f32x16& xw, const f32x16& wv, const f32x16& bv, int lane) {
+    f32x16 x[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) x[kb] = load_block(X + kb * kTile, lane);
+    const float mean = rsum128(x) * (1.0f / 128.0f);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) { x[kb] = x[kb] - mean; x[kb] = x[kb] * x[kb]; }
+    const float rstd = 1.0f / sqrtf(rsum128(x) * (1.0f / 128.0f) + 1e-5f);
+    return (xw - mean) * rstd * wv + bv;
+}
+
+// ---- product wave: one unit = the K = 128 contraction of one 32-channel output block (4 weight tiles) --------------------------
+// CL = false: weights as A operand -> T-layout accumulator (token on the lane); CL = true: activations as A -> C-layout.
+// Slot indices are compile-time (S0 = tile offset of the unit inside its block, mod kNT); every slot is refilled with the tile
+// kNT positions further down the wave's stream right after the MFMAs that read it are queued.
+// LDS-DMA through inline asm (hipcc drains the builtin form with vmcnt(0) before the next LDS access, see gat_tiled.hip): used
+// only to pull lines into this XCD's L2 - the bytes land in a window nobody reads, no registers are held
+__device__ __forceinline__ void glds4(const float* gsrc, const float* lds_dst) {      // one dword per lane, per-lane source address
+    unsigned keep;
+    const unsigned dst = (unsigned)(unsigned long long)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+// One tile product with the refill of its weight slot woven in: a plane's load (tile kNT positions further down the stream) is
+// issued right behind the LAST MFMA that reads that plane, so it issues in the shadow of the next MFMA.  Issued as a burst behind
+// the twelve MFMAs (k_gat's form) the six 1 KiB loads hold the in-order wave at the memory pipeline's issue rate while the matrix
+// pipe idles: measured here as 3.2k cycles per 4-tile unit against 1.5k of MFMA time.  sched_barrier pins the order.
+template <bool CL>
+__device__ __forceinline__ void tile_mma_refill(X3& w, const X3& b, f32x16& acc, const float* __restrict__ wp, int lane) {
+    const bf16x8* q = reinterpret_cast<const bf16x8*>(wp) + lane;
+#define GAT8_MM(wpl, bpl, s) acc = CL ? GATOR_MFMA_BF16(b.p[bpl][s], w.p[wpl][s], acc) : GATOR_MFMA_BF16(w.p[wpl][s], b.p[bpl][s], acc)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        GAT8_MM(2, 0, s);                                  // lo*hi
+        __builtin_amdgcn_sched_barrier(0);
+        w.p[2][s] = q[(2 * 2 + s) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        GAT8_MM(0, 2, s);                                  // hi*lo
+        GAT8_MM(1, 1, s);                                  // mid*mid
+        GAT8_MM(1, 0, s);                                  // mid*hi
+        __builtin_amdgcn_sched_barrier(0);
+        w.p[1][s] = q[(1 * 2 + s) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        GAT8_MM(0, 1, s);                                  // hi*mid
+        GAT8_MM(0, 0, s);                                  // hi*hi
+        __builtin_amdgcn_sched_barrier(0);
+        w.p[0][s] = q[(0 * 2 + s) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef GAT8_MM
+}
+
+// ---- product wave: one unit = the K = 128 contraction of one 32-channel output block (4 weight tiles) --------------------------
+// CL = false: weights as A operand -> T-layout accumulator (token on the lane); CL = true: activations as A -> C-layout.
+// Slot indices are compile-time (S0 = tile offset of the unit inside its block, mod kNT).
+// `b` = the unit's first operand tile, already requested: where that tile was complete two barriers ago (Y for k / v / h0 / h1, Y2
+// for the later fc1 units, the hidden blocks for fc2) the caller reads it BEFORE the barrier that opens the step, so the matrix
+// pipe does not idle through an LDS round trip after every barrier.
+template <int S0, bool CL>
+__device__ __forceinline__ void unit4(X3 (&W)[kNT], const float* __restrict__& wp, X3 b, const float* o1, const float* o2, const float* o3,
+                                      float* raw, int lane) {
+    const float* ops[4] = {o1, o1, o2, o3};
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        X3 bn = b;
+        if (kb < 3) bn = x3_load(ops[kb + 1], lane);
+        tile_mma_refill<CL>(W[(S0 + kb) % kNT], b, acc, wp, lane);
+        wp += kTileX3;
+        b = bn;
+    }
+    store_block(raw, lane, acc);
+}
+// one tile: partial hop-2 linear (linears[1], 128 -> 16) over k block `w` of SB; C-layout
+template <int S0>
+__device__ __forceinline__ void unit1(X3 (&W)[kNT], const float* __restrict__& wp, const float* o0, float* raw, int lane) {
+    f32x16 acc = zero16();
+    const X3 b = x3_load(o0, lane);
+    tile_mma_refill<true>(W[S0 % kNT], b, acc, wp, lane);
+    wp += kTileX3;
+    store_block(raw, lane, acc);
+}
+
+__global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* A = lds + kA;
+    float* Bq = lds + kBq;
+    float* X = lds + kXo;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int w = wave & 3;                              // channel block of this wave (either role)
+    float* R0w = lds + kR + w * kTile;
+    float* R1w = lds + kR + (4 + w) * kTile;
+
+
+    // ---------------- embedding: GraphLinear(2->64) . GroupNorm(4,64) . GELU . GraphLinear(64->128) + pos (GAT.py:135-144)
+    {
+        float* hbuf = Bq;                 // [64][32]
+        float* gt = Bq + 2 * kTile;       // 2 T-layout tiles
+        float* stat = Bq + 4 * kTile;     // [4][2]
+        const float* p = a.pose2d + (size_t)b * J * 2;
+        for (int e = t; e < 64 * 32; e += 512) {
+            const int c = e >> 5, j = e & 31;
+            hbuf[e] = j < J ? a.gl0_W[c * 2] * p[j * 2] + a.gl0_W[c * 2 + 1] * p[j * 2 + 1] + a.gl0_b[c] : 0.f;
+        }
+        __syncthreads();
+        if (wave >= 4) {   // helper w -> GroupNorm group w (16 channels x J tokens), two-pass
+            float s = 0.f;
+            for (int e = lane; e < 16 * 32; e += 64) s += ((e & 31) < J) ? hbuf[w * 512 + e] : 0.f;
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s / (16.0f * J);
+            float q = 0.f;
+            for (int e = lane; e < 16 * 32; e += 64) {
+                const float d = hbuf[w * 512 + e] - mean;
+                q += ((e & 31) < J) ? d * d : 0.f;
+            }
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            if (lane == 0) { stat[w * 2] = mean; stat[w * 2 + 1] = 1.0f / sqrtf(q / (16.0f * J) + 1e-5f); }
+        }
+        __syncthreads();
+        // GroupNorm affine + GELU as two T-layout operand tiles gt[kb][g][lane][j] <-> token lane&31, channel 32kb+8g+4h+j
+        for (int e = t; e < 2 * kTile; e += 512) {
+            const int j4 = e & 3, ln = (e >> 2) & 63, g = (e >> 8) & 3, kb = e >> 10;
+            const int tok = ln & 31, c = 32 * kb + 8 * g + 4 * (ln >> 5) + j4;
+            gt[e] = tok < J ? gelu_f((hbuf[c * 32 + tok] - stat[(c >> 4) * 2]) * stat[(c >> 4) * 2 + 1] * a.gn_w[c] + a.gn_b[c]) : 0.f;
+        }
+        __syncthreads();
+        if (wave >= 4) {   // GraphLinear(64->128) on the fp32-input MFMA: helper w -> channel block w; + folded position tiles
+            f32x16 acc = load_chanvec_T(a.gl3_b, 32 * w, h) + load_block(a.posT + (size_t)w * kTile, lane), ac1 = zero16();
+            mma2_T(load_wtile(a.gl3_p, w * 2 + 0, lane), load_block(gt, lane), acc, load_wtile(a.gl3_p, w * 2 + 1, lane),
+                   load_block(gt + kTile, lane), ac1);
+            store_block(X + w * kTile, lane, acc + ac1);
+        }
+        __syncthreads();
+    }
+
+    if (wave < 4) {
+        // =========================================== product waves ===========================================================
+        X3 W[kNT];                                                          // the head of the weight stream (held back until here: five tiles
+        const float* __restrict__ wp = a.wstream + (size_t)w * kWaveTiles * kTileX3;     // live across the embedding would spill)
+#pragma unroll
+        for (int s = 0; s < kNT; ++s) { W[s] = x3_load(wp, lane); wp += kTileX3; }
+        asm volatile("" ::: "memory");
+#ifdef GATOR_DIAG
+        unsigned long long* st_out = (a.stamps && b == 0 && t == 0) ? a.stamps : nullptr;
+        unsigned long long st_last = __builtin_amdgcn_s_memtime();
+        int bi_ = 0;
+#endif
+        GAT8_BAR(0);                                                        // helpers: Y = LN1(x) of block 0
+#pragma unroll 1
+        for (int bi = 0; bi < kDepth; ++bi) {
+#ifdef GATOR_DIAG
+            bi_ = bi;
+#endif
+            const float *Y0 = A, *Y1 = A + kTileX3, *Y2 = A + 2 * kTileX3, *Y3 = A + 3 * kTileX3;
+            X3 pre = x3_load(Y0, lane);
+            unit4<0, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             // q  (T)
+            pre = x3_load(Y0, lane);
+            GAT8_BAR(1);
+            unit4<4, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             // k  (T)
+            pre = x3_load(Y0, lane);
+            GAT8_BAR(2);
+            unit4<3, true>(W, wp, pre, Y1, Y2, Y3, R0w, lane);              // v  (C)
+            pre = x3_load(Y0, lane);
+            GAT8_BAR(3);
+            unit4<2, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             // h0 = y W[0]  (T: its MGCN term is token-wise)
+            pre = x3_load(Y0, lane);
+            GAT8_BAR(4);
+            unit4<1, true>(W, wp, pre, Y1, Y2, Y3, R0w, lane);              // h1 = y W[1]  (C)
+            GAT8_BAR(5);
+            pre = x3_load(Bq, lane);
+            unit4<0, false>(W, wp, pre, Bq + kTileX3, Bq + 2 * kTileX3, Bq + 3 * kTileX3, R1w, lane);                   // proj(AT)
+            GAT8_BAR(6);
+            GAT8_BAR(7);                                                    // helpers: SB = proj + attention bias + MGCN
+            pre = x3_load(Bq + 4 * kTileX3, lane);
+            unit4<4, true>(W, wp, pre, Bq + 5 * kTileX3, Bq + 6 * kTileX3, Bq + 7 * kTileX3, R0w, lane);                // linears[0](SB)  (C)
+            unit1<3>(W, wp, Bq + (4 + w) * kTileX3, X + w * kTile, lane);                                              // linears[1], k block w
+            GAT8_BAR(8);
+            GAT8_BAR(9);                                                    // helpers: hop aggregations -> FB
+            pre = x3_load(Bq + 8 * kTileX3, lane);
+            unit4<4, false>(W, wp, pre, Bq + 9 * kTileX3, Bq + 10 * kTileX3, Bq + 11 * kTileX3, R1w, lane);             // linearback(FB), k < 128
+            GAT8_BAR(10);
+            GAT8_BAR(11);                                                   // helpers: residual
+            GAT8_BAR(12);                                                   // helpers: Y2 = LN2(x)
+            pre = x3_load(Y0, lane);
+            unit4<3, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             // fc1, hidden block 4w
+            pre = x3_load(Y0, lane);
+            GAT8_BAR(13);
+            unit4<2, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 1
+            pre = x3_load(Y0, lane);
+            GAT8_BAR(14);
+            unit4<1, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             //      4w + 2
+            pre = x3_load(Y0, lane);
+            GAT8_BAR(15);
+            unit4<0, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 3
+            pre = x3_load(Bq, lane);                                        // (hidden blocks 4w' were complete at barrier 14)
+            GAT8_BAR(16);
+            // fc2: unit u contracts over hidden blocks {4w' + u}: tiles 3w' + u of B for u < 3, tile w' of A for u = 3
+            unit4<4, false>(W, wp, pre, Bq + 3 * kTileX3, Bq + 6 * kTileX3, Bq + 9 * kTileX3, R0w, lane);
+            pre = x3_load(Bq + 1 * kTileX3, lane);
+            GAT8_BAR(17);
+            unit4<3, false>(W, wp, pre, Bq + 4 * kTileX3, Bq + 7 * kTileX3, Bq + 10 * kTileX3, R1w, lane);
+            pre = x3_load(Bq + 2 * kTileX3, lane);
+            GAT8_BAR(18);
+            unit4<2, false>(W, wp, pre, Bq + 5 * kTileX3, Bq + 8 * kTileX3, Bq + 11 * kTileX3, R0w, lane);
+            pre = x3_load(Y0, lane);                                        // (hidden blocks 4w' + 3, complete at barrier 17)
+            GAT8_BAR(19);
+            unit4<1, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);
+            GAT8_BAR(20);
+            GAT8_BAR(21);                                                   // helpers: residual
+            GAT8_BAR(22);                                                   // helpers: Y = LN1(x) of the next block | final norm
+        }
+        return;
+    }
+
+    // =============================================== helper waves ===============================================================
+    const int tok = lane & 31;
+#ifdef GATOR_DIAG
+    if (a.dbg & 1) {
+        for (int n = 0; n < 1 + 22 * kDepth; ++n) __syncthreads();
+        return;
+    }
+    unsigned long long* st_out = (a.stamps && b == 0 && t == 256) ? a.stamps + (size_t)kDepth * 23 * 2 : nullptr;
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    int bi_ = 0;
+#endif
+    f32x16 xw = load_block(X + w * kTile, lane);          // this wave's channel block of the residual stream
+    {
+        const float* vec = a.blk[0].vecs;
+        const f32x16 y = ln_own(X, xw, load_chanvec_T(vec, V_N1W + 32 * w, h), load_chanvec_T(vec, V_N1B + 32 * w, h), lane);
+        x3_store(A + w * kTileX3, lane, x3_split(y));
+    }
+    GAT8_BAR(0);
+#pragma unroll 1
+    for (int bi = 0; bi < kDepth; ++bi) {
+#ifdef GATOR_DIAG
+        bi_ = bi;
+#endif
+        const Gat8Blk& kb = a.blk[bi];
+        const float* vec = kb.vecs;
+        // ---- step 1: constants of the attention (nothing to pick up yet)
+        const f32x16 bq = load_chanvec_T(vec, V_QKVB + 32 * w, h), bk = load_chanvec_T(vec, V_QKVB + 128 + 32 * w, h);
+        const float vb = vec[V_QKVB + 256 + 32 * w + tok];
+        const f32x16 ba = load_block(a.biasT + (size_t)(2 * w) * kTile, lane), bb = load_block(a.biasT + (size_t)(2 * w + 1) * kTile, lane);
+        GAT8_BAR(1);
+        // ---- step 2: q
+        const f32x16 q = load_block(R0w, lane) + bq;
+        GAT8_BAR(2);
+        // ---- step 3: k; scores and softmax of heads 2w, 2w+1 (modules.py:121-133): S^T[key][query], query on the lane
+        f32x16 sa = zero16(), sb = zero16();
+        {
+            const f32x16 k = load_block(R1w, lane) + bk;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                sa = GATOR_MFMA(k[r], q[r], sa);                                    // head 2w:   channels 0..15 of the block
+                sb = GATOR_MFMA(k[r + 8], q[r + 8], sb);                            // head 2w+1: channels 16..31
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = kap(r) + 4 * h < J;
+                sa[r] = ok ? (sa[r] * 0.25f + ba[r]) * kLog2e8 : -1e30f;             // q k^T * head_dim**-0.5 + hop/path bias
+                sb[r] = ok ? (sb[r] * 0.25f + bb[r]) * kLog2e8 : -1e30f;
+            }
+            float ma, mb, la, lb;
+            {   // row maxima and sums as trees (four independent partials each)
+                float pa[4], pb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pa[q] = fmaxf(fmaxf(sa[4 * q], sa[4 * q + 1]), fmaxf(sa[4 * q + 2], sa[4 * q + 3]));
+                    pb[q] = fmaxf(fmaxf(sb[4 * q], sb[4 * q + 1]), fmaxf(sb[4 * q + 2], sb[4 * q + 3]));
+                }
+                ma = fmaxf(fmaxf(pa[0], pa[1]), fmaxf(pa[2], pa[3]));
+                mb = fmaxf(fmaxf(pb[0], pb[1]), fmaxf(pb[2], pb[3]));
+                ma = fmaxf(ma, xhalf(ma));
+                mb = fmaxf(mb, xhalf(mb));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sa[r] = __builtin_amdgcn_exp2f(sa[r] - ma);
+                    sb[r] = __builtin_amdgcn_exp2f(sb[r] - mb);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pa[q] = (sa[4 * q] + sa[4 * q + 1]) + (sa[4 * q + 2] + sa[4 * q + 3]);
+                    pb[q] = (sb[4 * q] + sb[4 * q + 1]) + (sb[4 * q + 2] + sb[4 * q + 3]);
+                }
+                la = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+                lb = (pb[0] + pb[1]) + (pb[2] + pb[3]);
+            }
+            la += xhalf(la);
+            lb += xhalf(lb);
+            const float ia = 1.0f / la, ib = 1.0f / lb;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sa[r] = sa[r] * ia; sb[r] = sb[r] * ib; }
+        }
+        GAT8_BAR(3);
+        // ---- steps 4, 5: v; P.V (both heads, rows 0..15 <- head 2w, rows 16..31 <- head 2w+1); pick up h0 in between
+        f32x16 O = zero16(), Ob = zero16();
+        const bool lo = tok < 16;
+        {
+            const f32x16 v = load_block(R0w, lane);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float vv = v[r] + vb;
+                O = GATOR_MFMA(lo ? vv : 0.f, sa[r], O);
+                Ob = GATOR_MFMA(lo ? 0.f : vv, sb[r], Ob);
+            }
+            GAT8_BAR(4);
+            const f32x16 mdt = load_block(kb.mdT + (size_t)w * kTile, lane);        // (constants are requested about one step before their use)
+            f32x16 h0 = load_block(R1w, lane);
+#pragma unroll
+            for (int r = 8; r < 16; ++r) {
+                const float vv = v[r] + vb;
+                O = GATOR_MFMA(lo ? vv : 0.f, sa[r], O);
+                Ob = GATOR_MFMA(lo ? 0.f : vv, sb[r], Ob);
+            }
+            x3_store(Bq + w * kTileX3, lane, x3_split(O + Ob));                      // AT[w]
+            O = h0 * mdt;                                                          // diag(A)[t] * M[t][n] * h0[t][n]  (O re-used)
+        }
+        const f32x16 mct = load_block(kb.mc + (size_t)w * kTile, lane), aoff = load_block(kb.aoffT, lane);
+        const f32x16 bg = load_chanvec_T(vec, V_GCNB + 32 * w, h);
+        GAT8_BAR(5);
+        // ---- step 6: h1; MGCN (modules.py:243-255): sum_j (M.h1)[j][n] Aoff[t][j] as one MFMA product + the token-wise term
+        f32x16 g_out;
+        {
+            const f32x16 h1 = load_block(R0w, lane) * mct;
+            g_out = dot16(h1, aoff, bg) + O;
+        }
+        const f32x16 bp = load_chanvec_T(vec, V_PROJB + 32 * w, h);
+        GAT8_BAR(6);
+        // ---- step 7: SB = proj(attention) + bias + MGCN
+        {
+            const f32x16 acc = load_block(R1w, lane) + bp;
+            x3_store(Bq + (4 + w) * kTileX3, lane, x3_split(acc + g_out));
+        }
+        GAT8_BAR(7);
+        // constants of the X_Feat steps
+        const f32x16 m1 = load_block(a.m1T, lane), m2 = load_block(a.m2T, lane);
+        const float b0 = vec[V_LIN0B + 32 * w + tok];
+        f32x16 f1 = load_block(kb.f1b, lane);                                      // rowsum(m2)[t] * linears[1].bias[n]
+        GAT8_BAR(8);
+        // ---- step 9: X_Feat (modules.py:158-177): hop<=1 aggregation of linears[0], hop==2 aggregation of linears[1]
+        {
+            const f32x16 u0 = load_block(R0w, lane) + b0;
+            f32x16 u1 = (load_block(X, lane) + load_block(X + kTile, lane)) + (load_block(X + 2 * kTile, lane) + load_block(X + 3 * kTile, lane));
+            f32x16 f0 = zero16(), f1a = zero16();
+            dot16x2(u0, m1, f0, u1, m2, f1a);
+            x3_store(Bq + (8 + w) * kTileX3, lane, x3_split(f0));                  // FB[w]
+            f1 += f1a;
+        }
+        const f32x16 bback = load_chanvec_T(vec, V_BACKB + 32 * w, h);
+        f32x4 wb40, wb41;                                                          // linearback's k block 4 (fp32 tile): only k < 16 is live
+        {
+            const f32x4* p = reinterpret_cast<const f32x4*>(kb.back32) + ((size_t)(w * 5 + 4) * 4) * 64 + lane;
+            wb40 = p[0];
+            wb41 = p[64];
+        }
+        GAT8_BAR(9);
+        // ---- step 10: linearback's k tail (channels 128..143 <- the hop-2 features), exact fp32 products
+        f32x16 tl = bback, tl2 = zero16();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tl = GATOR_MFMA(wb40[j], f1[j], tl);
+            tl2 = GATOR_MFMA(wb41[j], f1[4 + j], tl2);
+        }
+        const f32x16 n2w = load_chanvec_T(vec, V_N2W + 32 * w, h), n2b = load_chanvec_T(vec, V_N2B + 32 * w, h);
+        GAT8_BAR(10);
+        // ---- step 11: residual
+        xw += (load_block(R1w, lane) + tl) + tl2;
+        store_block(X + w * kTile, lane, xw);
+        GAT8_BAR(11);
+        // ---- step 12: Y2 = LN2(x)
+        x3_store(A + w * kTileX3, lane, x3_split(ln_own(X, xw, n2w, n2b, lane)));
+        GAT8_BAR(12);
+        // ---- steps 13-17: MLP hidden blocks 4w + j: bias, GELU, split (modules.py:188-196)
+        f32x16 fb0 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 0), h), fb1 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 1), h);
+        GAT8_BAR(13);
+        {
+            f32x16 hd = load_block(R0w, lane) + fb0;
+            gelu_tile8(hd);
+            x3_store(Bq + (3 * w + 0) * kTileX3, lane, x3_split(hd));
+        }
+        fb0 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 2), h);
+        GAT8_BAR(14);
+        {
+            f32x16 hd = load_block(R1w, lane) + fb1;
+            GAT8_SUB(0);
+            gelu_tile8(hd);
+            GAT8_SUB(1);
+            const X3 sp = x3_split(hd);
+            GAT8_SUB(2);
+            x3_store(Bq + (3 * w + 1) * kTileX3, lane, sp);
+            GAT8_SUB(3);
+        }
+        fb1 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 3), h);
+        GAT8_BAR(15);
+        {
+            f32x16 hd = load_block(R0w, lane) + fb0;
+            gelu_tile8(hd);
+            x3_store(Bq + (3 * w + 2) * kTileX3, lane, x3_split(hd));
+        }
+        GAT8_BAR(16);
+        {
+            f32x16 hd = load_block(R1w, lane) + fb1;
+            gelu_tile8(hd);
+            x3_store(A + w * kTileX3, lane, x3_split(hd));                         // (Y2 is dead: fc1 finished before barrier 16)
+        }
+        const f32x16 bfc2 = load_chanvec_T(vec, V_FC2B + 32 * w, h);
+        GAT8_BAR(17);
+        // ---- steps 18-21: the four partial sums of fc2, residual
+        f32x16 c01 = load_block(R0w, lane) + bfc2;
+        // L2 warm-up (the helpers idle through the fc2 steps).  Between two launches of this kernel the rest of the forward moves
+        // ~1 GB, so the weights start in HBM; all workgroups of an XCD walk them in step, so every tile would be an HBM-latency
+        // miss for all of them at once (measured on the skeleton: 120 -> 140 us with cold weights).  Each workgroup pulls its
+        // 1/n-th of the NEXT block's four streams into its XCD's L2 one block ahead, and this helper's share of that block's tables.
+        const bool warm = bi + 1 < kDepth && a.pf_loads > 0;
+        const float* dummy = lds + kDummy + w * 256;
+        const Gat8Blk& nx = a.blk[bi + 1 < kDepth ? bi + 1 : bi];
+        if (warm) {
+            // one dword per 128-byte line: a wave instruction touches 64 lines = 8 KiB (an LDS-DMA instruction costs the issuing wave
+            // 60-180 cycles whatever it moves, so 1 KiB contiguous copies would eat the idle steps: 30 instructions against 4)
+            const char* wsrc = reinterpret_cast<const char*>(a.wstream + ((size_t)w * kWaveTiles + (size_t)(bi + 1) * kBlkTiles) * kTileX3);
+            const int share = a.pf_loads * 8192, first = ((b >> 3) % a.pf_n) * share, lim = kBlkTiles * kTileX3 * 4 - 128;
+            for (int i = 0; i < a.pf_loads; ++i)
+                glds4(reinterpret_cast<const float*>(wsrc + min(first + i * 8192 + lane * 128, lim)), dummy);
+        }
+        GAT8_BAR(18);
+        c01 += load_block(R1w, lane);
+        if (warm) {                                  // this helper's share of the next block's tables and vectors, one lane per line
+            const int l32 = lane & 31;
+            glds4(h == 0 ? nx.mdT + (size_t)w * kTile + l32 * 32 : nx.mc + (size_t)w * kTile + l32 * 32, dummy);
+            if (w == 0) glds4(nx.vecs + lane * 32, dummy);
+            if (w == 1) glds4(h == 0 ? nx.aoffT + l32 * 32 : nx.f1b + l32 * 32, dummy);
+            glds4(nx.back32 + (size_t)(w * 5 + 4) * kTile + (lane & 15) * 32, dummy);
+        }
+        GAT8_BAR(19);
+        f32x16 c23 = load_block(R0w, lane);
+        // LayerNorm weights of what follows: the next block's norm1, or the encoder's final norm
+        const bool last = bi + 1 == kDepth;
+        const float* nvec = last ? a.norm_w : a.blk[bi + 1 < kDepth ? bi + 1 : bi].vecs + V_N1W;
+        const float* nvecb = last ? a.norm_b : a.blk[bi + 1 < kDepth ? bi + 1 : bi].vecs + V_N1B;
+        const f32x16 nw = load_chanvec_T(nvec, 32 * w, h), nb = load_chanvec_T(nvecb, 32 * w, h);
+        GAT8_BAR(20);
+        c23 += load_block(R1w, lane);
+        xw += c01 + c23;
+        store_block(X + w * kTile, lane, xw);
+        if (a.blk_tap && tok < J) {          // debug tap (off in timed runs): this wave's channel block of the block output
+            float* dst = a.blk_tap + (((size_t)bi * a.tapB + b) * J + tok) * kC + 32 * w + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v4[j] = xw[4 * g + j];
+                *reinterpret_cast<f32x4*>(dst + 8 * g) = v4;
+            }
+        }
+        GAT8_BAR(21);
+        // ---- step 22: Y = LN1(x) for the next block; after the last block LN -> GELU -> feat (GAT.py:148-150)
+        {
+            f32x16 y = ln_own(X, xw, nw, nb, lane);
+            if (!last) {
+                x3_store(A + w * kTileX3, lane, x3_split(y));
+            } else {
+                gelu_tile8(y);
+                if (tok < J) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v4[j] = y[4 * g + j];
+                        *reinterpret_cast<f32x4*>(a.feat + ((size_t)b * J + tok) * kC + 32 * w + 8 * g + 4 * h) = v4;
+                    }
+                }
+            }
+        }
+        GAT8_BAR(22);
+    }
+}
+
+// one workgroup per destination tile: dst tile i <- src tile idx[i]  (6 KiB = 384 x 16 B)
+__global__ void k_gather_tiles(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst) {
+    const f32x4* s = reinterpret_cast<const f32x4*>(src + (size_t)idx[blockIdx.x] * kTileX3);
+    f32x4* d = reinterpret_cast<f32x4*>(dst + (size_t)blockIdx.x * kTileX3);
+    for (int e = threadIdx.x; e < kTileX3 / 4; e += blockDim.x) d[e] = s[e];
+}
+
+}  // namespace
+
+constexpr size_t kGat8Lds = (size_t)kGat8LdsFloats * sizeof(float);
+
+int gat8_prepare_device() {
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    return GATOR_OK;
+}
+
+// The per-wave weight streams: the X3 tile grids of fused_create_gat (gxbuf, tile-for-tile image of gbuf from gblk[0].qkv on)
+// re-ordered into the order product wave w consumes them, block after block.
+int gat8_build_stream(FusedState* f, void* stream) {
+    if (!f->gat_x3 || !f->gxbuf) return GATOR_OK;
+    std::vector<int> idx((size_t)4 * kWaveTiles + kNT, 0);
+    auto tile_of = [&](const float* grid) { return (int)((grid - f->gblk[0].qkv) / kTile); };
+    for (int w = 0; w < 4; ++w) {
+        int* o = idx.data() + (size_t)w * kWaveTiles;
+        for (int bi = 0; bi < kDepth; ++bi) {
+            const GatBlockPk& p = f->gblk[bi];
+            const int qkv = tile_of(p.qkv), w0 = tile_of(p.w0), w1 = tile_of(p.w1), proj = tile_of(p.proj), lin0 = tile_of(p.lin0), lin1 = tile_of(p.lin1),
+                      back = tile_of(p.back), fc1 = tile_of(p.fc1), fc2 = tile_of(p.fc2);
+            for (int kb = 0; kb < 4; ++kb) *o++ = qkv + (w * 4 + kb);                  // q
+            for (int kb = 0; kb < 4; ++kb) *o++ = qkv + ((4 + w) * 4 + kb);            // k
+            for (int kb = 0; kb < 4; ++kb) *o++ = qkv + ((8 + w) * 4 + kb);            // v
+            for (int kb = 0; kb < 4; ++kb) *o++ = w0 + (w * 4 + kb);                   // MGCN W[0]
+            for (int kb = 0; kb < 4; ++kb) *o++ = w1 + (w * 4 + kb);                   // MGCN W[1]
+            for (int kb = 0; kb < 4; ++kb) *o++ = proj + (w * 4 + kb);                 // attention proj
+            for (int kb = 0; kb < 4; ++kb) *o++ = lin0 + (w * 4 + kb);                 // X_Feat linears[0]
+            *o++ = lin1 + w;                                                           // X_Feat linears[1], k block w
+            for (int kb = 0; kb < 4; ++kb) *o++ = back + (w * 5 + kb);                 // linearback, k < 128
+            for (int j = 0; j < 4; ++j)
+                for (int kb = 0; kb < 4; ++kb) *o++ = fc1 + ((4 * w + j) * 4 + kb);    // fc1, hidden block 4w + j
+            for (int u = 0; u < 4; ++u)
+                for (int wq = 0; wq < 4; ++wq) *o++ = fc2 + (w * 16 + 4 * wq + u);     // fc2, hidden blocks {4w' + u}
+        }
+        if (o - idx.data() != (ptrdiff_t)(w + 1) * kWaveTiles) return fail(GATOR_EINVAL, "gat8_build_stream: tile count");
+    }
+    int* d_idx = nullptr;
+    GATOR_HIP_CHECK(hipMalloc(&d_idx, idx.size() * sizeof(int)));
+    GATOR_HIP_CHECK(hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+    GATOR_HIP_CHECK(hipMalloc(&f->g8stream, (size_t)kStreamFloats * sizeof(float)));
+    k_gather_tiles<<<(unsigned)idx.size(), 128, 0, (hipStream_t)stream>>>(f->gxbuf, d_idx, f->g8stream);
+    GATOR_HIP_CHECK(hipGetLastError());
+    GATOR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    GATOR_HIP_CHECK(hipFree(d_idx));
+    return GATOR_OK;
+}
+
+// feat only (the lifter and the MDR joint tokens are the batched launches of gat_tail.hip)
+int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total, int tap_row0) {
+    Gat8Args a;
+    const Weights& w = c->w;
+    a.B = B; a.J = c->J; a.pose2d = pose2d;
+    a.gl0_W = w.gl0_W; a.gl0_b = w.gl0_b; a.gn_w = w.gn_w; a.gn_b = w.gn_b; a.gl3_p = f->g_gl3; a.gl3_b = w.gl3_b; a.posT = f->g_posT;
+    a.biasT = f->g_biasT; a.m1T = f->g_m1T; a.m2T = f->g_m2T;
+    a.norm_w = w.norm_w; a.norm_b = w.norm_b;
+    a.wstream = f->g8stream;
+    for (int i = 0; i < kDepth; ++i) {
+        const GatBlockPk& p = f->gblk[i];
+        a.blk[i] = Gat8Blk{p.back, p.mc, p.mdT, p.aoffT, p.f1b, f->g_vecs + (size_t)i * 2048};
+    }
+    a.feat = feat;
+    a.blk_tap = nullptr;
+    a.tapB = B;
+    if (c->block_taps) {
+        const int Bt = B_total > 0 ? B_total : B;
+        int rc = gat_ensure_blk_tap(c, f, Bt);
+        if (rc) return rc;
+        a.blk_tap = f->blk_tap + (size_t)tap_row0 * c->J * kC;
+        a.tapB = Bt;
+    }
+    static const bool l2warm = [] { const char* e = getenv("GATOR_GAT_L2WARM"); return !(e && atoi(e) == 0); }();     // default on; =0 for A/B
+    a.pf_n = std::min(32, (B + 7) / 8);                  // workgroups b and b + 8 share an XCD (round-robin dispatch; speed only)
+    a.pf_loads = l2warm ? (kBlkTiles * kTileX3 * 4 / a.pf_n + 8191) / 8192 : 0;       // 8 KiB (64 lines) per instruction
+#ifdef GATOR_DIAG
+    a.stamps = nullptr;
+    a.dbg = getenv("GATOR_GAT8_DBG") ? atoi(getenv("GATOR_GAT8_DBG")) : 0;
+    static const bool want_stamps = getenv("GATOR_GAT_STAMPS") != nullptr;
+    constexpr int kSt = 2 * kDepth * 23 * 2 + kDepth * 8;
+    if (want_stamps) {
+        GATOR_HIP_CHECK(hipMalloc(&a.stamps, kSt * sizeof(unsigned long long)));
+        GATOR_HIP_CHECK(hipMemset(a.stamps, 0, kSt * sizeof(unsigned long long)));
+    }
+#endif
+    k_gat8<<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    GATOR_HIP_CHECK(hipGetLastError());
+#ifdef GATOR_DIAG
+    if (a.stamps) {     // diagnostic build: synchronous read-back; blocks 1..5 averaged (block 0 carries the cold start)
+        std::vector<unsigned long long> hs(kSt);
+        GATOR_HIP_CHECK(hipMemcpy(hs.data(), a.stamps, kSt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        GATOR_HIP_CHECK(hipFree(a.stamps));
+        double tot[2] = {0, 0};
+        fprintf(stderr, "[k_gat8 stamps, wg0, B=%d] cycles per step, mean of blocks 1-5: step | product work wait | helper work wait\n", B);
+        for (int n = 0; n < 23; ++n) {
+            double v[4] = {0, 0, 0, 0};
+            for (int role = 0; role < 2; ++role)
+                for (int bi = 1; bi < kDepth; ++bi)
+                    for (int k = 0; k < 2; ++k) v[role * 2 + k] += (double)hs[(((size_t)role * kDepth + bi) * 23 + n) * 2 + k] / (kDepth - 1);
+            fprintf(stderr, "  %2d | %7.0f %7.0f | %7.0f %7.0f\n", n, v[0], v[1], v[2], v[3]);
+            tot[0] += v[0] + v[1]; tot[1] += v[2] + v[3];
+        }
+        fprintf(stderr, "  per block: product %.0f, helper %.0f cycles\n", tot[0], tot[1]);
+        fprintf(stderr, "  helper sub-stamps of step 15 (block 1), cycles since the barrier:");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %llu", hs[(size_t)2 * kDepth * 23 * 2 + 1 * 8 + k]);
+        fprintf(stderr, "\n");
+    }
+#endif
+    return GATOR_OK;
+}
+
+}  // namespace gator

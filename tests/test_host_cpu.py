@@ -82,3 +82,23 @@ def test_bad_configuration_is_rejected():
         models.GAT.get_model(17, 256, 4, graph_adj=[np.eye(17)], J_regressor=np.zeros((17, 6890), np.float32), base_data={})
     with pytest.raises(ValueError):
         models.GAT.get_model(24, 128, 6, graph_adj=[np.eye(24)], J_regressor=np.zeros((24, 6890), np.float32), base_data={})
+
+
+def test_gat8_roles_keep_the_same_barrier_sequence():
+    """csrc/gat_roles.hip: the product waves and the helper waves of k_gat8 run disjoint branches of one kernel that meet at
+    numbered workgroup barriers; a barrier that only one role executes would hang the GPU.  Both branches must name exactly the
+    sequence 0, 1 .. 22, each number once and in order."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gator_amd', 'csrc', 'gat_roles.hip')).read()
+    body = src[src.index('void k_gat8('):src.index('__global__ void k_gather_tiles')]
+    body = re.sub(r'#ifdef GATOR_DIAG.*?#endif', '', body, flags=re.S)       # (the diagnostic library's stamps / experiments)
+    head, rest = body.split('product waves ====', 1)
+    product, helper = rest.split('helper waves ====', 1)
+    assert 'GAT8_BAR' not in head                              # the embedding uses plain __syncthreads() in uniform code
+    want = list(range(23))
+    for role, text in (('product', product), ('helper', helper)):
+        got = [int(n) for n in re.findall(r'GAT8_BAR\((\d+)\)', text)]
+        assert got == want, (role, got)
+    # and neither role leaves its branch early: one `return` (the product waves', after their last barrier)
+    assert product.count('return;') == 1 and helper.count('return') == 0

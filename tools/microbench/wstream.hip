@@ -116,6 +116,25 @@ static float* g_out;
 static f32x4* g_w;
 static int g_nwg = 256;
 
+// the same launch after 1 GiB of unrelated stores (the weights are then neither in an L2 nor in the Infinity Cache): median of 7
+static char* g_flush = nullptr;
+template <typename F> double time_cold_us(F launch) {
+    if (!g_flush) hipMalloc(&g_flush, (size_t)1 << 30);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    std::vector<float> ts;
+    for (int rep = 0; rep < 7; ++rep) {
+        hipMemsetAsync(g_flush, rep, (size_t)1 << 30, 0);
+        hipEventRecord(a);
+        launch();
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        ts.push_back(ms * 1000.f);
+    }
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
 template <typename F> double time_us(F launch) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -137,7 +156,7 @@ template <typename F> double time_us(F launch) {
 // Two roles in one workgroup of 8 waves: waves 0-3 stream weights (NT tiles in flight in registers) and issue the MFMAs of one
 // 4-tile unit per step with the activation operand re-read from LDS, then park the raw accumulator in LDS; waves 4-7 read the
 // previous step's raw tile, run NV VALU instructions on it and write a 6 KiB operand tile back.  One workgroup barrier per step.
-template <int NT, int NV>
+template <int NT, int NV, int WM>
 __global__ __launch_bounds__(512, 2) void k_roles(const f32x4* __restrict__ W, float* out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -147,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void k_roles(const f32x4* __restrict__ W, f
     if (wave < 4) {
         f32x4 buf[NT][6];
         auto ld = [&](int i, f32x4(&dst)[6]) {
-            const f32x4* p = W + ((size_t)(i * 4 + wave) * 6) * 64 + lane;
+            const f32x4* p = W + ((size_t)(WM ? wave * (per + 8) + i : i * 4 + wave) * 6) * 64 + lane;      // WM: one contiguous stream per wave
 #pragma unroll
             for (int k = 0; k < 6; ++k) dst[k] = p[k * 64];
         };
@@ -209,13 +228,14 @@ __global__ __launch_bounds__(512, 2) void k_roles(const f32x4* __restrict__ W, f
         if (keep == 1.f) out[0] = keep;
     }
 }
-template <int NT, int NV> void run_roles() {
+template <int NT, int NV, int WM = 0> void run_roles() {
     const size_t ldsb = (4 * 1536 + 8 * 1024) * 4;
-    hipFuncSetAttribute((const void*)k_roles<NT, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    const double us = time_us([&] { k_roles<NT, NV><<<g_nwg, 512, ldsb>>>(g_w, g_out); });
+    hipFuncSetAttribute((const void*)k_roles<NT, NV, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    const double us = time_us([&] { k_roles<NT, NV, WM><<<g_nwg, 512, ldsb>>>(g_w, g_out); });
     const double bytes = (double)kTiles * 6 * 1024;
-    printf("roles 4 stream+MFMA waves (%d tiles in flight each) + 4 helper waves (%3d VALU per step), barrier per 4-tile unit : %7.1f us  %6.1f GB/s/CU\n",
-           NT, NV, us, bytes / us * 1e-3);
+    const double cold = time_cold_us([&] { k_roles<NT, NV, WM><<<g_nwg, 512, ldsb>>>(g_w, g_out); });
+    printf("roles 4 stream+MFMA waves (%d tiles in flight each, %s) + 4 helper waves (%3d VALU per step), barrier per 4-tile unit : %7.1f us  %6.1f GB/s/CU | weights cold: %7.1f us\n",
+           NT, WM ? "stream per wave" : "tiles interleaved", NV, us, bytes / us * 1e-3, cold);
     fflush(stdout);
 }
 
@@ -257,6 +277,7 @@ int main(int argc, char** argv) {
     run_reg<4, 6, 4, 12>(); run_reg<4, 4, 8, 12>(); run_dma<4, 8, 4, 12>(); run_dma<4, 4, 8, 12>();
     printf("-- two roles\n");
     run_roles<3, 0>(); run_roles<3, 300>(); run_roles<5, 0>(); run_roles<5, 300>(); run_roles<5, 600>(); run_roles<6, 300>();
+    run_roles<5, 0, 1>(); run_roles<5, 300, 1>();
     printf("-- MFMA only reference: 1584 x 12 MFMAs over 4 / 8 waves = %.1f us at 2.1 GHz if issue-bound\n", 1584.0 * 12 * 32 / 4 / 2100.0);
     return 0;
 }
