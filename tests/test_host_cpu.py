@@ -101,4 +101,4 @@ def test_gat8_roles_keep_the_same_barrier_sequence():
         got = [int(n) for n in re.findall(r'GAT8_BAR\((\d+)\)', text)]
         assert got == want, (role, got)
     # and neither role leaves its branch early: one `return` (the product waves', after their last barrier)
-    assert product.count('return;') == 1 and helper.count('return') == 0
+    assert product.count('return;') == 1 and helper.count('return;') == 0

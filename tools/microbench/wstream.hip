@@ -10,9 +10,14 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#include "x3_common.h"
+using gator::X3; using gator::x3_split; using gator::x3_store; using gator::pk_fma;
+#if 0
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#endif
+using gator::f32x16; using gator::f32x4; using gator::f32x2; using gator::bf16x8;
 
 constexpr int kTiles = 1584;
 
@@ -153,11 +158,44 @@ template <typename F> double time_us(F launch) {
     return ts[ts.size() / 2];
 }
 
+
+__device__ __forceinline__ void gelu_tile8(f32x16& v) {
+    f32x2 x[8], t[8], r[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        x[p][0] = v[2 * p]; x[p][1] = v[2 * p + 1];
+        const f32x2 a = x[p] * 0.70710678118654752440f;
+        t[p][0] = fminf(fabsf(a[0]), 4.3f);
+        t[p][1] = fminf(fabsf(a[1]), 4.3f);
+    }
+    const float c[8] = {4.369443071e-04f, -1.460381877e-03f, -8.251648338e-04f, 2.830188636e-02f, -1.485066472e-01f, -9.184098145e-01f,
+                        -1.627909326e+00f, -9.999999783e-01f};
+#pragma unroll
+    for (int p = 0; p < 8; ++p) r[p] = pk_fma(f32x2(-4.435285315e-05f), t[p], f32x2(c[0]));
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) r[p] = pk_fma(r[p], t[p], f32x2(c[k]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { r[p][0] = __builtin_amdgcn_exp2f(r[p][0]); r[p][1] = __builtin_amdgcn_exp2f(r[p][1]); }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const f32x2 up = 1.0f - r[p];
+        f32x2 phi;
+        phi[0] = x[p][0] < 0.f ? r[p][0] : up[0];
+        phi[1] = x[p][1] < 0.f ? r[p][1] : up[1];
+        const f32x2 y = x[p] * phi;
+        v[2 * p] = y[0]; v[2 * p + 1] = y[1];
+    }
+}
+
 // Two roles in one workgroup of 8 waves: waves 0-3 stream weights (NT tiles in flight in registers) and issue the MFMAs of one
 // 4-tile unit per step with the activation operand re-read from LDS, then park the raw accumulator in LDS; waves 4-7 read the
 // previous step's raw tile, run NV VALU instructions on it and write a 6 KiB operand tile back.  One workgroup barrier per step.
-template <int NT, int NV, int WM>
-__global__ __launch_bounds__(512, 2) void k_roles(const f32x4* __restrict__ W, float* out) {
+template <int NT, int NV, int WM, int PRIO = 0>
+__global__ __launch_bounds__(512, 2) void k_roles(const f32x4* __restrict__ W, float* out, unsigned long long* cyc = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* OP = lds;                     // 4 operand tiles of 6 KiB
@@ -174,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void k_roles(const f32x4* __restrict__ W, f
         for (int s = 0; s < NT; ++s) ld(s, buf[s]);
         asm volatile("" ::: "memory");
         int i = 0;
+        unsigned long long p_go = __builtin_readcyclecounter();
         for (int u = 0; u < units; u += NT) {          // NT units per trip so that slot indices stay compile-time
 #pragma unroll
             for (int uu = 0; uu < NT; ++uu) {
@@ -201,12 +240,15 @@ __global__ __launch_bounds__(512, 2) void k_roles(const f32x4* __restrict__ W, f
                     reinterpret_cast<f32x4*>(r)[g * 64 + lane] = t;
                 }
                 __syncthreads();
+                if (cyc && lane == 0 && blockIdx.x == 0 && wave == 0) { const unsigned long long now = __builtin_readcyclecounter(); cyc[256 + u + uu] = now - p_go; p_go = now; }
             }
         }
     } else {
         const int hw = wave - 4;
         float keep = 0.f;
+        if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
         for (int u = 0; u < (units + NT - 1) / NT * NT; ++u) {
+            const unsigned long long t_go = __builtin_readcyclecounter();
             if (u > 0) {
                 const float* r = RAW + (((u - 1) & 1) * 4 + hw) * 1024;
                 f32x4 t[4];
@@ -215,27 +257,46 @@ __global__ __launch_bounds__(512, 2) void k_roles(const f32x4* __restrict__ W, f
                 float v[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) for (int j = 0; j < 4; ++j) v[4 * g + j] = t[g][j];
+                if (NV >= 0) {
 #pragma unroll
-                for (int n = 0; n < NV; ++n) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[n & 15]) : "v"(keep));
-                f32x4 o[6];
+                    for (int n = 0; n < NV; ++n) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[n & 15]) : "v"(keep));
+                    f32x4 o[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) for (int j = 0; j < 4; ++j) o[k][j] = v[(4 * k + j) & 15] * 1e-30f;
+                    for (int k = 0; k < 6; ++k) for (int j = 0; j < 4; ++j) o[k][j] = v[(4 * k + j) & 15] * 1e-30f;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) reinterpret_cast<f32x4*>(OP + hw * 1536 + k * 256)[lane] = o[k];
+                    for (int k = 0; k < 6; ++k) reinterpret_cast<f32x4*>(OP + hw * 1536 + k * 256)[lane] = o[k];
+                } else {            // the real thing: GELU + exact three-way split + operand tile store (gat_roles.hip, steps 14-17)
+                    f32x16 hd;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) hd[q] = v[q] * 1e-3f + 0.25f;
+                    if (NV == -1 || NV == -2) gelu_tile8(hd);
+                    if (NV == -1 || NV == -3) x3_store(OP + hw * 1536, lane, x3_split(hd));
+                    else keep += hd[3];
+                }
+                if (cyc && lane == 0 && blockIdx.x == 0 && hw == 0) { const unsigned long long now = __builtin_readcyclecounter(); cyc[u] = now - t_go; }
             }
             __syncthreads();
         }
         if (keep == 1.f) out[0] = keep;
     }
 }
-template <int NT, int NV, int WM = 0> void run_roles() {
+template <int NT, int NV, int WM = 0, int PRIO = 0> void run_roles() {
     const size_t ldsb = (4 * 1536 + 8 * 1024) * 4;
-    hipFuncSetAttribute((const void*)k_roles<NT, NV, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    const double us = time_us([&] { k_roles<NT, NV, WM><<<g_nwg, 512, ldsb>>>(g_w, g_out); });
+    hipFuncSetAttribute((const void*)k_roles<NT, NV, WM, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    const double us = time_us([&] { k_roles<NT, NV, WM, PRIO><<<g_nwg, 512, ldsb>>>(g_w, g_out); });
     const double bytes = (double)kTiles * 6 * 1024;
-    const double cold = time_cold_us([&] { k_roles<NT, NV, WM><<<g_nwg, 512, ldsb>>>(g_w, g_out); });
-    printf("roles 4 stream+MFMA waves (%d tiles in flight each, %s) + 4 helper waves (%3d VALU per step), barrier per 4-tile unit : %7.1f us  %6.1f GB/s/CU | weights cold: %7.1f us\n",
-           NT, WM ? "stream per wave" : "tiles interleaved", NV, us, bytes / us * 1e-3, cold);
+    static unsigned long long* d_cyc = nullptr;
+    if (!d_cyc) hipMalloc(&d_cyc, 512 * 8);
+    hipMemset(d_cyc, 0, 512 * 8);
+    k_roles<NT, NV, WM, PRIO><<<g_nwg, 512, ldsb>>>(g_w, g_out, d_cyc);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> hc(512);
+    hipMemcpy(hc.data(), d_cyc, 512 * 8, hipMemcpyDeviceToHost);
+    std::sort(hc.begin() + 10, hc.begin() + 90); std::sort(hc.begin() + 266, hc.begin() + 346);
+    printf("   [in-kernel, wg 0: helper work per step %llu cycles, product step (incl. barrier) %llu cycles]\n", hc[50], hc[306]);
+    const double cold = time_cold_us([&] { k_roles<NT, NV, WM, PRIO><<<g_nwg, 512, ldsb>>>(g_w, g_out); });
+    printf("helper prio %d: roles 4 stream+MFMA waves (%d tiles in flight each, %s) + 4 helper waves (%3d VALU per step), barrier per 4-tile unit : %7.1f us  %6.1f GB/s/CU | weights cold: %7.1f us\n",
+           PRIO, NT, WM ? "stream per wave" : "tiles interleaved", NV, us, bytes / us * 1e-3, cold);
     fflush(stdout);
 }
 
@@ -278,6 +339,9 @@ int main(int argc, char** argv) {
     printf("-- two roles\n");
     run_roles<3, 0>(); run_roles<3, 300>(); run_roles<5, 0>(); run_roles<5, 300>(); run_roles<5, 600>(); run_roles<6, 300>();
     run_roles<5, 0, 1>(); run_roles<5, 300, 1>();
+    printf("-- helper = GELU + split + store (-1), GELU only (-2), split + store only (-3)\n");
+    run_roles<5, -1, 1>(); run_roles<5, -3, 1>();
+    run_roles<5, -1, 1, 1>(); run_roles<5, -1, 1, 3>(); run_roles<5, 300, 1, 3>(); run_roles<5, -3, 1, 3>();
     printf("-- MFMA only reference: 1584 x 12 MFMAs over 4 / 8 waves = %.1f us at 2.1 GHz if issue-bound\n", 1584.0 * 12 * 32 / 4 / 2100.0);
     return 0;
 }
