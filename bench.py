@@ -56,6 +56,30 @@ STAGE_BYTES = {'mdr_layer0': _VF + _QKV, 'mdr_layer': 2 * (_VF + _QKV), 'mdr_att
                'upsample': 3 * 431 * 2 * 3 + 6890 * 3 * 4, 'gat': 136 + 17 * 128 * 4 + 204 + 12 * 4096}
 STAGE_KERNEL = {'gat': 'k_gat', 'mdr_layer0': 'k_mdr_layer<0,', 'mdr_layer': 'k_mdr_layer<1,',
                 'mdr_attn_head': 'k_mdr_layer<2,', 'upsample': 'k_upsample_x3'}
+# BASELINE.json `configs`, 1-based as VERDICT.md numbers them (config 1 is the reference's own CPU demo): per-GPU presets
+BASELINE_CONFIGS = {
+    2: dict(batch=256, joints=17, precision='f32', mode='gather', gpus=1,
+            name='configs[1]: B=256 synthetic Human3.6M 17-joint poses, GAT+MDR forward, 1xMI355X fp32'),
+    3: dict(batch=2048, joints=19, precision='bf16', mode='gather', gpus=1,
+            name='configs[2]: B=2048 COCO 19-joint poses, full GATOR forward bf16, 1xMI355X (MFMA vertex regressor)'),
+    4: dict(batch=1024, joints=17, precision='f32', mode='gather', gpus=8,
+            name='configs[3]: B=8192 Human3.6M poses sharded over 8xMI355X (1024 per GPU), RCCL all-gather of 6890x3 vertices over xGMI'),
+    5: dict(batch=1024, joints=19, precision='f32', mode='eval', gpus=8,
+            name='configs[4]: 3DPW path_3dpw graph (19 input joints), 8xMI355X end-to-end inference with MPJPE/PA-MPJPE eval (all-reduce only)'),
+}
+
+
+def baseline_config_of(a, world):
+    """Which BASELINE config a run is (exactly, or as a scaled-down instance of it), for the line's `config.baseline_config`."""
+    if a.config:
+        c = BASELINE_CONFIGS[a.config]
+        exact = (a.batch, a.joints, a.precision, a.mode, world) == (c['batch'], c['joints'], c['precision'], c['mode'], c['gpus'])
+        return ('config %d = %s' % (a.config, c['name'])) + ('' if exact else
+                ' -- run here with batch %d per GPU on %d GPU(s)' % (a.batch, world))
+    for k, c in BASELINE_CONFIGS.items():
+        if (a.batch, a.joints, a.precision, a.mode) == (c['batch'], c['joints'], c['precision'], c['mode']) and (world == c['gpus'] or c['gpus'] == 1):
+            return ('config %d = %s' % (k, c['name'])) + ('' if world == c['gpus'] else ' -- weak-scaled to %d GPUs (same batch per GPU)' % world)
+    return 'none (free-form run: batch %d per GPU, J=%d, %s, mode %s, %d GPU(s))' % (a.batch, a.joints, a.precision, a.mode, world)
 
 
 def parse():
@@ -64,15 +88,24 @@ def parse():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--blocks', type=int, default=11, help='timed blocks of --steps steps each; the median block is reported')
-    ap.add_argument('--batch', type=int, default=256, help='samples per GPU per step')
-    ap.add_argument('--joints', type=int, default=17)
+    ap.add_argument('--config', type=int, default=0, choices=[0, 2, 3, 4, 5],
+                    help='BASELINE.json preset (1-based as in VERDICT.md): 2 = B=256 J=17 fp32, 3 = B=2048 J=19 bf16, 4 = 1024 per GPU J=17 + '
+                         'all-gather (8 GPUs = B 8192), 5 = evaluation mode J=19 (all-reduce only); --batch/--joints/--precision/--mode override')
+    ap.add_argument('--batch', type=int, default=None, help='samples per GPU per step (default 256, or the preset)')
+    ap.add_argument('--joints', type=int, default=None)
     ap.add_argument('--impl', default=os.environ.get('GATOR_AMD_IMPL', 'fused'))
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'], help='bf16: vertex regressor on bf16 MFMA (config 3)')
-    ap.add_argument('--mode', default='gather', choices=['gather', 'eval'],
+    ap.add_argument('--precision', default=None, choices=['f32', 'bf16'], help='bf16: vertex regressor on bf16 MFMA (config 3)')
+    ap.add_argument('--mode', default=None, choices=['gather', 'eval'],
                     help='N>1: all-gather the vertices (config 4) or the all-reduce-only evaluation mode (config 5)')
     ap.add_argument('--subbatch-variant', action='store_true', help='also time the sub-batch-streams=2 mode (extra key)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    return ap.parse_args()
+    ap.add_argument('--no-variants', action='store_true', help='skip the A/B variants measured beside the headline (N = 1 only)')
+    a = ap.parse_args()
+    preset = BASELINE_CONFIGS.get(a.config, dict(batch=256, joints=17, precision='f32', mode='gather'))
+    for k in ('batch', 'joints', 'precision', 'mode'):
+        if getattr(a, k) is None:
+            setattr(a, k, preset[k])
+    return a
 
 
 def _free_port():
@@ -156,20 +189,76 @@ def build_model(J, impl, device):
     return m.to(device).eval(), base, alpha
 
 
-def pmc_traffic(stage, B):
-    """HBM-side bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 as the gfx950
-    guide prescribes, + WRITE_SIZE), collected with this same command at B=256; None for other batch sizes / kernels."""
+def pmc_digest(B):
+    """The committed rocprofv3 PMC digest of this same command at B=256 (tools/profile_round.sh + tools/pmc_digest.py), newest
+    round first; None for other batch sizes."""
     if B != 256:
-        return None
-    for name in ('r02_pmc_summary_B256.json', 'r01_pmc_summary_B256.json'):
+        return None, None
+    for name in ('r03_pmc_summary_B256.json', 'r02_pmc_summary_B256.json', 'r01_pmc_summary_B256.json'):
         path = os.path.join(ROOT, 'profiles', name)
-        if not os.path.exists(path):
-            continue
-        want = STAGE_KERNEL.get(stage, '')
-        for row in json.load(open(path)):
-            if row['kernel'].startswith(want) and want:
-                return int((row['fetch_MB_corrected'] + row['write_MB']) * 1048576)
+        if os.path.exists(path):
+            return json.load(open(path)), name
+    return None, None
+
+
+def pmc_row(rows, stage):
+    want = STAGE_KERNEL.get(stage, '')
+    for row in rows or []:
+        if want and row['kernel'].startswith(want):
+            return row
     return None
+
+
+def pmc_traffic(rows, stage):
+    """HBM-side bytes per launch of the stage's kernel: FETCH_SIZE x2 (as the gfx950 guide prescribes) + WRITE_SIZE."""
+    row = pmc_row(rows, stage)
+    if row is None or 'fetch_MB_corrected' not in row:
+        return None
+    return int((row['fetch_MB_corrected'] + row.get('write_MB', 0.0)) * 1048576)
+
+
+def pmc_forward_bytes(rows):
+    """HBM-side bytes of ONE whole forward (every launch of every kernel of a step) from the digest: the figure SURVEY 8(d)'s
+    83 kB per mesh of compulsory traffic is to be compared with.  A step = one launch of the vertex-regressor kernel."""
+    if not rows:
+        return None
+    steps = max([r.get('launches', 0) for r in rows if r['kernel'].startswith('k_upsample')] or [0])
+    if steps <= 0:
+        return None
+    tot = 0.0
+    for r in rows:
+        if 'fetch_MB_corrected' in r:
+            tot += (r['fetch_MB_corrected'] + r.get('write_MB', 0.0)) * 1048576 * r.get('launches', steps) / steps
+    return int(tot)
+
+
+def gpu_clocks(index=0):
+    """Shader / memory clock levels and the power cap of the device as sysfs reports them after the timed region (box-to-box spread of
+    one binary is 280-340k meshes/s: this makes a line comparable).  Read from files: a GPU-initialised process must not start
+    another program on this pool, so no rocm-smi.  None where a file is not readable by this user."""
+    import glob
+    out = {}
+    cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/pp_dpm_sclk'))
+    if not cards:
+        return {'error': 'no /sys/class/drm/card*/device/pp_dpm_sclk'}
+    dev = os.path.dirname(cards[min(index, len(cards) - 1)])
+
+    def levels(name):
+        try:
+            rows = [ln.strip() for ln in open(os.path.join(dev, name)) if ln.strip()]
+        except OSError:
+            return None
+        cur = [r for r in rows if r.endswith('*')]
+        return {'current': cur[0].rstrip('*').strip() if cur else None, 'levels': [r.rstrip('*').strip() for r in rows]}
+
+    out['sclk'], out['mclk'] = levels('pp_dpm_sclk'), levels('pp_dpm_mclk')
+    for key, pat in (('power_cap_w', 'hwmon/hwmon*/power1_cap'), ('power_w', 'hwmon/hwmon*/power1_average'), ('power_input_w', 'hwmon/hwmon*/power1_input')):
+        f = glob.glob(os.path.join(dev, pat))
+        try:
+            out[key] = round(int(open(f[0]).read().strip()) / 1e6, 1) if f else None
+        except (OSError, ValueError):
+            out[key] = None
+    return out
 
 
 def cpu_baseline(model, base, alpha, J):
@@ -309,14 +398,30 @@ def main():
             mflop = STAGE_MFLOP.get(stage, None)
             if mflop is not None and avg_s > 0:
                 ach = mflop * 1e6 * B / avg_s / 1e12
-                traffic = pmc_traffic(stage, B)
+                rows, digest = pmc_digest(B)
+                traffic = pmc_traffic(rows, stage)
                 pipe, peak = stage_pipe(stage, a.impl)
-                alg = STAGE_BYTES.get(stage)
+                designed = STAGE_BYTES.get(stage)
+                fwd_bytes = pmc_forward_bytes(rows)
+                row = pmc_row(rows, stage)
+                executed = None
+                if row and 'mfma_bf16_insts' in row:       # what the matrix pipe really executed per launch (instruction counts from the PMC pass)
+                    executed = (row['mfma_bf16_insts'] + row.get('mfma_f16_insts', 0)) * 32768.0 + row.get('mfma_f32_insts', 0) * 4096.0
                 roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                         'frac': round(ach / peak, 4), 'frac_of_all_bf16x3_ceiling_416.7': round(ach / PEAK_X3_TFLOPS, 4),
-                        'frac_of_fp32_mfma_peak_157.3': round(ach / PEAK_F32_TFLOPS, 4), 'traffic': traffic,
-                        'algorithmic_bytes': int(alg * B) if alg else None,
-                        'traffic_ratio': round(traffic / (alg * B), 3) if (traffic and alg) else None,
+                        # executed MFMA FLOP (all planes, padding included) / live duration / 2.5 PFLOP/s dense 16-bit peak
+                        'frac_of_dense_16bit_peak_2500': round(executed / avg_s / 1e12 / PEAK_BF16_TFLOPS, 4) if executed else None,
+                        'speedup_over_fp32_mfma_roof_157.3': round(ach / PEAK_F32_TFLOPS, 3),
+                        'traffic': traffic,
+                        # the algorithmic bytes of the path are its compulsory HBM traffic, 83 kB per mesh for the WHOLE
+                        # forward; the kernels exchange operand tiles through L2 / Infinity Cache on top of that (counted at the
+                        # L2's memory side, so cache-resident re-reads are included)
+                        'whole_forward_traffic_bytes_per_mesh': int(fwd_bytes / B) if fwd_bytes else None,
+                        'algorithmic_bytes_per_mesh': BYTES_PER_MESH.get(J),
+                        'traffic_ratio': round(fwd_bytes / B / BYTES_PER_MESH[J], 1) if (fwd_bytes and J in BYTES_PER_MESH) else None,
+                        'kernel_designed_operand_bytes': int(designed * B) if designed else None,
+                        'kernel_traffic_over_designed': round(traffic / (designed * B), 3) if (traffic and designed) else None,
+                        'pmc_digest': digest,
                         'avg_launch_ms': round(avg_s * 1e3, 4), 'pipe': pipe,
                         'stages_ms': {k: round(v[0] / v[1], 4) for k, v in prof.items()}}
         if roof is None:   # no per-kernel events available (bring-up path): price the whole forward
@@ -332,7 +437,9 @@ def main():
                 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic',
                 'config': {'workload': 'B=%d synthetic %s poses per GPU, GAT+MDR forward %s%s' % (B, jset, prec, tail),
-                           'batch_per_gpu': B, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world, 'mode': a.mode},
+                           'baseline_config': baseline_config_of(a, world),
+                           'batch_per_gpu': B, 'global_batch': B * world, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world,
+                           'mode': a.mode},
                 'timing': {'blocks': len(dts), 'reported': 'median block',
                            'block_ms': [round(d * 1e3, 3) for d in dts],
                            'min_ms_per_step': round(min(dts) / a.steps * 1e3, 4), 'max_ms_per_step': round(max(dts) / a.steps * 1e3, 4)},
@@ -341,8 +448,36 @@ def main():
                                   'frac_of_split_precision_peak_416.7': round(per_gpu_tf / PEAK_X3_TFLOPS, 4),
                                   'compulsory_bytes_per_mesh': BYTES_PER_MESH.get(J)},
                 'roofline': roof}
+        line['clocks'] = gpu_clocks(local)
         if comm is not None:
             line['comm'] = comm
+        if world == 1 and not a.no_variants and a.impl == 'fused' and a.mode == 'gather':
+            # The same workload, same process, same box, with the library's A/B switches (read when a context is created).  The
+            # headline's 431x431 attention core ROUNDS its operands to two fp16 planes (22 bits; output parity demonstrated in
+            # tests/test_gpu_x3.py); `exact_split` is the build without any rounded operand, `fp32_mfma` every product on the
+            # fp32-input MFMA, `k_gat` the previous one-sample-per-workgroup encoder.
+            variants = {}
+            for vname, env in (('headline, re-measured with the variants\' protocol (5 blocks, later in the run: clocks drift)', {}),
+                               ('exact_split (GATOR_MDR_X3=1)', {'GATOR_MDR_X3': '1'}),
+                               ('fp32_mfma (GATOR_GAT_X3=0 GATOR_MDR_X3=0 GATOR_UPSAMPLE_X3=0)', {'GATOR_GAT_X3': '0', 'GATOR_MDR_X3': '0', 'GATOR_UPSAMPLE_X3': '0'}),
+                               ('k_gat encoder (GATOR_GAT8=0)', {'GATOR_GAT8': '0'})):
+                old = {k: os.environ.get(k) for k in env}
+                os.environ.update(env)
+                try:
+                    mv, _, _ = build_model(J, a.impl, dev)
+                    mv.precision = a.precision
+                    for _ in range(a.warmup):
+                        mv(x)
+                    dv = sorted(block(lambda: mv(x), a.steps)[0] for _ in range(5))[2]
+                    variants[vname] = {'value': round(B * a.steps / dv, 1), 'ms_per_step': round(dv / a.steps * 1e3, 4)}
+                    del mv
+                finally:
+                    for k, v in old.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
+            line['variants'] = variants
         if world == 1 and B >= 128 and a.subbatch_variant:
             # same workload with the library's sub-batch pipelining (two half-batches on two streams; bit-identical results).
             # Reported beside the headline, not as it: concurrent streams make per-kernel durations (and so `roofline`) ambiguous.

@@ -417,6 +417,13 @@ extern "C" int gator_enable_block_taps(gator_ctx* c, int32_t on) {
     return GATOR_OK;
 }
 
+extern "C" int gator_set_encoder(gator_ctx* c, int32_t mode) {
+    if (!c) return fail(GATOR_EINVAL, "gator_set_encoder: null ctx");
+    if (c->impl != GATOR_IMPL_FUSED || !c->fused) return fail(GATOR_EUNSUPPORTED, "gator_set_encoder: fused ctx only");
+    if (mode < GATOR_ENCODER_AUTO || mode > GATOR_ENCODER_TILED) return fail(GATOR_EINVAL, "gator_set_encoder: mode must be -1, 0 or 1");
+    return fused_set_encoder(c, mode);
+}
+
 extern "C" int gator_get_tap(gator_ctx* c, const char* name, float* dst, int64_t capacity, int64_t* count, void* stream) {
     if (!c || !name || !dst) return fail(GATOR_EINVAL, "gator_get_tap: null argument");
     const float* src = nullptr;

@@ -552,6 +552,12 @@ int fused_set_joint_regressor(gator_ctx* c, const int32_t* row, const int32_t* c
     return GATOR_OK;
 }
 
+int fused_set_encoder(gator_ctx* c, int mode) {
+    if (mode == 1 && !c->fused->gat_x3) return fail(GATOR_EUNSUPPORTED, "gator_set_encoder: the sample-tiled encoder needs the split-precision path (GATOR_GAT_X3)");
+    c->fused->gat_tiled = mode;
+    return GATOR_OK;
+}
+
 int fused_forward_joints(gator_ctx* c, const float* pose2d, int B, float* joints, float* pose3d, float* verts, void* stream) {
     FusedState* f = c->fused;
     if (!f || f->jr_nnz == 0) return fail(GATOR_EINVAL, "gator_forward_joints_f32: call gator_set_joint_regressor first");

@@ -23,7 +23,16 @@ it, so it hides behind step k+1's kernels (xGMI is point-to-point, 7 links x ~15
     for the gather) before reading them;
   * the buffers returned by step k are overwritten by the gather of step k+depth, which the side stream starts only after
     everything the CALLING stream had queued when step k+depth was called (wait_stream), i.e. after every read the consumer
-    queued on that stream in between.  A consumer on another stream must synchronise with the calling stream itself."""
+    queued on that stream in between.  A consumer on another stream must synchronise with the calling stream itself;
+  * the backlog is bounded: before step k issues its kernels, the calling stream waits for the collective of step k - depth
+    (the one whose output buffer step k re-uses).  If the gather is slower than the compute, the compute therefore runs at the
+    gather's rate `depth` steps ahead instead of queueing collectives (and the temporaries pinned for them) without limit.
+    `max_inflight` records the largest number of collectives that were ever outstanding (tests assert <= depth).
+
+Encoder choice.  The library picks the GAT encoder kernel from the batch size of each call (gator_set_encoder); the two kernels
+agree to fp32 rounding, not bit for bit.  With more than one rank that would make a sample's last bits depend on how many ranks
+the batch was cut into, so a sharded run pins ONE kernel for all its calls: the one the library would use for the local batch
+(`encoder='auto'` here), or the caller's choice.  Run the single-process reference with the same pin to compare bit for bit."""
 import contextlib
 
 import torch
@@ -31,7 +40,7 @@ import torch
 
 class ShardedForward:
     def __init__(self, model, world_size=1, rank=0, dist=None, micro_batch=None, always_gather=False, mode='gather', depth=2,
-                 metrics_fn=None):
+                 metrics_fn=None, encoder='auto'):
         if mode not in ('gather', 'eval'):
             raise ValueError("mode must be 'gather' or 'eval'")
         self.model, self.world, self.rank, self.dist = model, world_size, rank, dist
@@ -50,6 +59,38 @@ class ShardedForward:
         self._eval_joints = None
         self._last = None                       # (kind, tensors) of the last collective, for comm_only()
         self.last_event = None
+        self._inflight = []                     # completion events (None on the host) of the collectives not yet waited for
+        self.max_inflight = 0
+        if encoder not in ('auto', 'sample', 'tiled'):
+            raise ValueError("encoder must be 'auto', 'sample' or 'tiled'")
+        self.encoder = encoder
+        self._pinned = None
+
+    TILED_MIN_BATCH = 1024                      # the library's own threshold (fused_state.h: gat_tiled_min_batch)
+
+    def _pin_encoder(self, calls_batch):
+        """world > 1: one encoder kernel for every call of this run (see the module docstring)."""
+        if self._pinned is not None or not hasattr(self.model, 'set_encoder'):
+            return
+        want = self.encoder
+        if want == 'auto':
+            if self.world <= 1 and not self.always_gather:
+                self._pinned = 'auto'
+                return
+            want = 'tiled' if calls_batch >= self.TILED_MIN_BATCH else 'sample'
+        self.model.set_encoder(want)
+        self._pinned = want
+
+    def _throttle(self, device):
+        """Before a step queues work: at most `depth` collectives outstanding (the oldest one wrote the buffer this step re-uses)."""
+        while len(self._inflight) >= self.depth:
+            ev = self._inflight.pop(0)
+            if ev is not None:
+                torch.cuda.current_stream(device).wait_event(ev)
+
+    def _issued(self, event):
+        self._inflight.append(event)
+        self.max_inflight = max(self.max_inflight, len(self._inflight))
 
     # ---- shared plan: chunks of the local batch, rotating output buffers ------------------------------------------------
     def _plan(self, B):
@@ -116,6 +157,8 @@ class ShardedForward:
         if self.dist is None or (self.world == 1 and not self.always_gather):
             return self.model(pose2d_shard)
         B, J = pose2d_shard.shape[0], pose2d_shard.shape[1]
+        self._pin_encoder(min(B, self.micro or B))
+        self._throttle(pose2d_shard.device)
         gv, gp = self._buffers(B, J, pose2d_shard.device)
         side, chunks = None, []
         for s, e in self._plan(B):
@@ -126,6 +169,7 @@ class ShardedForward:
         self._last = ('gather', (chunks, B, gv, gp))
         # the compute stream does NOT wait: the next step overlaps this gather
         self.last_event = side.record_event() if side is not None else None
+        self._issued(self.last_event)
         return gv, gp
 
     # ---- mode 'eval' -----------------------------------------------------------------------------------------------------
@@ -166,6 +210,8 @@ class ShardedForward:
         if fused and getattr(self.model, '_jreg', None) is None:
             self.model.set_joint_regressor(self._regressor_dense)
         B = pose2d_shard.shape[0]
+        self._pin_encoder(min(B, self.micro or B))
+        self._throttle(pose2d_shard.device)
         acc = None
         for s, e in self._plan(B):
             if fused:
@@ -182,6 +228,7 @@ class ShardedForward:
             if side is not None:
                 acc.record_stream(side)
                 self.last_event = side.record_event()
+            self._issued(self.last_event if side is not None else None)
             self._last = ('reduce', (acc,))
         return acc
 

@@ -102,6 +102,17 @@ int gator_get_tap(gator_ctx* ctx, const char* name, float* dst, int64_t capacity
  * of the stand-alone gator_gat_forward_f32 aliases the caller's `feat` buffer. */
 int gator_enable_block_taps(gator_ctx* ctx, int32_t on);
 
+/* Encoder policy of a fused ctx.  The six GAT blocks (lib/models/GAT.py:145-147) have two kernels: one workgroup per sample
+ * (bit-identical results whatever the batch size or the position in the batch) and a sample-tiled one for large batches
+ * (7 / 6 samples per workgroup; bit-identical within itself, equal to the first to fp32 rounding).  mode GATOR_ENCODER_AUTO (the
+ * default) picks per call from the batch size, so above 1 024 samples a sample's last bits depend on how the batch was cut;
+ * GATOR_ENCODER_SAMPLE / GATOR_ENCODER_TILED pin one kernel for every call on the ctx - what a sharded run uses so that the
+ * all-gathered result is independent of the number of ranks (gathered == single-GPU, bit for bit). */
+#define GATOR_ENCODER_AUTO (-1)
+#define GATOR_ENCODER_SAMPLE 0
+#define GATOR_ENCODER_TILED 1
+int gator_set_encoder(gator_ctx* ctx, int32_t mode);
+
 /* Measurement hook (bench.py `roofline`): gator_profile_enable(ctx, n) with n >= 1 brackets every stage launch of every
  * n-th forward by a hipEvent pair recorded on the launch stream (n = 0 switches it off).  gator_profile_read synchronises those events and returns, per stage name
  * ('\n'-separated in `names`), the summed duration in ms and the number of launches since the last enable/read. */

@@ -116,6 +116,24 @@ for micro in (None, 10):
         run.wait()
         ok = ok and bool(torch.equal(gv, rv)) and bool(torch.equal(gp, rp))
         prev = (gv, rv)
+    ok = ok and 1 <= run.max_inflight <= run.depth              # bounded backlog of collectives
+    ok = ok and run._pinned == 'sample'                         # one encoder kernel for every call of a multi-rank run
+# evaluation mode (BASELINE config 5): on-device joint regression + error sums, ONE all-reduce of three doubles
+import numpy as np
+jr = synthetic.load_j_regressors()['h36m']
+full = torch.from_numpy(synthetic.synthetic_pose2d(world * n, 17, seed=77)).to(dev)
+tgt = torch.from_numpy(np.random.RandomState(5).randn(world * n, 17, 3).astype(np.float32) * 150).to(dev)
+erun = ShardedForward(m, world, rank, dist, micro_batch=10, mode='eval')
+erun.set_eval(jr, tgt[rank * n:(rank + 1) * n])
+for step in range(3):
+    got = erun.step(full[rank * n:(rank + 1) * n])
+erun.wait()
+single = ShardedForward(m, 1, 0, None, mode='eval')
+single.set_eval(jr, tgt)
+want = single.step(full)
+torch.cuda.synchronize()
+ok = ok and float(got[2]) == world * n and bool(torch.allclose(got, want, rtol=1e-9, atol=0))
+ok = ok and erun.max_inflight <= erun.depth
 # the same gather through the C ABI's own RCCL communicator (gator_allgather_verts); the id travels over torch's object broadcast
 from gator_amd.comm import NativeComm
 def _bcast(b):
@@ -170,3 +188,10 @@ def test_bench_launches_its_own_ranks():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['parallelism'] == 'dp2'
     assert 'comm' in line and line['comm']['collective_ms'] > 0
+    # the BASELINE presets: config 4 (gather) and config 5 (evaluation mode, all-reduce only)
+    for cfg, mode in (('4', 'gather'), ('5', 'eval')):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--config', cfg, '--steps', '2', '--warmup', '1',
+                            '--blocks', '2', '--batch', '96'], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+        assert line['n_gpus'] == 2 and line['config']['mode'] == mode and line['config']['batch_per_gpu'] == 96

@@ -121,4 +121,25 @@ def test_config4_single_process_b8192(monkeypatch):
     assert np.abs(v[idx].cpu().numpy().astype(np.float64) - ref.numpy()).max() * 1e3 <= 1e-3
     vs, ps = m(x[3072:4096].contiguous())                        # rank 3's shard of an 8-way split
     assert torch.equal(vs, v[3072:4096]) and torch.equal(ps, p[3072:4096])     # both run entirely on the tiled encoder
-    del v, v2
+    del v2
+    # What ShardedForward does with 8 ranks x 1 024 samples: ONE pinned encoder for every call (gator_set_encoder), so that ALL eight
+    # shards - whatever their position - reproduce the rows of the single-process batch bit for bit, also for shard sizes at which
+    # the per-call policy would mix the two kernels (8 x 1 000: a single process would run 7 168 tiled + 832 on the per-sample kernel).
+    from gator_amd.parallel import ShardedForward
+    for n in (1024, 1000):
+        for pin in ('tiled', 'sample'):
+            m.set_encoder(pin)
+            xb = x[:8 * n].contiguous()
+            vb, pb = m(xb)
+            for r in range(8):
+                vs, ps = m(xb[r * n:(r + 1) * n].contiguous())
+                assert torch.equal(vs, vb[r * n:(r + 1) * n]) and torch.equal(ps, pb[r * n:(r + 1) * n]), (n, pin, r)
+            del vb, pb
+    m.set_encoder('auto')
+    run = ShardedForward(m, 8, 3, object())                      # (no collective is issued: only the pin is exercised)
+    run._pin_encoder(1024)
+    assert run._pinned == 'tiled'
+    vs, ps = m(x[3072:4096].contiguous())
+    assert torch.equal(vs, v[3072:4096])
+    m.set_encoder('auto')
+    del v

@@ -18,6 +18,17 @@ def _fake_forward(x):                       # per-sample, batch-independent: lik
     return verts, x.repeat(1, 1, 2)[:, :, :3].contiguous()
 
 
+class _FakeModel:                           # the module surface ShardedForward touches: __call__ and set_encoder
+    def __init__(self):
+        self.encoder_calls = []
+
+    def __call__(self, x):
+        return _fake_forward(x)
+
+    def set_encoder(self, mode):
+        self.encoder_calls.append(mode)
+
+
 def _fake_metrics(verts, pose3d, target, sl):      # per-sample partial sums, like gator_amd.eval on the device
     t = target[sl]
     return torch.stack([(verts[:, :17].double() - t.double()).abs().sum(), pose3d.double().sum(),
@@ -39,9 +50,10 @@ def _worker(rank, world, port, micro, mode, q):
     n = 6
     ok = True
     if mode == 'gather':
-        run = ShardedForward(_fake_forward, world, rank, dist, micro_batch=micro)
+        model = _FakeModel()
+        run = ShardedForward(model, world, rank, dist, micro_batch=micro)
         kept = []
-        for step in range(3):                # three steps: the two output buffers rotate; step k's result survives step k+1
+        for step in range(5):                # five steps: the two output buffers rotate; step k's result survives step k+1
             torch.manual_seed(step)
             full = torch.randn(world * n, 17, 2)
             gv, gp = run.step(full[rank * n:(rank + 1) * n])
@@ -53,6 +65,8 @@ def _worker(rank, world, port, micro, mode, q):
             kept.append((gv, rv))
         run.comm_only()
         ok = ok and bool(torch.equal(gv, rv))
+        ok = ok and 1 <= run.max_inflight <= run.depth          # the backlog of collectives is bounded by the buffer rotation
+        ok = ok and model.encoder_calls == ['sample']            # world > 1: ONE encoder for every call (small local batch -> per-sample kernel)
     else:
         torch.manual_seed(0)
         full = torch.randn(world * n, 17, 2)
@@ -97,5 +111,19 @@ def test_eval_mode_allreduce_only():
 def test_single_rank_passthrough():
     from gator_amd.parallel import ShardedForward
     x = torch.randn(3, 17, 2)
-    v, p = ShardedForward(_fake_forward, 1, 0, None).step(x)
+    m = _FakeModel()
+    v, p = ShardedForward(m, 1, 0, None).step(x)
     assert torch.equal(v, _fake_forward(x)[0])
+    assert m.encoder_calls == []             # one rank: the library's own per-call choice stays
+
+
+def test_encoder_pin_follows_the_local_batch():
+    """world > 1: the pinned kernel is the one the library would use for the calls this run makes (local batch, or the micro-batch),
+    decided once; an explicit choice wins."""
+    from gator_amd.parallel import ShardedForward
+    for kw, B, want in (({}, 1024, 'tiled'), ({}, 1023, 'sample'), ({'micro_batch': 256}, 2048, 'sample'), ({'encoder': 'sample'}, 4096, 'sample')):
+        m = _FakeModel()
+        run = ShardedForward(m, 8, 3, object(), **kw)
+        run._pin_encoder(min(B, run.micro or B))
+        run._pin_encoder(7)
+        assert m.encoder_calls == [want], (kw, B, m.encoder_calls)

@@ -3,15 +3,15 @@
 #   kernel-trace stats of the bench command, then separate PMC passes (never combined with a trace domain).
 # Output: gpurun_out/prof_<tag>/...; digest with tools/pmc_digest.py.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 cd "$REPO"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 --blocks 5 > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --no-cpu-baseline --no-variants --steps 20 --warmup 5 --blocks 5 > "$OUT/stats.log" 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_VALU_MFMA_F16 SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   name=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$name" -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 --blocks 2 > "$OUT/pmc_$name.log" 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$name" -- python3 bench.py --no-cpu-baseline --no-variants --steps 5 --warmup 2 --blocks 2 > "$OUT/pmc_$name.log" 2>&1
 done
 find "$OUT" -name "*.csv" | head -30
