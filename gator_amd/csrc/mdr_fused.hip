@@ -118,6 +118,13 @@ __device__ __forceinline__ void linear64_T(const float* __restrict__ Wp, const f
     }
 }
 
+// Two waves share a SIMD.  A wave whose next instruction is an MFMA that cannot issue yet (matrix pipe busy) still wins the issue
+// arbitration against a younger partner and starves the partner's VALU work (tools/microbench/helper_valu.hip: a VALU wave beside
+// a wave of back-to-back MFMAs makes NO progress at equal priority, full speed at priority 1 - and the MFMAs still issue every 32
+// cycles).  So a wave raises its priority while it runs VALU sections (softmax, splits, LayerNorm, GELU) and drops it for its
+// MFMA bursts: whoever has vector work gets the issue slots, the matrix pipe is fed from the gaps.
+#define MDR_PRIO_VALU() __builtin_amdgcn_s_setprio(1)
+#define MDR_PRIO_MFMA() __builtin_amdgcn_s_setprio(0)
 #define MDR_PIN()                            \
     do {                                     \
         asm volatile("" ::: "memory");       \
@@ -261,7 +268,9 @@ __device__ __forceinline__ f32x16 self_attention_head_x3(const float* __restrict
 constexpr float kX2QK = 16.0f, kX2V = 16.0f;
 #define ATTN_TILE_X2(KT, KB, VB, OACC)                                                                      \
     {                                                                                                       \
+        MDR_PRIO_MFMA();                                                                                    \
         f32x16 S = x2_mma(KB, qx, zero16());  /* 256 x S^T[key][query] */                                   \
+        MDR_PRIO_VALU();                                                                                    \
         float bm = -1e30f;                                                                                  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
             float sc = S[r];                                                                                \
@@ -286,7 +295,9 @@ constexpr float kX2QK = 16.0f, kX2V = 16.0f;
             ps += pe;                                                                                       \
         }                                                                                                   \
         l += ps;                                                                                            \
-        OACC = x2_mma(VB, x2_split(S), OACC);   /* O^T[d][query] += V^T[d][key] P^T[key][query] */          \
+        const X2 px_ = x2_split(S);                                                                         \
+        MDR_PRIO_MFMA();                                                                                    \
+        OACC = x2_mma(VB, px_, OACC);   /* O^T[d][query] += V^T[d][key] P^T[key][query] */                  \
     }
 __device__ __forceinline__ f32x16 self_attention_head_x2(const float* __restrict__ qt, const float* __restrict__ kbase,
                                                          const float* __restrict__ vbase, int lane) {
