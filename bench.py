@@ -21,6 +21,14 @@ roofline  : the dominant kernel of the forward (largest share of device time), t
             MFMA with every fp32 operand split exactly into three bf16 planes and six partial products per fp32 product
             (x3_common.h), so their ceiling is the dense bf16 peak / 6 = 416.7 TFLOP/s of fp32-equivalent work; a stage
             switched back to the fp32-input MFMA (GATOR_*_X3=0) is priced against 157.3 TFLOP/s.
+            `traffic_ratio` = HBM-side bytes of the WHOLE forward per mesh (committed PMC digest of this command: FETCH_SIZE x 2 +
+            WRITE_SIZE over every launch of a step) / the 83 020 compulsory bytes of SURVEY 8(d); `frac_of_dense_16bit_peak_2500` =
+            executed MFMA FLOP of the dominant kernel (PMC instruction counts) / live duration / 2.5 PFLOP/s.
+variants   : (N = 1) the same workload in the same process with the library's A/B switches: no rounded operand anywhere
+            (GATOR_MDR_X3=1), every product on the fp32-input MFMA, the previous encoder kernel; and the headline re-measured with
+            the variants' protocol.  clocks: sclk / mclk levels and power cap from sysfs.
+--config   : BASELINE.json presets (2: B=256 J=17 fp32; 3: B=2048 J=19 bf16; 4: 1024 per GPU + all-gather, 8 GPUs = B 8192; 5: evaluation
+            mode, all-reduce only); `config.baseline_config` names the BASELINE config a run is.
 cpu_baseline: the oracle (torch-CPU restatement of the reference forward, kind "port") timed on this box's host cores with
             BASELINE.md section 3's protocol (B in {16,64,256}, 3 warm-up + 10 timed, median per B, best B), rank 0, N=1 only.
 """
