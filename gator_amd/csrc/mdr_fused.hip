@@ -492,9 +492,9 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         f32x16 att[2];
         if constexpr (XA == 2) {
             att[0] = self_attention_head_x2(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
-                                            a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
+                                    a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
             att[1] = self_attention_head_x2(a.q_in + (tile + 1) * TQ, a.k_in + ((size_t)b * kVT * 2 + 1) * TQ,
-                                            a.v_in + ((size_t)b * kVT * 2 + 1) * TQ, lane);
+                                    a.v_in + ((size_t)b * kVT * 2 + 1) * TQ, lane);
         } else if constexpr (XA == 1) {
             att[0] = self_attention_head_x3(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
                                             a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
