@@ -25,17 +25,6 @@ class GemmProblem(ctypes.Structure):            # include/gator_train.h: gator_g
                 ('ws_off', ctypes.c_int64), ('total_wgs', ctypes.c_int32), ('total_fin', ctypes.c_int32), ('bias', ctypes.c_void_p)]
 
 
-class GatBlock(ctypes.Structure):               # include/gator_train.h: gator_gat_block
-    IN = ('x', 'hop_bias', 'adj', 'm1', 'm2', 'n1w', 'n1b', 'qkv_w', 'qkv_b', 'proj_w', 'proj_b', 'W', 'M', 'gbias', 'l0_w', 'l0_b', 'l1_w', 'l1_b',
-          'back_w', 'back_b', 'n2w', 'n2b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b')
-    FWD = ('y', 'qkv', 'P', 'a0', 'h0', 'h1', 's', 'cat', 'x1', 'y2', 'hpre', 'hd', 'x2', 'stats', 't0', 't1', 't2', 't3')
-    BWD = ('dx2', 'dx', 'dqkv', 'da1', 'dh0', 'dh1', 'dl0', 'dl1', 'dxf', 'dhpre', 'dm', 'dgout', 'pm', 'dadj', 'dS', 'ln1_gw', 'ln1_gb', 'ln2_gw',
-           'ln2_gb', 'u0', 'u1', 'u2', 'u3', 'u4')
-    _fields_ = ([('B', ctypes.c_int32), ('J', ctypes.c_int32)] + [(n, ctypes.c_void_p) for n in IN + FWD] +
-                [('seed', ctypes.c_uint64), ('counter', ctypes.c_void_p), ('off', ctypes.c_uint64 * 6), ('rate', ctypes.c_float * 6)] +
-                [(n, ctypes.c_void_p) for n in BWD])
-
-
 class GatorConfig(ctypes.Structure):
     _fields_ = [('num_joint', ctypes.c_int32), ('alpha', ctypes.c_int32), ('impl', ctypes.c_int32),
                 ('max_batch', ctypes.c_int32), ('parts', ctypes.c_int32), ('subbatch_streams', ctypes.c_int32)]
@@ -88,8 +77,6 @@ SIGNATURES = {
     'gator_t_batchnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),
     'gator_t_batchnorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'gator_t_struct_size': (_L, [_I]),
-    'gator_t_gat_block_fwd': (_I, [_P, _P]),
-    'gator_t_gat_block_bwd': (_I, [_P, _P]),
     'gator_t_layernorm_fwd': (_I, [_P, _L, _I, _P, _P, ctypes.c_float, _I, _P, _P, _P, _P]),
     'gator_t_layernorm_bwd': (_I, [_P, _P, _P, _P, _P, _L, _I, ctypes.c_float, _I, _P, _P, _P, _P]),
     'gator_t_add_n': (_I, [_P, _P, _P, _P, _P, _L, _P]),

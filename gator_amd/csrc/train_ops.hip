@@ -900,7 +900,16 @@ int face_loss(bool normal, const float* pred, const float* target, const int32_t
     return check_launch(normal ? "gator_t_normal_loss" : "gator_t_edge_loss");
 }
 
-#include "train_gat.inc"
+// keep decision of element `idx` of a tensor, exactly as k_t_dropout draws it (quad idx/4, lane idx%4 of one Philox block)
+__device__ __forceinline__ bool philox_keep(unsigned long long seed, unsigned long long offset, int64_t idx, uint32_t thresh) {
+    const int64_t q = idx >> 2;
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < GATOR_PHILOX_ROUNDS; ++r) philox_round(c, k);
+    return c[idx & 3] >= thresh;
+}
+
 #include "train_attn.inc"
 
 }  // namespace
@@ -1270,30 +1279,8 @@ int gator_t_batchnorm_bwd(const float* dy, const float* x, const float* w, const
     return check_launch("gator_t_batchnorm_bwd");
 }
 
-static int gat_block_check(const gator_gat_block* a, const char* what) {
-    static_assert(sizeof(gator_gat_block) == sizeof(GatBlkArgs), "gator_gat_block / GatBlkArgs layouts");
-    if (!a || a->B <= 0 || a->J < 2 || a->J > 20) { fail(1, "%s: bad argument (2 <= J <= 20)", what); return 1; }
-    return 0;
-}
-
-int gator_t_gat_block_fwd(const gator_gat_block* a, gator_stream stream) {
-    if (gat_block_check(a, "gator_t_gat_block_fwd")) return 1;
-    GatBlkArgs k;
-    memcpy(&k, a, sizeof(k));
-    hipLaunchKernelGGL(k_t_gat_block_fwd, dim3(a->B), dim3(kThreads), 0, (hipStream_t)stream, k);
-    return check_launch("gator_t_gat_block_fwd");
-}
-
-int gator_t_gat_block_bwd(const gator_gat_block* a, gator_stream stream) {
-    if (gat_block_check(a, "gator_t_gat_block_bwd")) return 1;
-    GatBlkArgs k;
-    memcpy(&k, a, sizeof(k));
-    hipLaunchKernelGGL(k_t_gat_block_bwd, dim3(a->B), dim3(kThreads), 0, (hipStream_t)stream, k);
-    return check_launch("gator_t_gat_block_bwd");
-}
-
 int64_t gator_t_struct_size(int which) {
-    return which == 0 ? (int64_t)sizeof(gator_gemm_problem) : which == 1 ? (int64_t)sizeof(gator_gat_block) : -1;
+    return which == 0 ? (int64_t)sizeof(gator_gemm_problem) : -1;
 }
 
 int64_t gator_t_loss_ws_bytes(int64_t B, int64_t F) { return 65536 + B * F * 9 * (int64_t)sizeof(float); }

@@ -121,10 +121,6 @@ def hop_path_bias(P, c, p='pose_lifter.get_hop_path_encoding.'):
 
 import os
 
-# GATOR_TRAIN_FUSED_GAT=1: one launch per GATBlock and direction (train/fused.py) instead of the block composed from primitives.
-# Measured: the per-sample kernels are correct and remove ~640 launches per step, but their ~45 dependent products per
-# block run serially on one CU per sample - 7.95 vs 6.98 ms at B=64, 16.35 vs 15.95 at B=256 - so the composed block stays the default.
-FUSED_GAT_BLOCKS = os.environ.get('GATOR_TRAIN_FUSED_GAT', '0')
 # GATOR_TRAIN_FUSED_ATTN=0: attention cores and the MGCN aggregation composed from the primitives (the cross-check form) instead of
 # their one-launch kernels
 FUSED_SELF_ATTENTION = os.environ.get('GATOR_TRAIN_FUSED_ATTN', '1') != '0'
@@ -197,11 +193,7 @@ def gat_forward(P, c, pose2d, gen, rates, training=True, p='pose_lifter.'):
     x = ops.add(x, ops.matmul(c.deg_onehot, g('pos_num_embed.weight')))
     biases = ops.fork(hop_path_bias(P, c, p + 'get_hop_path_encoding.'), DEPTH)
     for i in range(DEPTH):
-        if FUSED_GAT_BLOCKS == '1':
-            from . import fused
-            x = fused.gat_block(P, c, x, biases[i], i, gen, rates, training, p)
-        else:
-            x = gat_block(P, c, x, biases[i], i, gen, rates, training, p)
+        x = gat_block(P, c, x, biases[i], i, gen, rates, training, p)
     feat = ops.gelu(ops.layernorm(x, g('norm.weight'), g('norm.bias'), 1e-5, 0))
     feat, f2 = ops.fork(feat)
     x_out = ops.linear(f2.reshape(B, J * C), g('lifter.weight'), g('lifter.bias'))

@@ -63,27 +63,6 @@ typedef struct gator_gemm_problem {
 int64_t gator_t_gemm_grouped_prepare(gator_gemm_problem* problems, int n);
 int gator_t_gemm_grouped(const gator_gemm_problem* table_host, int n, void* table_dev, float* ws, gator_stream stream);
 
-/* One GATBlock of the training step (lib/models/GAT.py:33-43 in .train() mode) as one launch per direction: a workgroup owns a sample
- * and walks the block's operations itself (same device code as the stand-alone primitives, same Philox masks), leaving the inputs X
- * and output gradients dY of its nine linears in memory for the grouped weight-gradient launch.  All tensors row-major [B, ...];
- * weights in the reference's state_dict layouts.  off[i] / rate[i]: dropout sites attn, proj, DropPath 1, mlp 1, mlp 2, DropPath 2. */
-typedef struct gator_gat_block {
-    int32_t B, J;
-    const float *x, *hop_bias /* [8,J,J] */, *adj /* sym(A + adj2) [J,J] */, *m1, *m2 /* hop masks [J,J] */;
-    const float *n1w, *n1b, *qkv_w, *qkv_b, *proj_w, *proj_b, *W, *M, *gbias, *l0_w, *l0_b, *l1_w, *l1_b, *back_w, *back_b, *n2w, *n2b,
-        *fc1_w, *fc1_b, *fc2_w, *fc2_b;
-    float *y, *qkv, *P, *a0, *h0, *h1, *s, *cat, *x1, *y2, *hpre, *hd, *x2, *stats;   /* forward outputs kept for the backward */
-    float *t0, *t1, *t2, *t3;                                                           /* scratch [B,J,128] x2, [B,J,16], [B,8,J,J] */
-    uint64_t seed;
-    const uint64_t* counter;                                                            /* device step counter or NULL */
-    uint64_t off[6];
-    float rate[6];
-    const float* dx2;                                                                   /* backward: gradient of the block output */
-    float *dx, *dqkv, *da1, *dh0, *dh1, *dl0, *dl1, *dxf, *dhpre, *dm, *dgout, *pm, *dadj, *dS, *ln1_gw, *ln1_gb, *ln2_gw, *ln2_gb;
-    float *u0, *u1, *u2, *u3, *u4;                                                      /* backward scratch */
-} gator_gat_block;
-int gator_t_gat_block_fwd(const gator_gat_block* args, gator_stream stream);
-int gator_t_gat_block_bwd(const gator_gat_block* args, gator_stream stream);   /* dx, the nine dY, per-sample partials of the small gradients */
 
 /* Multi-head self-attention core with dropout on the probabilities (vanilla_transformer_encoder.py:36-46): o = dropout(softmax(scale q k^T)) v
  * for q, o of shape [B, T, H*D] and k, v [B, Tk, H*D] (head h in columns D*h ..; D = 32; Tk = T: the 431-token self-attention, Tk = J: the
@@ -121,7 +100,7 @@ int gator_t_batchnorm_fwd(const float* x, const float* w, const float* b, float*
 int gator_t_batchnorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rinv, float* dx, float* dw, float* db, int B,
                           int C, int L, gator_stream stream);
 
-/* sizeof(gator_gemm_problem) (which = 0) / sizeof(gator_gat_block) (1): lets a binding check its mirror of the structs */
+/* sizeof(gator_gemm_problem) (which = 0): lets a binding check its mirror of the struct */
 int64_t gator_t_struct_size(int which);
 
 /* rows of n contiguous floats.  mode 0: nn.LayerNorm (biased variance, eps inside the root); mode 1: the MDR LayerNorm
