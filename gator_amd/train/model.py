@@ -101,8 +101,9 @@ def conv1d_k3(x, w, b):
     B, C, _ = x.shape
     u = _Unfold3.apply(x).reshape(B, 3, C * 3)
     wr = w.reshape(w.shape[0], C * 3)
-    if ops.grad_slot(w) is not None:
-        wr._gslot = ops.grad_slot(w).reshape(w.shape[0], C * 3)      # the view keeps its slice of the flat gradient buffer
+    slot = getattr(w, '_gslot', None)                                # (forwarded, not consumed: ops.linear below is the one writer)
+    if slot is not None:
+        wr._gslot = slot.reshape(w.shape[0], C * 3)                  # the view keeps its slice of the flat gradient buffer
     y = ops.linear(u, wr, b)                                         # [B,3,O]
     return y.transpose(1, 2)
 

@@ -121,9 +121,22 @@ def raw_gemm(a, b, out=None, bias=None, alpha=1.0, accumulate=False, a_rowsum=No
     return out
 
 
-def grad_slot(p):
-    """The slice of the flat gradient buffer that belongs to parameter view `p` (set by optim.FlatParams.views), or None."""
-    return getattr(p, '_gslot', None)
+def grad_slot(p, part=None):
+    """The slice of the flat gradient buffer that belongs to parameter view `p` (set by optim.FlatParams.views), or None.
+
+    A slot-aware op WRITES its weight gradient into that slice (deferred, accumulate = 0) and hands the slice itself back to autograd,
+    so a view may feed exactly ONE such op per step (or several that each own a disjoint `part` of it, like the two rows of the MGCN
+    weight): a second writer would overwrite the first, and autograd would sum an unwritten buffer.  That used to hold by convention;
+    it is checked here - the views are made afresh every step, so the marks do not outlive it."""
+    sl = getattr(p, '_gslot', None)
+    if sl is None:
+        return None
+    used = p.__dict__.setdefault('_gslot_used', set())
+    if None in used or part in used or (part is None and used):
+        raise RuntimeError('gator_amd.train: a parameter view feeds two gradient-slot-aware ops in one step (its slice of the flat gradient '
+                           'would be written twice); route one of the uses through a plain op or give each its own part')
+    used.add(part)
+    return sl
 
 
 def raw_copy(x):
@@ -166,11 +179,13 @@ class Deferred:
 
     @staticmethod
     def flush(dev):
-        q = Deferred.queue
-        if not q:
+        """Runs the queued products of device `dev` (two trainers on two devices interleaved in one process keep their lists apart)."""
+        dev = torch.device(dev)
+        mine = [e for e in Deferred.queue if e[2].device == dev]
+        if not mine:
             return
-        run_group([(a4, b4, out4, rowsum, None) for (a4, b4, out4, rowsum) in q], dev)
-        q.clear()
+        Deferred.queue[:] = [e for e in Deferred.queue if e[2].device != dev]
+        run_group([(a4, b4, out4, rowsum, None) for (a4, b4, out4, rowsum) in mine], dev)
 
 
 def run_group(problems, dev):
@@ -504,7 +519,7 @@ class _XW(torch.autograd.Function):
         wk = W.narrow(0, k, 1).reshape(1, 1, W.shape[1], W.shape[2])
         ctx.save_for_backward(x2, wk)
         ctx.xshape, ctx.k, ctx.wshape = x.shape, k, W.shape
-        sl = grad_slot(W)
+        sl = grad_slot(W, part=k)
         ctx.wslot = sl.narrow(0, k, 1).view(1, 1, W.shape[1], W.shape[2]) if sl is not None else None
         ctx.full = sl
         return raw_gemm(x2, wk).reshape(list(x.shape[:-1]) + [W.shape[2]])

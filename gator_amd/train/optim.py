@@ -54,7 +54,8 @@ class FlatParams:
     def views(self):
         """name -> differentiable view of the flat buffer (call once per step, inside the graph).  Every view carries its slice
         of this step's flat gradient buffer (`_gslot`): linear / LayerNorm backward write weight gradients straight into it."""
-        ops.Deferred.queue.clear()                         # (a backward that raised may have left entries behind)
+        dev = self.flat.device                             # (a backward that raised may have left entries of THIS device behind)
+        ops.Deferred.queue[:] = [e for e in ops.Deferred.queue if e[2].device != dev]
         self.gflat = ops.zeros((self.numel,), self.flat.device)
         vs = _Unflatten.apply(self.flat, self)
         for v, (a, b, shape) in zip(vs, self.slots):

@@ -152,3 +152,21 @@ def test_linear_group_matches_separate_linears():
         return torch.cat([F.linear(x0, w0, b0).reshape(5, -1), F.linear(x1, w1).reshape(5, -1), F.linear(x2, w2, b2).reshape(5, -1)], 1)
 
     _check(ours, ref, ins)
+
+
+def test_gradient_slot_may_feed_only_one_slot_aware_op():
+    """the in-place weight-gradient slots were safe only by convention.  A parameter view used by two slot-aware ops
+    in one step (both would write the same slice of the flat gradient, deferred, accumulate = 0) now raises instead of silently
+    losing a gradient; disjoint parts of one view (the two rows of the MGCN weight) stay legal."""
+    w = torch.randn(8, 16, device='cuda', requires_grad=True)
+    w._gslot = torch.zeros(8, 16, device='cuda')
+    x = torch.randn(4, 16, device='cuda')
+    ops.linear(x, w, None)
+    with pytest.raises(RuntimeError, match='two gradient-slot-aware ops'):
+        ops.linear(x, w, None)
+    W = torch.randn(2, 16, 16, device='cuda', requires_grad=True)
+    W._gslot = torch.zeros(2, 16, 16, device='cuda')
+    ops.xw(x, W, 0)
+    ops.xw(x, W, 1)
+    with pytest.raises(RuntimeError, match='two gradient-slot-aware ops'):
+        ops.xw(x, W, 1)
