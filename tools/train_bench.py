@@ -73,24 +73,52 @@ def main():
         from gator_amd.train.model import is_buffer
         from tests.helpers import oracle_setup
         zz, c, sd = oracle_setup(name)
-        best = None
-        for nt in (8, 16, 32):
+
+        def cpu_step(P, leaves, xb, tgb):
+            mesh, p3 = go.gator_forward_train(P, c, xb, torch.float32)
+            loss, _ = go.training_loss(mesh, p3, tgb, jreg, faces, with_edge=True)
+            torch.autograd.grad(loss, leaves, allow_unused=True)
+
+        def cpu_batch(B):
+            xb = torch.from_numpy(synthetic.synthetic_pose2d(B, a.joints, 3))
+            tgb = {k: torch.from_numpy(v) for k, v in synthetic.training_targets(B, a.joints, base, jreg, 3).items()}
+            return xb, tgb
+
+        # BASELINE.md section 3's protocol, as bench.py applies it to the forward: thread count by a short probe (8 / 16 / 32: all host
+        # threads is pathological for these small tensors), then B in {16, 64, 256}, warm-up + timed steps, median per B, best B
+        P = {k: (v.float().requires_grad_(True) if (v.is_floating_point() and not is_buffer(k)) else v) for k, v in sd.items()}
+        leaves = [v for v in P.values() if torch.is_tensor(v) and v.requires_grad]
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cands = sorted({n for n in (8, 16, 32) if n <= avail}) or [avail]
+        xb, tgb = cpu_batch(64)
+        probe = {}
+        for nt in cands:
             torch.set_num_threads(nt)
-            P = {k: (v.float().requires_grad_(True) if (v.is_floating_point() and not is_buffer(k)) else v) for k, v in sd.items()}
-            leaves = [v for v in P.values() if torch.is_tensor(v) and v.requires_grad]
-            tgc = {k: v.cpu() for k, v in tg.items()}
+            cpu_step(P, leaves, xb, tgb)
+            t0 = time.perf_counter()
+            cpu_step(P, leaves, xb, tgb)
+            probe[nt] = time.perf_counter() - t0
+        nt = min(probe, key=probe.get)
+        torch.set_num_threads(nt)
+        per_b = {}
+        for B, (nw, ntimed) in ((16, (3, 10)), (64, (3, 10)), (256, (1, 3))):
+            xb, tgb = cpu_batch(B)
+            for _ in range(nw):
+                cpu_step(P, leaves, xb, tgb)
             ts = []
-            for it in range(3):
+            for _ in range(ntimed):
                 t0 = time.perf_counter()
-                mesh, p3 = go.gator_forward_train(P, c, x.cpu(), torch.float32)
-                loss, _ = go.training_loss(mesh, p3, tgc, jreg, faces, with_edge=True)
-                torch.autograd.grad(loss, leaves, allow_unused=True)
+                cpu_step(P, leaves, xb, tgb)
                 ts.append(time.perf_counter() - t0)
-            t = min(ts[1:])
-            if best is None or t < best[0]:
-                best = (t, nt)
-        out['cpu_baseline'] = {'value': round(a.batch / best[0], 1), 'unit': 'samples/s', 'cores': best[1], 'kind': 'port',
-                               'sample': 'oracle forward(train, no dropout) + losses + torch autograd backward, B=%d, best of 2 after 1 warm-up, no optimizer' % a.batch}
+            per_b[B] = B / float(np.median(ts))
+        bb = max(per_b, key=per_b.get)
+        out['cpu_baseline'] = {'value': round(per_b[bb], 1), 'unit': 'samples/s', 'cores': int(nt), 'kind': 'port',
+                               'sample': 'oracle forward(train, no dropout) + five losses + torch-CPU autograd backward, no optimizer; B in {16,64,256} x '
+                                         '(3 warm-up + 10 timed; B=256: 1 + 3), median per B, best B=%d; %d of %d host threads (probe over %s)' % (bb, nt, avail, cands),
+                               'per_batch': {str(k): round(v, 1) for k, v in per_b.items()}}
     print(json.dumps(out))
 
 
