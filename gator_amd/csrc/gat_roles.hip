@@ -712,6 +712,7 @@ int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* 
     static const bool l2warm = [] { const char* e = getenv("GATOR_GAT_L2WARM"); return !(e && atoi(e) == 0); }();     // default on; =0 for A/B
     a.pf_n = std::min(32, (B + 7) / 8);                  // workgroups b and b + 8 share an XCD (round-robin dispatch; speed only)
     a.pf_loads = l2warm ? (kBlkTiles * kTileX3 * 4 / a.pf_n + 8191) / 8192 : 0;       // 8 KiB (64 lines) per instruction
+    if (a.pf_loads > 6) a.pf_loads = 0;      // fewer than ~8 workgroups per XCD (B < 64): a share is so large that touching it costs more than it hides
 #ifdef GATOR_DIAG
     a.stamps = nullptr;
     a.dbg = getenv("GATOR_GAT8_DBG") ? atoi(getenv("GATOR_GAT8_DBG")) : 0;
