@@ -63,7 +63,7 @@ _VF, _QKV = 14 * 2 * 4096, 3 * 14 * 2 * 4096          # Q/K/V as two fp16 planes
 STAGE_BYTES = {'mdr_layer0': _VF + _QKV, 'mdr_layer': 2 * (_VF + _QKV), 'mdr_attn_head': _VF + _QKV + 431 * 32 * 4 + 431 * 64 * 4,
                'upsample': 3 * 431 * 2 * 3 + 6890 * 3 * 4, 'gat': 136 + 17 * 128 * 4 + 204 + 12 * 4096}
 STAGE_KERNEL = {'gat': 'k_gat', 'mdr_layer0': 'k_mdr_layer<0,', 'mdr_layer': 'k_mdr_layer<1,',
-                'mdr_attn_head': 'k_mdr_layer<2,', 'upsample': 'k_upsample_x3'}
+                'mdr_attn_head': 'k_mdr_layer<2,', 'upsample': 'k_upsample_x'}
 # BASELINE.json `configs`, 1-based as VERDICT.md numbers them (config 1 is the reference's own CPU demo): per-GPU presets
 BASELINE_CONFIGS = {
     2: dict(batch=256, joints=17, precision='f32', mode='gather', gpus=1,
@@ -461,12 +461,13 @@ def main():
             line['comm'] = comm
         if world == 1 and not a.no_variants and a.impl == 'fused' and a.mode == 'gather':
             # The same workload, same process, same box, with the library's A/B switches (read when a context is created).  The
-            # headline's 431x431 attention core ROUNDS its operands to two fp16 planes (22 bits; output parity demonstrated in
-            # tests/test_gpu_x3.py); `exact_split` is the build without any rounded operand, `fp32_mfma` every product on the
+            # headline's 431x431 attention core and its vertex regressor ROUND their operands to two fp16 planes (22 bits; output
+            # parity demonstrated in tests/test_gpu_x3.py); `exact_split` is the build without any rounded operand, `fp32_mfma` every product on the
             # fp32-input MFMA, `k_gat` the previous one-sample-per-workgroup encoder.
             variants = {}
             for vname, env in (('headline, re-measured with the variants\' protocol (5 blocks, later in the run: clocks drift)', {}),
-                               ('exact_split (GATOR_MDR_X3=1)', {'GATOR_MDR_X3': '1'}),
+                               ('exact_split (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1)', {'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1'}),
+                               ('three-plane vertex regressor (GATOR_UPSAMPLE_X3=1)', {'GATOR_UPSAMPLE_X3': '1'}),
                                ('fp32_mfma (GATOR_GAT_X3=0 GATOR_MDR_X3=0 GATOR_UPSAMPLE_X3=0)', {'GATOR_GAT_X3': '0', 'GATOR_MDR_X3': '0', 'GATOR_UPSAMPLE_X3': '0'}),
                                ('k_gat encoder (GATOR_GAT8=0)', {'GATOR_GAT8': '0'})):
                 old = {k: os.environ.get(k) for k in env}

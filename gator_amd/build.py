@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libgator_hip.so')
-SOURCES = ['api.hip', 'basic_kernels.hip', 'fused_api.hip', 'fused_pack.hip', 'upsample_fused.hip', 'mdr_fused.hip', 'gat_fused.hip', 'gat_roles.hip', 'gat_tiled.hip', 'gat_tail.hip', 'upsample_bf16.hip', 'upsample_x3.hip', 'caller_kernels.hip', 'train_ops.hip',
+SOURCES = ['api.hip', 'basic_kernels.hip', 'fused_api.hip', 'fused_pack.hip', 'upsample_fused.hip', 'mdr_fused.hip', 'gat_fused.hip', 'gat_roles.hip', 'gat_tiled.hip', 'gat_tail.hip', 'upsample_bf16.hip', 'upsample_x3.hip', 'upsample_x2.hip', 'caller_kernels.hip', 'train_ops.hip',
            'graph_consts.cpp', 'comm_rccl.cpp']
 HEADERS = ['internal.h', os.path.join(ROOT, 'include', 'gator_hip.h'), os.path.join(ROOT, 'include', 'gator_train.h')]
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-Wall', '-Wno-unused-function',

@@ -35,7 +35,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
                  o_q = take(3 * tiles), o_k = take(3 * tiles), o_v = take(3 * tiles) /* q/k/v sized for X3 tiles (1.5x) */, o_jkv = take((size_t)cap * 12 * kTile),
                  o_hf = take((size_t)cap * kV * 32), o_lbf = take((size_t)cap * kV * kE), o_feat = take((size_t)cap * J * kC),
                  o_xout = take((size_t)cap * J * 3), o_pc = take((size_t)cap * J * 133),
-                 o_vcp3 = take(upsample_x3_vcp_elems(cap) / 2), o_lpart = take(gat_tail_part_floats(cap, J));
+                 o_vcp3 = take(std::max(upsample_x3_vcp_elems(cap), upsample_x2_vcp_elems(cap)) / 2), o_lpart = take(gat_tail_part_floats(cap, J));
     GATOR_HIP_CHECK(hipMalloc(&f->ws, n * sizeof(float)));
     GATOR_HIP_CHECK(hipMemset(f->ws, 0, n * sizeof(float)));
     GATOR_HIP_CHECK(hipDeviceSynchronize());      // the memset runs on the null stream; a non-blocking stream would not wait for it
@@ -203,7 +203,10 @@ int fused_create(gator_ctx* c, void* stream) {
     if (!(c->parts & GATOR_PART_MDR)) return GATOR_OK;
     // vertex regressor: split-precision bf16 planes by default; GATOR_UPSAMPLE_X3=0 keeps the fp32-input MFMA kernel (A/B runs)
     const char* x3env = getenv("GATOR_UPSAMPLE_X3");
-    f->x3 = !(x3env && atoi(x3env) == 0);
+    const int up_mode = x3env ? atoi(x3env) : 2;
+    if (up_mode < 0 || up_mode > 2) return fail(GATOR_EINVAL, "GATOR_UPSAMPLE_X3 must be 0, 1 or 2");
+    f->x3 = up_mode != 0;
+    f->up_x2 = up_mode == 2;
     const char* mx3 = getenv("GATOR_MDR_X3");
     f->mdr_x3 = mx3 ? atoi(mx3) : 2;
     if (f->mdr_x3 < 0 || f->mdr_x3 > 2) return fail(GATOR_EINVAL, "GATOR_MDR_X3 must be 0, 1 or 2");
@@ -215,7 +218,12 @@ int fused_create(gator_ctx* c, void* stream) {
     auto take = [&](size_t k) { float* r = p; p += k; return r; };
     // upsample_conv.weight [6890][431][3] -> one packed [216][14] tile grid per tap
     float* up = take(n_up);
-    if (f->x3) {
+    if (f->x3 && f->up_x2) {
+        GATOR_HIP_CHECK(hipMalloc(&f->up_w2, upsample_x2_weight_elems() * 2));
+        int rc = pack_upsample_x2(w.up_w, f->up_w2, &f->up_w2_unscale, stream);
+        if (rc == GATOR_OK) rc = upsample_x2_prepare_device();
+        if (rc) return rc;
+    } else if (f->x3) {
         GATOR_HIP_CHECK(hipMalloc(&f->up_w3, upsample_x3_weight_elems() * 2));
         int rc = pack_upsample_x3(w.up_w, f->up_w3, stream);
         if (rc) return rc;
@@ -344,8 +352,14 @@ void fused_destroy(gator_ctx* c) {
     for (void* p : {c->fused->jr_blk, c->fused->jr_ent, (void*)c->fused->jr_w, (void*)c->fused->jr_rowptr, (void*)c->fused->jr_P})
         if (p) (void)hipFree(p);
     if (c->fused->up_w3) (void)hipFree(c->fused->up_w3);
+    if (c->fused->up_w2) (void)hipFree(c->fused->up_w2);
     delete c->fused;
     c->fused = nullptr;
+}
+
+int launch_upsample_any(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints) {
+    if (!f->x3) return launch_upsample(f, c, B, verts, stream);
+    return f->up_x2 ? launch_upsample_x2(f, c, B, verts, stream, with_joints) : launch_upsample_x3(f, c, B, verts, stream, with_joints);
 }
 
 int fused_gat_forward(gator_ctx* c, const float* pose2d, int B, float* x_out, float* feat, void* stream) {
@@ -357,10 +371,11 @@ static int fused_upsample_in(gator_ctx* c, const float* vert431, int B, float* v
     int rc = fused_ensure_ws(c, B);
     if (rc) return rc;
     FusedState* f = c->fused;
-    rc = f->x3 ? launch_pack_vc_x3(vert431, B, f->cap, f->vcp3, stream) : launch_pack_vc(vert431, B, f->vcp, stream);
+    rc = !f->x3 ? launch_pack_vc(vert431, B, f->vcp, stream)
+         : f->up_x2 ? launch_pack_vc_x2(vert431, B, f->vcp3, stream) : launch_pack_vc_x3(vert431, B, f->cap, f->vcp3, stream);
     if (rc) return rc;
     StageTimer tm(c, "upsample", stream);
-    return f->x3 ? launch_upsample_x3(f, c, B, verts, stream) : launch_upsample(f, c, B, verts, stream);
+    return launch_upsample_any(f, c, B, verts, stream);
 }
 
 int fused_upsample(gator_ctx* c, const float* vert431, int B, float* verts, void* stream) {
@@ -407,7 +422,7 @@ static int fused_mdr_forward_impl(gator_ctx* c, const float* pc, int B, float* v
     if (rc) return rc;
     if (bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);
     StageTimer tm(c, "upsample", stream);
-    return f->x3 ? launch_upsample_x3(f, c, B, verts, stream) : launch_upsample(f, c, B, verts, stream);
+    return launch_upsample_any(f, c, B, verts, stream);
 }
 
 int fused_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* stream) {
@@ -498,14 +513,14 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
             GATOR_HIP_CHECK(hipMalloc(&f->jr_P, (size_t)B * f->jr_nnz * 3 * sizeof(float)));
             f->jr_cap = B;
         }
-        { StageTimer tm(c, "upsample", stream); rc = launch_upsample_x3(f, c, B, verts, stream, true); }
+        { StageTimer tm(c, "upsample", stream); rc = launch_upsample_any(f, c, B, verts, stream, true); }
         if (rc) return rc;
         StageTimer tm(c, "jreg_reduce", stream);
         return launch_jreg_reduce(f, B, joints, stream);
     }
     if (bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);
     StageTimer tm(c, "upsample", stream);
-    return f->x3 ? launch_upsample_x3(f, c, B, verts, stream) : launch_upsample(f, c, B, verts, stream);
+    return launch_upsample_any(f, c, B, verts, stream);
 }
 
 // Register a sparse [nj, 6890] joint regressor (COO, host or device pointers are both read through hipMemcpy) for the fused epilogue

@@ -26,7 +26,8 @@ struct FusedWs {
     size_t ws_floats = 0;
     int cap = 0;
     float *vcp = nullptr;               // [MT][3][kCB][4][64][4]  packed vert431 (A operand of the fp32-MFMA upsample GEMM)
-    void* vcp3 = nullptr;               // bf16 [plane 3][MT][3][28][64][8]  hi/mid/lo split of vert431 (split-precision GEMM)
+    void* vcp3 = nullptr;               // split-precision A operand of the vertex GEMM: bf16 [plane 3][MT][3][28][64][8] (hi/mid/lo, upsample_x3.hip)
+                                        // or fp16 [MT/4][28][4][3][plane 2][64][8] (hi/lo, upsample_x2.hip); sized for the larger
     float *vc = nullptr;                // [B][431][3]
     float *vf = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;   // [B][14][2][kTile] each
     float *jkv = nullptr;               // [B][3 layers][2 (k,v)][2 heads][kTile]
@@ -58,6 +59,9 @@ struct FusedState : FusedWs {
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
     int mdr_x3 = 2;                     // GATOR_MDR_X3: 0 fp32-input MFMA; 1 exact bf16 x 3 split everywhere; 2 (default) that + the 431x431 attention on two fp16 planes
     bool x3 = true;                     // split-precision vertex regressor (GATOR_UPSAMPLE_X3=0: fp32-input MFMA kernel)
+    bool up_x2 = true;                  // ... on two fp16 planes (default; GATOR_UPSAMPLE_X3=1: the exact three bf16 planes)
+    void* up_w2 = nullptr;              // fp16 [ob/2][28][2][tap 3][plane 2][64][8]  scaled hi/lo split of upsample_conv.weight
+    float up_w2_unscale = 1.f;          // 2^-(weight shift + activation shift), applied to the finished sums
     void* up_w16 = nullptr;             // bf16 [tap][ob][28][64][8] (packed on the first bf16 call, which waits for the pack)
     // joint regressor fused into the vertex GEMM's epilogue (gator_set_joint_regressor / gator_forward_joints_f32)
     void *jr_blk = nullptr, *jr_ent = nullptr;    // int2 [kOB] (first, count) ; int2 [nnz] (vertex, slot)
@@ -117,6 +121,15 @@ int pack_upsample_x3(const float* up_w, void* dst, void* stream);
 int launch_pack_vc_x3(const float* vc, int B, int cap, void* vcp3, void* stream);
 int launch_upsample_x3(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints = false);
 int launch_jreg_reduce(const FusedState* f, int B, float* joints, void* stream);
+// upsample_x2.hip
+size_t upsample_x2_weight_elems();
+size_t upsample_x2_vcp_elems(int B);
+int upsample_x2_prepare_device();
+int pack_upsample_x2(const float* up_w, void* dst, float* unscale, void* stream);
+int launch_pack_vc_x2(const float* vc, int B, void* vcp2, void* stream);
+int launch_upsample_x2(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints = false);
+// the vertex regressor the ctx was created with (fp32-input MFMA | bf16 x 3 | fp16 x 2)
+int launch_upsample_any(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints = false);
 // mdr_fused.hip
 int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream, const float* x_out = nullptr, const float* pose2d = nullptr);
 

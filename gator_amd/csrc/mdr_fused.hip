@@ -752,6 +752,7 @@ struct HeadArgs {
     float *vc, *vcp;
     __bf16* vcp3;           // non-null: write the hi/mid/lo bf16 planes of the split-precision vertex GEMM instead of vcp
     size_t vcp3_plane;
+    _Float16* vcp2;         // non-null: write the scaled hi/lo fp16 planes of the two-plane vertex GEMM (upsample_x2.hip) instead
     int alpha;
 };
 template <int NT>
@@ -833,7 +834,14 @@ __global__ __launch_bounds__(NT) void k_mdr_head(const HeadArgs a) {
             for (int m = 0; m < 20; ++m) o += (p[m] * il) * bc[m][c];
             const float val = sc * o + cc[c];
             a.vc[((size_t)b * kV + v) * 3 + c] = val;
-            if (a.vcp3) {       // exact three-way bf16 split, in k_upsample_x3's operand order [plane][mt][l'][v/16][lane][v%8]
+            if (a.vcp2) {       // two fp16 planes of 2^4 * val, in k_upsample_x2's operand order [mt/4][v/16][mt%4][l'][plane][lane][v%8]
+                const float sv = val * 16.0f;
+                const _Float16 hi = (_Float16)sv;
+                const _Float16 lo = (_Float16)(sv - (float)hi);
+                const size_t pair = ((((size_t)(mt >> 2) * 28 + (v >> 4)) * 4 + (mt & 3)) * 3 + c) * 2;
+                const size_t e = (size_t)(((v >> 3) & 1) * 32 + sl) * 8 + (v & 7);
+                a.vcp2[pair * 512 + e] = hi; a.vcp2[(pair + 1) * 512 + e] = lo;
+            } else if (a.vcp3) {       // exact three-way bf16 split, in k_upsample_x3's operand order [plane][mt][l'][v/16][lane][v%8]
                 const __bf16 hi = (__bf16)val;
                 const float r1 = val - (float)hi;
                 const __bf16 mid = (__bf16)r1;
@@ -932,7 +940,8 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     HeadArgs ha;
     ha.hf = f->hf; ha.bn_w = w.bn_w; ha.bn_b = w.bn_b; ha.bn_mean = w.bn_mean; ha.bn_var = w.bn_var;
     ha.bconv_w = w.bconv_w; ha.bconv_b = w.bconv_b; ha.vc = f->vc; ha.vcp = f->vcp;
-    ha.vcp3 = f->x3 ? (__bf16*)f->vcp3 : nullptr; ha.vcp3_plane = upsample_x3_vcp_elems(f->cap) / 3;     // plane stride fixed by the workspace capacity
+    ha.vcp2 = f->x3 && f->up_x2 ? (_Float16*)f->vcp3 : nullptr;
+    ha.vcp3 = f->x3 && !f->up_x2 ? (__bf16*)f->vcp3 : nullptr; ha.vcp3_plane = upsample_x3_vcp_elems(f->cap) / 3;     // plane stride fixed by the workspace capacity
     ha.alpha = c->alpha;
     { StageTimer tm(c, "mdr_head", stream); k_mdr_head<512><<<B, 512, 0, st>>>(ha); }
     GATOR_HIP_CHECK(hipGetLastError());

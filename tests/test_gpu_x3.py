@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 SWITCHES = ('GATOR_GAT_X3', 'GATOR_MDR_X3', 'GATOR_UPSAMPLE_X3')
 
 
-def _run(monkeypatch, name, x, off, mdr_mode='1'):
+def _run(monkeypatch, name, x, off, mdr_mode='1', up_mode='1'):
     for k in SWITCHES:
-        monkeypatch.setenv(k, '0' if k in off else (mdr_mode if k == 'GATOR_MDR_X3' else '1'))
+        on = mdr_mode if k == 'GATOR_MDR_X3' else (up_mode if k == 'GATOR_UPSAMPLE_X3' else '1')
+        monkeypatch.setenv(k, '0' if k in off else on)
     z, m = build_model(name, 'fused')          # a fresh module -> a fresh context, which reads the switches
     v, p = m(x.cuda())
     torch.cuda.synchronize()
@@ -33,23 +34,25 @@ def test_x3_and_fp32_mfma_paths_both_meet_the_bar(monkeypatch, name, B):
     ref, rp = go.gator_forward(sd, c, x, torch.float64)
     ref, rp = ref.numpy(), rp.numpy()
     outs = {}
-    # 'default' = exact bf16 x 3 split for every linear + the 431x431 self-attention on two fp16 planes (GATOR_MDR_X3=2)
-    for label, off in (('default', ()), ('all x3', ()), ('gat fp32', ('GATOR_GAT_X3',)), ('mdr fp32', ('GATOR_MDR_X3',)),
+    # 'default' = exact bf16 x 3 split for the token-wise linears + the 431x431 self-attention and the vertex regressor on two
+    # fp16 planes (GATOR_MDR_X3=2, GATOR_UPSAMPLE_X3=2); 'upsample x3' = the default with the exact three-plane regressor
+    for label, off in (('default', ()), ('all x3', ()), ('upsample x3', ()), ('gat fp32', ('GATOR_GAT_X3',)), ('mdr fp32', ('GATOR_MDR_X3',)),
                        ('upsample fp32', ('GATOR_UPSAMPLE_X3',)), ('all fp32', SWITCHES)):
-        v, p = _run(monkeypatch, name, x, off, '2' if label == 'default' else '1')
+        v, p = _run(monkeypatch, name, x, off, '2' if label in ('default', 'upsample x3') else '1', '2' if label == 'default' else '1')
         e = np.abs(v - ref).max() * 1e3
         print('\n[%s B=%d] %-14s max |verts - fp64| = %.2e mm, pose3d %.2e mm' % (name, B, label, e, np.abs(p - rp).max()))
         assert e <= 1e-3, label
         assert np.abs(p - rp).max() <= 1e-3, label
         outs[label] = v
     # the two forms of every stage are the same function up to fp32 rounding noise
-    for label in ('default', 'gat fp32', 'mdr fp32', 'upsample fp32', 'all fp32'):
+    for label in ('default', 'upsample x3', 'gat fp32', 'mdr fp32', 'upsample fp32', 'all fp32'):
         assert np.abs(outs[label] - outs['all x3']).max() * 1e3 <= 1.5e-3, label
 
 
-def test_x3_split_is_exact():
+def test_x3_split_is_exact(monkeypatch):
     """hi + mid + lo reproduces every fp32 value bit for bit (the premise of the scheme), checked through the vertex regressor:
     with one-hot activations the kernel must return single weights (+ bias + template) exactly."""
+    monkeypatch.setenv('GATOR_UPSAMPLE_X3', '1')      # the three-plane regressor (the default two-plane one rounds to 22 bits)
     z, m = build_model('h36m17_bn', 'fused')
     sd = m.state_dict()
     w = sd['pose2mesh.upsample_conv.weight'].double().cpu()      # [6890, 431, 3]
@@ -64,3 +67,26 @@ def test_x3_split_is_exact():
     # (x + bias) + template in fp32 vs exact: only the final roundings differ -> compare against the fp32 evaluation of the same sum
     tol = 2 * np.finfo(np.float32).eps * float(base.abs().max() + ref.abs().max())
     assert float((got - ref).abs().max()) <= tol
+
+
+def test_two_plane_regressor_error_and_scaling(monkeypatch):
+    """The default vertex regressor carries each operand as two fp16 planes (upsample_x2.hip).  Against the exact product in
+    float64: (a) realistic operands stay within fp32-arithmetic noise, (b) weights and activations far from 1 (2^-12 .. 2^6) lose
+    nothing to fp16's range -- the pack-time power-of-two scaling keeps both planes normal -- and (c) the result does not depend
+    on the batch it was computed in (one kernel shape for every batch size)."""
+    monkeypatch.setenv('GATOR_UPSAMPLE_X3', '2')
+    z, m = build_model('h36m17_bn', 'fused')
+    sd = m.state_dict()
+    w = sd['pose2mesh.upsample_conv.weight'].double().cpu()
+    base = m.pose2mesh.upsample(torch.zeros(1, 431, 3).cuda()).double().cpu()      # bias + template
+    g = torch.Generator().manual_seed(5)
+    for B, mag in ((200, 0.3), (33, 2.0 ** -12), (5, 64.0)):
+        vc = (torch.randn(B, 431, 3, generator=g) * mag).float()
+        out = m.pose2mesh.upsample(vc.cuda()).double().cpu()
+        ref = torch.nn.functional.conv1d(vc.double(), w, None, padding=1) + base
+        scale = float(ref.abs().max())
+        err = float((out - ref).abs().max())
+        print('\n[two-plane regressor] B=%d |x|~%.1e: max err %.2e (outputs up to %.2e)' % (B, mag, err, scale))
+        assert err <= 4 * np.finfo(np.float32).eps * scale + 1e-7 * mag
+        one = m.pose2mesh.upsample(vc[:1].cuda()).cpu()
+        assert torch.equal(one[0], m.pose2mesh.upsample(vc.cuda()).cpu()[0])
