@@ -755,15 +755,47 @@ struct HeadArgs {
     _Float16* vcp2;         // non-null: write the scaled hi/lo fp16 planes of the two-plane vertex GEMM (upsample_x2.hip) instead
     int alpha;
 };
-template <int NT>
-__global__ __launch_bounds__(NT) void k_mdr_head(const HeadArgs a) {
+// One workgroup per sample, three short phases with a barrier between them.  The kernel is a LATENCY chain, not a throughput one
+// (18.7 us at B = 64, 24 us at B = 256, round-3 sweep): with HOIST every global read it will ever need -- this lane's 63 conv
+// weights, its token's 32 head features -- is issued before the first phase, and the phases run on registers and LDS only
+// (16 / 13 us).  That costs 196 VGPRs, one workgroup per CU: batches of more than two workgroups per CU take the rolled form
+// (same arithmetic in the same order, 2 workgroups per CU), which is the faster one there.
+template <int NT, bool HOIST>
+__global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a) {
+    static_assert(NT >= kV, "one token per thread");
     __shared__ float bn[kV][3];
     __shared__ float bc[20][3];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* hf = a.hf + (size_t)b * kV * 32;
-    for (int v = t; v < kV; v += NT) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(hf + v * 32 + 24);
-        float x[3] = {q[0], q[1], q[2]};
+    const int v = t;
+    const bool tok = v < kV;
+    constexpr int NW = NT / 64, NIT = (kV * 3 + 63) / 64;
+    // ---- all global reads up front
+    f32x4 row[5], tail = {0.f, 0.f, 0.f, 0.f}, cc = tail;
+    auto load_rows = [&]() {
+        const float* r = hf + v * 32;
+#pragma unroll
+        for (int g = 0; g < 5; ++g) row[g] = *reinterpret_cast<const f32x4*>(r + 4 * g);
+        cc = *reinterpret_cast<const f32x4*>(r + 28);
+    };
+    if (tok) {
+        tail = *reinterpret_cast<const f32x4*>(hf + v * 32 + 24);
+        if (HOIST) load_rows();
+    }
+    // Conv1d(431->20,k3,p1) weight of row m = wave + 8 q at e = lane + 64 it
+    auto conv_w = [&](int q, int it) {
+        const int e = lane + 64 * it, m = wave + NW * q;
+        return e < kV * 3 ? a.bconv_w[(m < 20 ? m : 0) * (kV * 3) + e] : 0.f;
+    };
+    float wreg[3][HOIST ? NIT : 1];
+    if (HOIST) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) wreg[q][HOIST ? it : 0] = conv_w(q, it);
+    }
+    if (tok) {
+        float x[3] = {tail[0], tail[1], tail[2]};
         if (a.alpha) {      // LayerNorm(3)
             const float m = (x[0] + x[1] + x[2]) / 3.0f;
             const float qq = ((x[0] - m) * (x[0] - m) + (x[1] - m) * (x[1] - m) + (x[2] - m) * (x[2] - m)) / 3.0f;
@@ -776,26 +808,27 @@ __global__ __launch_bounds__(NT) void k_mdr_head(const HeadArgs a) {
         for (int c = 0; c < 3; ++c) bn[v][c] = gelu_f(x[c]);
     }
     __syncthreads();
-    {   // Conv1d(431->20,k3,p1) over the xyz axis.  Wave w owns output rows m = w, w+8, w+16 and walks the whole (c,k) axis with
-        // coalesced weight reads: 9 accumulators and 9 wave reductions per wave (all 20 rows in every wave: 60 reductions of 6
-        // cross-lane steps each plus a cross-wave pass -- two thirds of this kernel's time).
-        constexpr int NW = NT / 64;
+    {   // Conv1d(431->20,k3,p1) over the xyz axis.  Wave w owns output rows m = w, w+8, w+16 and walks the whole (c,k) axis:
+        // 9 accumulators and 9 wave reductions per wave.
         float acc[3][3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) acc[q][0] = acc[q][1] = acc[q][2] = 0.f;
-        for (int e = lane; e < kV * 3; e += 64) {
-            const int c = e / 3, k = e - 3 * c;
-            // tap k of channel c meets input position ll = l + k - 1 (zero padding outside 0..2)
-            const float in0 = (k >= 1) ? bn[c][k - 1] : 0.f;        // l=0: ll = k-1
-            const float in1 = bn[c][k];                             // l=1: ll = k
-            const float in2 = (k <= 1) ? bn[c][k + 1] : 0.f;        // l=2: ll = k+1
+#pragma unroll(HOIST ? NIT : 1)
+        for (int it = 0; it < NIT; ++it) {
+            const int e = lane + 64 * it;
+            if (e < kV * 3) {
+                const int c = e / 3, k = e - 3 * c;
+                // tap k of channel c meets input position ll = l + k - 1 (zero padding outside 0..2)
+                const float in0 = (k >= 1) ? bn[c][k - 1] : 0.f;        // l=0: ll = k-1
+                const float in1 = bn[c][k];                             // l=1: ll = k
+                const float in2 = (k <= 1) ? bn[c][k + 1] : 0.f;        // l=2: ll = k+1
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int m = wave + NW * q;
-                const float w = a.bconv_w[(m < 20 ? m : 0) * (kV * 3) + e];
-                acc[q][0] += w * in0;
-                acc[q][1] += w * in1;
-                acc[q][2] += w * in2;
+                for (int q = 0; q < 3; ++q) {
+                    const float w = HOIST ? wreg[q][HOIST ? it : 0] : conv_w(q, it);
+                    acc[q][0] += w * in0;
+                    acc[q][1] += w * in1;
+                    acc[q][2] += w * in2;
+                }
             }
         }
 #pragma unroll
@@ -810,15 +843,11 @@ __global__ __launch_bounds__(NT) void k_mdr_head(const HeadArgs a) {
     }
     __syncthreads();
     const int mt = b >> 5, sl = b & 31;
-    for (int v = t; v < kV; v += NT) {
-        const float* r = hf + v * 32;
+    if (tok) {
+        if (!HOIST) load_rows();
         float av[20];
 #pragma unroll
-        for (int g = 0; g < 5; ++g) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(r + 4 * g);
-            av[4 * g] = q[0]; av[4 * g + 1] = q[1]; av[4 * g + 2] = q[2]; av[4 * g + 3] = q[3];
-        }
-        const f32x4 tail = *reinterpret_cast<const f32x4*>(r + 24), cc = *reinterpret_cast<const f32x4*>(r + 28);
+        for (int g = 0; g < 5; ++g) { av[4 * g] = row[g][0]; av[4 * g + 1] = row[g][1]; av[4 * g + 2] = row[g][2]; av[4 * g + 3] = row[g][3]; }
         float mx = -1e30f, p[20], l = 0.f;
         for (int m = 0; m < 20; ++m) mx = fmaxf(mx, av[m]);
         for (int m = 0; m < 20; ++m) {
@@ -943,7 +972,11 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     ha.vcp2 = f->x3 && f->up_x2 ? (_Float16*)f->vcp3 : nullptr;
     ha.vcp3 = f->x3 && !f->up_x2 ? (__bf16*)f->vcp3 : nullptr; ha.vcp3_plane = upsample_x3_vcp_elems(f->cap) / 3;     // plane stride fixed by the workspace capacity
     ha.alpha = c->alpha;
-    { StageTimer tm(c, "mdr_head", stream); k_mdr_head<512><<<B, 512, 0, st>>>(ha); }
+    {
+        StageTimer tm(c, "mdr_head", stream);
+        if (B <= 2 * f->n_cu) k_mdr_head<512, true><<<B, 512, 0, st>>>(ha);
+        else k_mdr_head<512, false><<<B, 512, 0, st>>>(ha);
+    }
     GATOR_HIP_CHECK(hipGetLastError());
     c->set_tap(TAP_MDR_LBF2, f->lbf, (int64_t)B * kV * kE);
     c->set_tap(TAP_VERT431, f->vc, (int64_t)B * kV * 3);

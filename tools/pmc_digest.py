@@ -2,7 +2,7 @@
 (FETCH_SIZE x 2 as the gfx950 guide prescribes for wide coalesced reads, + WRITE_SIZE; both in KiB units -> bytes), MFMA
 instruction counts and MFMA-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs).
 Writes profiles/<tag>_* (kernel stats CSV, one CSV per PMC pass, the summary JSON)."""
-import csv, glob, json, os, shutil, sys
+import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
@@ -11,6 +11,9 @@ KEEP = ('k_gat', 'k_mdr_layer', 'k_mdr_head', 'k_upsample', 'k_mdr_joint', 'k_pa
 
 
 def short(name):
+    m = re.match(r'_ZN5gator\d+_GLOBAL__N_1\d+(k_[a-z0-9_]+?)E', name)      # a signature rocprofv3 could not demangle (_Float16 arguments)
+    if m:
+        return m.group(1)
     n = name.replace('(anonymous namespace)::', '').replace('void ', '').replace('gator::', '')
     return n.split('(')[0].strip()
 
