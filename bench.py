@@ -49,21 +49,24 @@ X3_PRODUCTS = 6                  # bf16 MFMA partial products per fp32 product o
 PEAK_X3_TFLOPS = round(PEAK_BF16_TFLOPS / X3_PRODUCTS, 1)
 # which switch moves a stage back to the fp32-input MFMA kernels (read by the library when the context is created)
 STAGE_X3_SWITCH = {'gat': 'GATOR_GAT_X3', 'gat_tail': None, 'mdr_layer0': 'GATOR_MDR_X3', 'mdr_layer': 'GATOR_MDR_X3',
-                   'mdr_attn_head': 'GATOR_MDR_X3', 'upsample': 'GATOR_UPSAMPLE_X3'}
+                   'mdr_attn_head': 'GATOR_MDR_X3', 'mdr_layers': 'GATOR_MDR_X3', 'upsample': 'GATOR_UPSAMPLE_X3'}
 FLOPS_PER_MESH = {17: 4.10e8, 19: 4.18e8}      # dense algorithmic count
 BYTES_PER_MESH = {17: 83020, 19: 83060}        # compulsory HBM bytes (pose2d in, vertices + pose3d out)
 # algorithmic MFLOP per mesh per stage, J=17
 # mdr_layer  = one middle LBF launch: 431x431 attention core of layer l-1 (47.6) + its out-proj (3.5) + cross-attn/Mlp of
 #              layer l (37.5) + q/k/v in-proj of layer l (10.6) = 99.2 ; mdr_layer0 = tokenise + the last two items
+# mdr_layers = the four of them in one persistent launch (k_mdr_persist, the default): 48.7 + 2 x 99.2 + 51.4
 STAGE_MFLOP = {'upsample_bf16': 53.45, 'gat': 56.66, 'mdr_layer0': 48.7, 'mdr_layer': 99.2, 'mdr_attn_head': 51.4, 'mdr_head': 1.3,
+               'mdr_layers': 298.5,
                'upsample': 53.45}
 # inter-kernel operand bytes per mesh the dominant kernels are DESIGNED to move: the residual tile set
 # vf (14 tiles x 2 blocks x 4 KiB) and the Q/K/V tile sets, read and/or written once
 _VF, _QKV = 14 * 2 * 4096, 3 * 14 * 2 * 4096          # Q/K/V as two fp16 planes: 4 KiB tiles (6 KiB when GATOR_MDR_X3=1)
 STAGE_BYTES = {'mdr_layer0': _VF + _QKV, 'mdr_layer': 2 * (_VF + _QKV), 'mdr_attn_head': _VF + _QKV + 431 * 32 * 4 + 431 * 64 * 4,
+               'mdr_layers': 6 * (_VF + _QKV) + 431 * 32 * 4 + 431 * 64 * 4,
                'upsample': 3 * 431 * 2 * 3 + 6890 * 3 * 4, 'gat': 136 + 17 * 128 * 4 + 204 + 12 * 4096}
 STAGE_KERNEL = {'gat': 'k_gat', 'mdr_layer0': 'k_mdr_layer<0,', 'mdr_layer': 'k_mdr_layer<1,',
-                'mdr_attn_head': 'k_mdr_layer<2,', 'upsample': 'k_upsample_x'}
+                'mdr_attn_head': 'k_mdr_layer<2,', 'mdr_layers': 'k_mdr_persist', 'upsample': 'k_upsample_x'}
 # BASELINE.json `configs`, 1-based as VERDICT.md numbers them (config 1 is the reference's own CPU demo): per-GPU presets
 BASELINE_CONFIGS = {
     2: dict(batch=256, joints=17, precision='f32', mode='gather', gpus=1,
@@ -152,7 +155,7 @@ def launch_ranks(a):
 
 # MFLOP of a stage that run on TWO fp16 planes per operand (3 partial products per fp32 product: the 431x431 self-attention
 # core, QK^T + PV = 47.6 MFLOP per layer) when GATOR_MDR_X3 is 2 (the default); the rest of the stage is on three bf16 planes
-STAGE_X2_MFLOP = {'mdr_layer': 47.6, 'mdr_attn_head': 47.6}
+STAGE_X2_MFLOP = {'mdr_layer': 47.6, 'mdr_attn_head': 47.6, 'mdr_layers': 3 * 47.6}
 PEAK_X2_TFLOPS = round(PEAK_BF16_TFLOPS / 3, 1)
 
 

@@ -31,11 +31,11 @@ int fused_ensure_ws(gator_ctx* c, int B) {
     const size_t tiles = (size_t)cap * kVT * 2 * kTile;
     size_t n = 0;
     auto take = [&](size_t k) { size_t o = n; n += (k + 63) & ~(size_t)63; return o; };
-    const size_t o_vcp = take((size_t)MT * 3 * kCB * kTile), o_vc = take((size_t)cap * kV * 3), o_vf = take(2 * tiles),
-                 o_q = take(3 * tiles), o_k = take(3 * tiles), o_v = take(3 * tiles) /* q/k/v sized for X3 tiles (1.5x) */, o_jkv = take((size_t)cap * 12 * kTile),
+    const size_t o_vcp = take((size_t)MT * 3 * kCB * kTile), o_vc = take((size_t)cap * kV * 3), o_vf = take(3 * tiles),
+                 o_q = take(9 * tiles / 2), o_k = take(9 * tiles / 2), o_v = take(9 * tiles / 2) /* THREE tile sets each (k_mdr_persist writes every set once per forward); q/k/v sized for X3 tiles (1.5x) */, o_jkv = take((size_t)cap * 12 * kTile),
                  o_hf = take((size_t)cap * kV * 32), o_lbf = take((size_t)cap * kV * kE), o_feat = take((size_t)cap * J * kC),
                  o_xout = take((size_t)cap * J * 3), o_pc = take((size_t)cap * J * 133),
-                 o_vcp3 = take(std::max(upsample_x3_vcp_elems(cap), upsample_x2_vcp_elems(cap)) / 2), o_lpart = take(gat_tail_part_floats(cap, J));
+                 o_vcp3 = take(std::max(upsample_x3_vcp_elems(cap), upsample_x2_vcp_elems(cap)) / 2), o_lpart = take(gat_tail_part_floats(cap, J)), o_ctr = take(16 + (size_t)3 * cap);
     GATOR_HIP_CHECK(hipMalloc(&f->ws, n * sizeof(float)));
     GATOR_HIP_CHECK(hipMemset(f->ws, 0, n * sizeof(float)));
     GATOR_HIP_CHECK(hipDeviceSynchronize());      // the memset runs on the null stream; a non-blocking stream would not wait for it
@@ -44,6 +44,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
     f->vcp = f->ws + o_vcp; f->vc = f->ws + o_vc; f->vf = f->ws + o_vf; f->q = f->ws + o_q; f->k = f->ws + o_k;
     f->v = f->ws + o_v; f->jkv = f->ws + o_jkv; f->hf = f->ws + o_hf; f->lbf = f->ws + o_lbf; f->feat = f->ws + o_feat;
     f->xout = f->ws + o_xout; f->pc = f->ws + o_pc; f->vcp3 = f->ws + o_vcp3; f->lpart = f->ws + o_lpart;
+    f->mdr_ctr = reinterpret_cast<unsigned*>(f->ws + o_ctr);
     return GATOR_OK;
 }
 
@@ -210,6 +211,8 @@ int fused_create(gator_ctx* c, void* stream) {
     const char* mx3 = getenv("GATOR_MDR_X3");
     f->mdr_x3 = mx3 ? atoi(mx3) : 2;
     if (f->mdr_x3 < 0 || f->mdr_x3 > 2) return fail(GATOR_EINVAL, "GATOR_MDR_X3 must be 0, 1 or 2");
+    const char* mper = getenv("GATOR_MDR_PERSIST");
+    f->mdr_persist = mper ? (atoi(mper) != 0 ? 1 : 0) : -1;
     const size_t n_up = f->x3 ? 0 : (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)64 * kTile;
     const size_t total = n_up + 3 * n_layer + 24 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
     GATOR_HIP_CHECK(hipMalloc(&f->wbuf, total * sizeof(float)));

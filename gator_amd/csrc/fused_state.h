@@ -35,6 +35,8 @@ struct FusedWs {
     float *lbf = nullptr;               // [B][431][64] tap: verts tokens after LBF3 (reference layout)
     float *feat = nullptr, *xout = nullptr, *pc = nullptr;
     float *lpart = nullptr;             // [MT][J][2][kTile] lifter partial tiles (gat_tail.hip)
+    bool mdr_ctr_clean = false;         // the joint-token kernel queued before launch_mdr has zeroed mdr_ctr for it
+    unsigned* mdr_ctr = nullptr;        // k_mdr_persist: [8] tickets per XCD, [8] flags, [3][cap] tiles done per (stage, sample)
     void* vcp16 = nullptr;              // bf16 packed vert431 for the bf16 vertex GEMM (cap-sized)
     int vcp16_cap = 0;
 };
@@ -57,6 +59,7 @@ struct FusedState : FusedWs {
     float* g8stream = nullptr;          // the same tiles as four per-wave streams in consumption order (gat_roles.hip)
     bool gat8 = true;                   // one-sample-per-workgroup encoder: the two-role kernel k_gat8 (GATOR_GAT8=0: k_gat)
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
+    int mdr_persist = -1;               // the four MDR stages as ONE persistent launch (k_mdr_persist): -1 by batch size (launch_mdr), GATOR_MDR_PERSIST=0 never, =1 always
     int mdr_x3 = 2;                     // GATOR_MDR_X3: 0 fp32-input MFMA; 1 exact bf16 x 3 split everywhere; 2 (default) that + the 431x431 attention on two fp16 planes
     bool x3 = true;                     // split-precision vertex regressor (GATOR_UPSAMPLE_X3=0: fp32-input MFMA kernel)
     bool up_x2 = true;                  // ... on two fp16 planes (default; GATOR_UPSAMPLE_X3=1: the exact three bf16 planes)

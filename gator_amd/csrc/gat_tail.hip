@@ -46,6 +46,7 @@ __global__ __launch_bounds__(128) void k_gat_lifter(const LifterArgs a) {
 struct JointTailArgs {
     const float *pose2d, *feat, *part, *lifter_b;
     float *x_out, *jkv;           // jkv == nullptr: lifter only (stand-alone GAT entry point)
+    unsigned* mdr_ctr;            // non-null: zero k_mdr_persist's tickets and completion counts for the launch that follows (mdr_fused.hip)
     const float *jf5, *jf_p, *jf_b, *posj_T;       // get_joint_feature: columns 0..4 as [5][64], columns 5..132 packed [2][4], bias
     const float *j_n1w[3], *j_n1b[3], *j_wk_p[3], *j_wv_p[3];
     int B, J;
@@ -63,6 +64,10 @@ __global__ __launch_bounds__(256) void k_gat_joint(const JointTailArgs a) {
     __shared__ __attribute__((aligned(16))) float JF[2 * kTile];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J, tok = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (a.mdr_ctr) {
+        if (t < 3) a.mdr_ctr[16 + (size_t)t * a.B + b] = 0u;
+        if (b == 0 && t >= 64 && t < 80) a.mdr_ctr[t - 64] = 0u;
+    }
     // operands of the joint-token part are requested first: their latency hides behind the partial sums below
     const int tkj = tok < J ? tok : 0;
     WTile jw[4], kw[2];
@@ -165,7 +170,9 @@ int launch_gat_tail(gator_ctx* c, FusedState* f, const float* pose2d, const floa
     JointTailArgs a{};
     a.pose2d = pose2d; a.feat = feat; a.part = f->lpart; a.lifter_b = w.lifter_b; a.x_out = x_out; a.B = B; a.J = J;
     a.jkv = nullptr;
+    a.mdr_ctr = nullptr;
     if (joint) {
+        if (f->mdr_persist != 0) { a.mdr_ctr = f->mdr_ctr; f->mdr_ctr_clean = true; }
         a.jkv = f->jkv; a.jf5 = f->jfeat5; a.jf_p = f->jfeat128_p; a.jf_b = w.jfeat_b; a.posj_T = f->posj_T;
         for (int i = 0; i < 3; ++i) { a.j_n1w[i] = w.lay[i].n1w; a.j_n1b[i] = w.lay[i].n1b; a.j_wk_p[i] = f->lay[i].wk; a.j_wv_p[i] = f->lay[i].wv; }
     }

@@ -19,7 +19,9 @@
 #include "fused_state.h"
 #include "x3_common.h"
 
+#include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace gator {
 namespace {
@@ -405,32 +407,14 @@ template <bool X> __device__ __forceinline__ typename TokOp<X>::A mk(const f32x1
 // MODE 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
 // XA   0: everything on the fp32-input MFMA ; 1: split precision (exact bf16 x 3) everywhere ; 2: split-precision linears and
 //         the 431x431 self-attention on two fp16 planes (the default)
-template <int MODE, int XA>
-__global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) {
-    constexpr bool X = XA != 0;
-    constexpr int TQ = XA == 1 ? kTileX3 : kTile;
-    __shared__ f32x4 park[X ? 8 : 1][X ? 256 : 1];
-    auto park_vf = [&](const f32x16 (&v)[2]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            f32x4 t4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t4[j] = v[i >> 2][4 * (i & 3) + j];
-            park[i][threadIdx.x] = t4;
-        }
-    };
-    auto unpark_vf = [&](f32x16 (&v)[2]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x4 t4 = park[i][threadIdx.x];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[i >> 2][4 * (i & 3) + j] = t4[j];
-        }
-    };
-    // per-channel vectors of this launch (biases, norm weights) staged once per workgroup
-    enum { VO_SA3B = 0, VO_N1W = 64, VO_N1B = 128, VO_PROJB = 192, VO_N2W = 256, VO_N2B = 320, VO_FC2B = 384, VO_A2 = 448, VO_B2 = 512,
-           VO_SA0B = 576, VO_SA1B = 640, VO_HEADB = 704, VO_FC1B = 768, VO_TOKW3 = 1024, VO_TOTAL = 1216 };
-    __shared__ __attribute__((aligned(16))) float VT[VO_TOTAL];
+// per-channel vectors of a stage (biases, norm weights) staged once per workgroup in LDS
+enum { VO_SA3B = 0, VO_N1W = 64, VO_N1B = 128, VO_PROJB = 192, VO_N2W = 256, VO_N2B = 320, VO_FC2B = 384, VO_A2 = 448, VO_B2 = 512,
+       VO_SA0B = 576, VO_SA1B = 640, VO_HEADB = 704, VO_FC1B = 768, VO_TOKW3 = 1024, VO_TOTAL = 1216 };
+constexpr int kParkF4 = 8 * 256;       // f32x4 slots of the residual-stream parking area (split-precision forms only)
+
+// cooperative (256 threads); the caller puts a barrier behind it
+template <int MODE>
+__device__ __forceinline__ void mdr_stage_vectors(const MdrArgs& a, float* VT) {
     for (int e = threadIdx.x; e < VO_TOTAL / 4; e += 256) {
         const int off = 4 * e;
         const float* src = nullptr;
@@ -443,9 +427,35 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
         } else if (MODE < 2 && off >= VO_FC1B && off < VO_TOKW3) src = a.cur.fc1_b + (off - VO_FC1B);
         if (src) reinterpret_cast<f32x4*>(VT)[e] = *reinterpret_cast<const f32x4*>(src);
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int id = xcd_remap(blockIdx.x, nwg) * 4 + wave;
+}
+
+// one wave, one 32-token tile `id` = sample * 14 + tile of the sample
+template <int MODE, int XA>
+__device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const float* VT, f32x4* park) {
+    constexpr bool X = XA != 0;
+    constexpr int TQ = XA == 1 ? kTileX3 : kTile;
+    auto park_vf = [&](const f32x16 (&v)[2]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x4 t4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t4[j] = v[i >> 2][4 * (i & 3) + j];
+            park[i * 256 + threadIdx.x] = t4;
+        }
+    };
+    auto unpark_vf = [&](f32x16 (&v)[2]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 t4 = park[i * 256 + threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i >> 2][4 * (i & 3) + j] = t4[j];
+        }
+    };
+    // `lane` is opaque to the optimiser: inside k_mdr_persist's ticket loops every address that depends only on the lane (the
+    // weight tiles) would otherwise be loop-invariant, hoisted in front of the loop and kept alive across it (470 B of scratch)
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int h = lane >> 5;
     if (id >= a.B * kVT) return;
 #ifdef GATOR_DIAG
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = a.stamps ? clock64() : 0;
@@ -688,6 +698,107 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
 #endif
 }
 
+template <int MODE, int XA>
+__global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) {
+    __shared__ f32x4 park[XA != 0 ? kParkF4 : 1];
+    __shared__ __attribute__((aligned(16))) float VT[VO_TOTAL];
+    mdr_stage_vectors<MODE>(a, VT);
+    __syncthreads();
+    mdr_tile<MODE, XA>(a, xcd_remap(blockIdx.x, nwg) * 4 + (threadIdx.x >> 6), VT, park);
+}
+
+// ---- all four stages in ONE persistent launch -------------------------------------------------------------------------------
+// Why: a tile costs one SIMD ~85k cycles whether or not a second wave shares the SIMD, so a launch takes
+// ceil(tiles / 1024 SIMDs) tile times -- at B = 256 that is 3 584 tiles = 3.5 per SIMD, billed as 4, in each of the four launches
+// (measured: B = 219 / 256 / 292 -> 127 / 160 / 164 us for the middle launch).  Over all four stages there are exactly 14 tiles per
+// SIMD, so one launch that hands out (stage, tile) units from a queue and lets a unit wait only for ITS OWN sample's previous
+// stage -- the path's only cross-tile dependency is the self-attention's K/V of the sample -- has no fractional generation left.
+//   * one queue per XCD: sample b lives on XCD b % 8 for all four stages, so the Q/K/V/residual tile sets of a sample are written
+//     and read through the same L2 (workgroups are dealt round-robin to the XCDs; if they were not, only locality would suffer);
+//   * a workgroup takes a ticket (4 consecutive tiles of its XCD's list, stage-major), stages the stage's channel vectors, each
+//     wave waits until `done[stage - 1][sample]` says all 14 tiles of its sample are finished (agent-scope acquire), runs the
+//     unchanged tile body and bumps `done[stage][sample]` behind an agent-scope release;
+//   * tickets are handed out in dependency order and a workgroup holds a ticket only while it runs, so every wait is for a unit
+//     that some running workgroup already owns: no deadlock whatever the residency.  A poll budget turns a would-be hang (a bug)
+//     into a flag in ctr[kCtrError] and garbage output instead of a dead GPU.
+constexpr int kCtrError = 8, kCtrDone = 16;       // ctr: [0..7] tickets per XCD, [8] error flag, [16 + stage * B + b] tiles done
+struct MdrPersistArgs {
+    MdrArgs st[4];
+    unsigned* ctr;
+    int dbg;          // experiments (GATOR_MDR_PERSIST_DBG): 1 no dependency wait, 2 no L1 invalidate
+};
+template <int XA>
+__global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) {
+    __shared__ f32x4 park[XA != 0 ? kParkF4 : 1];
+    __shared__ __attribute__((aligned(16))) float VT[VO_TOTAL];
+    __shared__ int s_unit;
+    const int B = p.st[0].B, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned xcc;                                                // the XCD this workgroup REALLY runs on picks its queue
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int xcd = (int)(xcc & 7u);
+    const int nb = xcd < B ? (B - xcd + 7) >> 3 : 0;            // samples of this XCD: xcd, xcd + 8, ...
+    const int ntile = nb * kVT, units = (ntile + 3) >> 2;       // per stage
+    if (units == 0) return;
+    auto ticket = [&]() {
+        __syncthreads();                                        // everyone is done with s_unit (and, at a stage change, with VT)
+        if (threadIdx.x == 0) s_unit = (int)atomicAdd(p.ctr + xcd, 1u);
+        __syncthreads();
+        return s_unit;
+    };
+    int staged = -1;                                            // the stage whose channel vectors are in VT
+    // one ticket: (stage the channel vectors,) wait for the sample's previous stage, run the tile, publish it
+    auto run = [&](auto mode, const MdrArgs& a, int stage, int unit) {
+        constexpr int MODE = decltype(mode)::value;
+        const int lt = 4 * (unit - stage * units) + wave;
+        const bool live = lt < ntile;                           // (wave-uniform) a ticket's last waves may have nothing left
+        const int smp = xcd + 8 * (lt / kVT), id = smp * kVT + lt % kVT;
+        // the completion count of the sample's previous stage is requested FIRST: its L2 round trip (1 - 2 us under load, once per
+        // tile) hides behind the staging below instead of standing in front of the tile
+        const unsigned* d = p.ctr + kCtrDone + (size_t)(MODE > 0 ? stage - 1 : 0) * B + smp;
+        unsigned seen = kVT;
+        if (MODE > 0 && live && lane == 0 && !(p.dbg & 1)) seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (staged != stage) {                                  // tickets come in stage order: at most three times per workgroup
+            mdr_stage_vectors<MODE>(a, VT);
+            staged = stage;
+            __syncthreads();
+        }
+        if (!live) return;
+        if (MODE > 0 && !(p.dbg & 1)) {
+            if (lane == 0) {
+                int budget = 1 << 22;
+                while (seen < (unsigned)kVT && --budget > 0) {
+                    __builtin_amdgcn_s_sleep(8);
+                    seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (budget <= 0) atomicExch(p.ctr + kCtrError, 1u + stage);
+            }
+            // Acquire among CUs that share an L2, with NO cache invalidate: every tile of the three tile sets is written exactly once
+            // per launch (launch_mdr) and read only behind its completion count, and the L1 starts a launch empty, so neither
+            // the L1 nor the L2 can hold an older copy of what is read from here on.  (The agent-scope fence pair instead --
+            // `buffer_wbl2 sc1` / `buffer_inv sc1` at each of ~10k tile starts -- measured +240 us per forward; `buffer_inv sc1`
+            // alone +30 us.)  The compiler barrier keeps the tile's loads behind the poll.
+            asm volatile("" ::: "memory");
+        }
+        mdr_tile<MODE, XA>(a, id, VT, park);
+        if (MODE < 2) {
+            // Release to the same L2: the L1 is write-through, so once the stores are acknowledged (vmcnt 0) every CU of the XCD
+            // sees them; then the count goes up (an atomic executed in that L2).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(p.ctr + kCtrDone + (size_t)stage * B + smp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // Tickets come in stage order, so a workgroup's stages only ever go up: three plain loops, one tile body each (one loop with a
+    // switch keeps all three bodies' state alive at once: 256 VGPRs + 760 B of scratch).
+    int unit = ticket();
+    for (; unit < units; unit = ticket()) run(std::integral_constant<int, 0>(), p.st[0], 0, unit);
+    for (; unit < 3 * units; unit = ticket()) {
+        const int stage = unit >= 2 * units ? 2 : 1;
+        run(std::integral_constant<int, 1>(), p.st[stage], stage, unit);
+    }
+    for (; unit < 4 * units; unit = ticket()) run(std::integral_constant<int, 2>(), p.st[3], 3, unit);
+}
+
 // Joint tokens: jf = Linear(133->64)(pose_combine) + pos_j (MDR.py:130-134); per layer k = wk(LN1(jf)), v = wv(LN1(jf))
 // (MDR.py:37-38 with norm1 applied to the concatenated tokens, :65).  jf does not change across the three layers.
 // One workgroup (2 waves) per sample; wave w owns channel block w (= head w).  Output in MFMA operand order:
@@ -698,12 +809,17 @@ struct JointArgs {
     const float *n1w[3], *n1b[3], *wk_p[3], *wv_p[3];
     float* jkv;
     int J;
+    unsigned* mdr_ctr;      // non-null: zero k_mdr_persist's tickets and completion counts (B = gridDim.x)
 };
 __global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
     __shared__ __attribute__((aligned(16))) float PCt[5 * kTile];
     __shared__ __attribute__((aligned(16))) float JF[2 * kTile];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (a.mdr_ctr) {
+        if (t < 3) a.mdr_ctr[16 + (size_t)t * gridDim.x + b] = 0u;
+        if (b == 0 && t >= 64 && t < 80) a.mdr_ctr[t - 64] = 0u;
+    }
     for (int e = t; e < 5 * kTile; e += 128) {
         const int j4 = e & 3, ln = (e >> 2) & 63, g = (e >> 8) & 3, kb = e >> 10;
         const int tok = ln & 31, k = 32 * kb + 8 * g + 4 * (ln >> 5) + j4;
@@ -753,6 +869,7 @@ struct HeadArgs {
     __bf16* vcp3;           // non-null: write the hi/mid/lo bf16 planes of the split-precision vertex GEMM instead of vcp
     size_t vcp3_plane;
     _Float16* vcp2;         // non-null: write the scaled hi/lo fp16 planes of the two-plane vertex GEMM (upsample_x2.hip) instead
+    const unsigned* persist_err;   // non-null: k_mdr_persist's hang-guard flag; if it is set the outputs are poisoned with NaN (loud, not silent)
     int alpha;
 };
 // One workgroup per sample, three short phases with a barrier between them.  The kernel is a LATENCY chain, not a throughput one
@@ -843,6 +960,7 @@ __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a
     }
     __syncthreads();
     const int mt = b >> 5, sl = b & 31;
+    const bool poisoned = a.persist_err && *a.persist_err != 0u;
     if (tok) {
         if (!HOIST) load_rows();
         float av[20];
@@ -861,7 +979,8 @@ __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a
         for (int c = 0; c < 3; ++c) {
             float o = 0.f;
             for (int m = 0; m < 20; ++m) o += (p[m] * il) * bc[m][c];
-            const float val = sc * o + cc[c];
+            float val = sc * o + cc[c];
+            if (poisoned) val = __builtin_nanf("");
             a.vc[((size_t)b * kV + v) * 3 + c] = val;
             if (a.vcp2) {       // two fp16 planes of 2^4 * val, in k_upsample_x2's operand order [mt/4][v/16][mt%4][l'][plane][lane][v%8]
                 const float sv = val * 16.0f;
@@ -907,10 +1026,16 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     JointArgs ja;
     ja.pc = pc; ja.jw_p = f->jfeat_p; ja.jb = w.jfeat_b; ja.posj_T = f->posj_T; ja.jkv = f->jkv; ja.J = c->J;
     for (int i = 0; i < 3; ++i) { ja.n1w[i] = w.lay[i].n1w; ja.n1b[i] = w.lay[i].n1b; ja.wk_p[i] = f->lay[i].wk; ja.wv_p[i] = f->lay[i].wv; }
-    if (pc) { StageTimer tm(c, "mdr_joint", stream); k_mdr_joint<<<B, 128, 0, st>>>(ja); }    // else: done by k_gat's epilogue
+    ja.mdr_ctr = nullptr;
+    if (pc) {
+        if (f->mdr_persist != 0) { ja.mdr_ctr = f->mdr_ctr; f->mdr_ctr_clean = true; }
+        StageTimer tm(c, "mdr_joint", stream);
+        k_mdr_joint<<<B, 128, 0, st>>>(ja);
+    }    // else: done by k_gat's epilogue / k_gat_joint
     const size_t per = (size_t)f->cap * kVT * 2 * kTile;      // one [B][14][2] tile set
     const size_t perq = (size_t)f->cap * kVT * 2 * (f->mdr_x3 == 1 ? kTileX3 : kTile);      // q/k/v tile sets: X3 tiles are 1.5x, fp32 and X2 tiles 4 KiB
-    float* set[2][4] = {{f->vf, f->q, f->k, f->v}, {f->vf + per, f->q + perq, f->k + perq, f->v + perq}};
+    float* set[3][4] = {{f->vf, f->q, f->k, f->v}, {f->vf + per, f->q + perq, f->k + perq, f->v + perq},
+                        {f->vf + 2 * per, f->q + 2 * perq, f->k + 2 * perq, f->v + 2 * perq}};
     MdrArgs a{};
     a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.xout = pc ? nullptr : x_out; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
     a.head_w = f->mdr_x3 ? f->wxbuf + (size_t)(f->head_w - f->lay[0].wq) / kTile * kTileX3 : f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = f->lbf;
@@ -923,17 +1048,33 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
 #else
     constexpr size_t solo = 0;
 #endif
+    MdrPersistArgs pa{};
+    // One persistent launch or four?  Same tile body, bitwise the same results; the persistent form wins where the four launches
+    // waste a fractional generation (R = workgroups per CU: 3.5 at B = 256, 5.25 at B = 384) and never loses once R is large; below
+    // R = 3 its per-sample dependency chain costs more than the fraction it saves (sweep in DESIGN.md 4d).
+    const bool ctr_clean = f->mdr_ctr_clean;      // zeroed for THIS call by the joint-token kernel queued just before (either entry point)
+    f->mdr_ctr_clean = false;
+    const double R = (double)nwg / f->n_cu;
+    const bool auto_persist = (R >= 3.0 && std::ceil(R) - R >= 0.4) || R >= 6.5;
+    bool persist = f->mdr_persist < 0 ? auto_persist : f->mdr_persist > 0;
+#ifdef GATOR_DIAG
+    if (want_stamps) persist = false;       // the stamps describe the per-stage launches
+#endif
     for (int li = 0; li <= 3; ++li) {
 #ifdef GATOR_DIAG
         a.stamps = (li == 1) ? d_st : nullptr;
 #endif
-        float** in = set[(li + 1) & 1];
-        float** out = set[li & 1];
+        // four launches: two sets in turn.  One persistent launch: stage li writes set li and nothing else ever does, so no CU can
+        // hold a stale L1 copy of a tile it reads (a line is only read after its one and only write) -- no cache invalidate in the
+        // kernel at all (`buffer_inv sc1` per tile start cost 30 us per forward, and `sc0` does not touch the L1 in this mode)
+        float** in = persist ? set[(li + 2) % 3] : set[(li + 1) & 1];
+        float** out = persist ? set[li % 3] : set[li & 1];
         a.layer = li;
         a.vf_in = in[0]; a.q_in = in[1]; a.k_in = in[2]; a.v_in = in[3];
         a.vf_out = out[0]; a.q_out = out[1]; a.k_out = out[2]; a.v_out = out[3];
         if (li > 0) a.prev = make_layer(f, c, li - 1);
         if (li < 3) a.cur = make_layer(f, c, li);
+        if (persist) { pa.st[li] = a; continue; }
         StageTimer tm(c, li == 0 ? "mdr_layer0" : (li < 3 ? "mdr_layer" : "mdr_attn_head"), stream);
         if (f->mdr_x3 == 2) {
             if (li == 0) k_mdr_layer<0, 2><<<nwg, 256, solo, st>>>(a, nwg);
@@ -948,6 +1089,17 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
             else if (li < 3) k_mdr_layer<1, 0><<<nwg, 256, 0, st>>>(a, nwg);
             else k_mdr_layer<2, 0><<<nwg, 256, 0, st>>>(a, nwg);
         }
+    }
+    if (persist) {      // the four stages as one launch (k_mdr_persist): tickets and per-sample completion counts start from zero
+        pa.ctr = f->mdr_ctr;
+        if (!ctr_clean) GATOR_HIP_CHECK(hipMemsetAsync(f->mdr_ctr, 0, (kCtrDone + (size_t)3 * B) * sizeof(unsigned), st));
+        StageTimer tm(c, "mdr_layers", stream);
+        static const int dbg = getenv("GATOR_MDR_PERSIST_DBG") ? atoi(getenv("GATOR_MDR_PERSIST_DBG")) : 0;
+        pa.dbg = dbg & 3;
+        const int grid = (dbg & 4) ? f->n_cu : 2 * f->n_cu;       // two workgroups per CU is what the registers allow; any grid drains the queues
+        if (f->mdr_x3 == 2) k_mdr_persist<2><<<grid, 256, 0, st>>>(pa);
+        else if (f->mdr_x3 == 1) k_mdr_persist<1><<<grid, 256, 0, st>>>(pa);
+        else k_mdr_persist<0><<<grid, 256, 0, st>>>(pa);
     }
 #ifdef GATOR_DIAG
     if (d_st) {
@@ -969,6 +1121,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     HeadArgs ha;
     ha.hf = f->hf; ha.bn_w = w.bn_w; ha.bn_b = w.bn_b; ha.bn_mean = w.bn_mean; ha.bn_var = w.bn_var;
     ha.bconv_w = w.bconv_w; ha.bconv_b = w.bconv_b; ha.vc = f->vc; ha.vcp = f->vcp;
+    ha.persist_err = persist ? f->mdr_ctr + kCtrError : nullptr;
     ha.vcp2 = f->x3 && f->up_x2 ? (_Float16*)f->vcp3 : nullptr;
     ha.vcp3 = f->x3 && !f->up_x2 ? (__bf16*)f->vcp3 : nullptr; ha.vcp3_plane = upsample_x3_vcp_elems(f->cap) / 3;     // plane stride fixed by the workspace capacity
     ha.alpha = c->alpha;

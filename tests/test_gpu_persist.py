@@ -1,0 +1,61 @@
+"""The four MDR stages as one persistent launch (k_mdr_persist, mdr_fused.hip) against the four per-stage launches.
+
+Both forms run the same tile body, so they must agree BIT FOR BIT at every batch size -- including the ones where the library's own
+rule would not pick the persistent form -- and the persistent form must not depend on how many samples share an XCD's queue."""
+import numpy as np
+import pytest
+import torch
+
+from gator_amd import synthetic
+from tests.helpers import build_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _forward(monkeypatch, mode, name, x):
+    if mode is None:
+        monkeypatch.delenv('GATOR_MDR_PERSIST', raising=False)
+    else:
+        monkeypatch.setenv('GATOR_MDR_PERSIST', mode)
+    z, m = build_model(name, 'fused')              # a fresh module -> a fresh context, which reads the switch
+    v, p = m(x)
+    v2, p2 = m(x)                                  # second call: tickets and completion counts must have been reset
+    torch.cuda.synchronize()
+    assert torch.equal(v, v2) and torch.equal(p, p2)
+    return v, p, m
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('name,J,B', [('h36m17_bn', 17, 1), ('h36m17_bn', 17, 7), ('h36m17_bn', 17, 100), ('h36m17_bn', 17, 256),
+                                      ('coco19_alpha', 19, 300), ('h36m17_bn', 17, 1100)])
+def test_persistent_launch_is_bitwise_the_four_launches(monkeypatch, name, J, B):
+    x = torch.from_numpy(synthetic.synthetic_pose2d(B, J, seed=11)).cuda()
+    v0, p0, _ = _forward(monkeypatch, '0', name, x)
+    v1, p1, m1 = _forward(monkeypatch, '1', name, x)
+    va, pa, _ = _forward(monkeypatch, None, name, x)
+    assert torch.isfinite(v1).all()
+    assert torch.equal(v0, v1) and torch.equal(p0, p1)
+    assert torch.equal(v0, va) and torch.equal(p0, pa)
+    # a sample's result does not depend on the batch (and so on the queue) it went through; from 1024 samples on the ENCODER is
+    # chosen by batch size (tests/test_gpu_tiled.py), so the check stops there
+    if B >= 1024:
+        return
+    idx = sorted({0, B // 2, B - 1})
+    vs, ps = m1(x[idx].contiguous())
+    assert torch.equal(vs, v1[idx]) and torch.equal(ps, p1[idx])
+
+
+@pytest.mark.timeout(300)
+def test_persistent_stage_entry_point_and_changing_batches(monkeypatch):
+    """gator_mdr_forward (pose_combine in, k_mdr_joint resets the counters) and a context whose batch size changes from call to call."""
+    monkeypatch.setenv('GATOR_MDR_PERSIST', '1')
+    z, m = build_model('h36m17_bn', 'fused')
+    monkeypatch.setenv('GATOR_MDR_PERSIST', '0')
+    z0, m0 = build_model('h36m17_bn', 'fused')
+    g = torch.Generator().manual_seed(3)
+    for B in (40, 3, 260, 40):
+        pc = torch.randn(B, 17, 133, generator=g).cuda()
+        assert torch.equal(m.pose2mesh(pc), m0.pose2mesh(pc)), B
+        x = torch.from_numpy(synthetic.synthetic_pose2d(B, 17, seed=B)).cuda()
+        a, b = m(x), m0(x)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), B
