@@ -1050,12 +1050,13 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
 #endif
     MdrPersistArgs pa{};
     // One persistent launch or four?  Same tile body, bitwise the same results; the persistent form wins where the four launches
-    // waste a fractional generation (R = workgroups per CU: 3.5 at B = 256, 5.25 at B = 384) and never loses once R is large; below
-    // R = 3 its per-sample dependency chain costs more than the fraction it saves (sweep in DESIGN.md 4d).
+    // waste a fractional generation (R = workgroups per CU: 3.5 at B = 256 is billed as 4, 5.25 at B = 384 as 6).  Below R = 3 its
+    // per-sample dependency chain costs more than the fraction it saves, and with nothing to save (B = 512, 1024, 2048: R whole)
+    // the four launches are 0 - 2 % faster (sweep in DESIGN.md 4d).
     const bool ctr_clean = f->mdr_ctr_clean;      // zeroed for THIS call by the joint-token kernel queued just before (either entry point)
     f->mdr_ctr_clean = false;
     const double R = (double)nwg / f->n_cu;
-    const bool auto_persist = (R >= 3.0 && std::ceil(R) - R >= 0.4) || R >= 6.5;
+    const bool auto_persist = R >= 3.0 && (std::ceil(R) - R) / R >= 0.04;
     bool persist = f->mdr_persist < 0 ? auto_persist : f->mdr_persist > 0;
 #ifdef GATOR_DIAG
     if (want_stamps) persist = false;       // the stamps describe the per-stage launches
