@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
 //     wave waits until `done[stage - 1][sample]` says all 14 tiles of its sample are finished (agent-scope acquire), runs the
 //     unchanged tile body and bumps `done[stage][sample]` behind an agent-scope release;
 //   * tickets are handed out in dependency order and a workgroup holds a ticket only while it runs, so every wait is for a unit
-//     that some running workgroup already owns: no deadlock whatever the residency.  A poll budget turns a would-be hang (a bug)
+//     that some running workgroup already owns: no deadlock whatever the residency.  A poll budget (~6 s) turns a would-be hang (a bug)
 //     into a flag in ctr[kCtrError] and garbage output instead of a dead GPU.
 constexpr int kCtrError = 8, kCtrDone = 16;       // ctr: [0..7] tickets per XCD, [8] error flag, [16 + stage * B + b] tiles done
 struct MdrPersistArgs {
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) 
         if (!live) return;
         if (MODE > 0 && !(p.dbg & 1)) {
             if (lane == 0) {
-                int budget = 1 << 22;
+                int budget = 1 << 24;                           // ~6 s of polling
                 while (seen < (unsigned)kVT && --budget > 0) {
                     __builtin_amdgcn_s_sleep(8);
                     seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
