@@ -11,6 +11,7 @@
 // Every output depends only on its own sample (an MFMA column never mixes samples), so results stay independent of the batch.
 #include "fused_common.h"
 #include "fused_state.h"
+#include "x3_common.h"
 
 namespace gator {
 namespace {
@@ -50,6 +51,7 @@ struct JointTailArgs {
     const float *jf5, *jf_p, *jf_b, *posj_T;       // get_joint_feature: columns 0..4 as [5][64], columns 5..132 packed [2][4], bias
     const float *j_n1w[3], *j_n1b[3], *j_wk_p[3], *j_wv_p[3];
     int B, J;
+    int x2;                       // K/V tiles as two fp16 planes of 16 x value (mdr_fused.hip: cross_attention_head_x2)
 };
 
 __device__ __forceinline__ float row_sum32x2(const f32x16& a, const f32x16& b) {
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void k_gat_joint(const JointTailArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) r0[r] = (kap(r) + 4 * h < J) ? r0[r] : 0.f;
         }
-        store_block(out, lane, r0);
+        if (a.x2) x2_store(out, lane, x2_split(r0 * 16.0f)); else store_block(out, lane, r0);
         kw[0] = nw0;
         kw[1] = nw1;
     }
@@ -171,6 +173,7 @@ int launch_gat_tail(gator_ctx* c, FusedState* f, const float* pose2d, const floa
     a.pose2d = pose2d; a.feat = feat; a.part = f->lpart; a.lifter_b = w.lifter_b; a.x_out = x_out; a.B = B; a.J = J;
     a.jkv = nullptr;
     a.mdr_ctr = nullptr;
+    a.x2 = f->mdr_x3 == 2;
     if (joint) {
         if (f->mdr_persist != 0) { a.mdr_ctr = f->mdr_ctr; f->mdr_ctr_clean = true; }
         a.jkv = f->jkv; a.jf5 = f->jfeat5; a.jf_p = f->jfeat128_p; a.jf_b = w.jfeat_b; a.posj_T = f->posj_T;

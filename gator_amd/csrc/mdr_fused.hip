@@ -20,6 +20,7 @@
 #include "x3_common.h"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <type_traits>
 
@@ -355,6 +356,36 @@ __device__ __forceinline__ f32x16 cross_attention_head(const float* __restrict__
     return dot16(vb, S * inv, zero16());
 }
 
+// The same on two fp16 planes (GATOR_MDR_X3=2): the joint K/V tiles arrive as X2 operand tiles scaled by 16 (k_gat_joint /
+// k_mdr_joint), q and the probabilities are split in registers (x 16, x 64) - 24 fp16 MFMAs of 32 cycles per tile instead of 64
+// fp32-input MFMAs of 64 cycles.  Like the 431x431 attention this rounds its operands to 22 bits; a softmax average over 17 joints.
+__device__ __forceinline__ f32x16 cross_attention_head_x2(const float* __restrict__ kj, const float* __restrict__ vjp,
+                                                          const f32x16& qh, int J, int lane) {
+    const int h = lane >> 5;
+    const X2 kx = x2_load(kj, lane);
+    f32x16 S = x2_mma(kx, x2_split(qh * 16.0f), zero16());                 // 256 x S^T[joint][token]
+    const X2 vx = x2_load(vjp, lane);                                      // in flight during the softmax
+    const float c = kLog2e * 0.17677669529663688110f * (1.0f / 256.0f);    // head_dim ** -0.5 (MDR.py:25), exp2 domain
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float s = (kap(r) + 4 * h < J) ? S[r] * c : -1e30f;
+        S[r] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = fmaxf(mx, xhalf(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(S[r] - mx);
+        S[r] = p;
+        sum += p;
+    }
+    sum += xhalf(sum);
+    const float inv = 64.0f / sum;                                         // probabilities x 64: low plane stays fp16-normal
+    return x2_mma(vx, x2_split(S * inv), zero16()) * (1.0f / 1024.0f);
+}
+
 // ---- weight stream of the tokenwise part: two buffers of one tile pair each (2 x 32 VGPRs).  The pair for the NEXT
 // product is requested right after the current product's MFMAs are queued, so its L2 latency hides behind them and
 // behind the co-resident wave.  MDR_PIN keeps the order (memory ops and scheduler).
@@ -577,7 +608,10 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         B = ldw<X>(w.proj, 2, 3, lane);
         MDR_PIN();
 #pragma unroll
-        for (int hd = 0; hd < 2; ++hd) o[hd] = cross_attention_head(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], a.J, lane);
+        for (int hd = 0; hd < 2; ++hd) {
+            if constexpr (XA == 2) o[hd] = cross_attention_head_x2(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], a.J, lane);
+            else o[hd] = cross_attention_head(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], a.J, lane);
+        }
         const Act ox[2] = {mk<X>(o[0]), mk<X>(o[1])};
         const f32x16 y0 = lin2_T(A, ox, chanvec_lds(VT, VO_PROJB, h));
         A = ldw<X>(w.fc1, 0, 1, lane);                                            // MLP chunk 0: fc1 rows 0..31
@@ -744,12 +778,21 @@ __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) 
         __syncthreads();                                        // everyone is done with s_unit (and, at a stage change, with VT)
         if (threadIdx.x == 0) s_unit = (int)atomicAdd(p.ctr + xcd, 1u);
         __syncthreads();
-        return s_unit;
+        return __builtin_amdgcn_readfirstlane(s_unit);          // a scalar: stage, tile and sample ids stay out of the VGPRs
     };
     int staged = -1;                                            // the stage whose channel vectors are in VT
     // one ticket: (stage the channel vectors,) wait for the sample's previous stage, run the tile, publish it
-    auto run = [&](auto mode, const MdrArgs& a, int stage, int unit) {
+    auto run = [&](auto mode, int stage, int unit) {
         constexpr int MODE = decltype(mode)::value;
+        // the stage's arguments (p.st[stage]) through a pointer into the kernel-argument segment that the optimiser cannot see
+        // through: otherwise every argument load of the body is loop-invariant, hoisted in front of the ticket loop and held in
+        // SGPRs across it (106 SGPRs, spills into VGPRs, scratch)
+        typedef const __attribute__((address_space(4))) MdrArgs* KArgPtr;
+        typedef const __attribute__((address_space(4))) char* KBytePtr;
+        unsigned aoff = (unsigned)offsetof(MdrPersistArgs, st) + (unsigned)__builtin_amdgcn_readfirstlane(stage) * (unsigned)sizeof(MdrArgs);
+        asm volatile("" : "+s"(aoff));
+        KArgPtr ap = (KArgPtr)((KBytePtr)__builtin_amdgcn_kernarg_segment_ptr() + aoff);
+        const MdrArgs& a = *(const MdrArgs*)ap;
         const int lt = 4 * (unit - stage * units) + wave;
         const bool live = lt < ntile;                           // (wave-uniform) a ticket's last waves may have nothing left
         const int smp = xcd + 8 * (lt / kVT), id = smp * kVT + lt % kVT;
@@ -791,12 +834,12 @@ __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) 
     // Tickets come in stage order, so a workgroup's stages only ever go up: three plain loops, one tile body each (one loop with a
     // switch keeps all three bodies' state alive at once: 256 VGPRs + 760 B of scratch).
     int unit = ticket();
-    for (; unit < units; unit = ticket()) run(std::integral_constant<int, 0>(), p.st[0], 0, unit);
+    for (; unit < units; unit = ticket()) run(std::integral_constant<int, 0>(), 0, unit);
     for (; unit < 3 * units; unit = ticket()) {
         const int stage = unit >= 2 * units ? 2 : 1;
-        run(std::integral_constant<int, 1>(), p.st[stage], stage, unit);
+        run(std::integral_constant<int, 1>(), stage, unit);
     }
-    for (; unit < 4 * units; unit = ticket()) run(std::integral_constant<int, 2>(), p.st[3], 3, unit);
+    for (; unit < 4 * units; unit = ticket()) run(std::integral_constant<int, 2>(), 3, unit);
 }
 
 // Joint tokens: jf = Linear(133->64)(pose_combine) + pos_j (MDR.py:130-134); per layer k = wk(LN1(jf)), v = wv(LN1(jf))
@@ -810,6 +853,7 @@ struct JointArgs {
     float* jkv;
     int J;
     unsigned* mdr_ctr;      // non-null: zero k_mdr_persist's tickets and completion counts (B = gridDim.x)
+    int x2;                 // K/V tiles as two fp16 planes of 16 x value (cross_attention_head_x2) instead of fp32 blocks
 };
 __global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
     __shared__ __attribute__((aligned(16))) float PCt[5 * kTile];
@@ -850,13 +894,13 @@ __global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
         mma2_T(load_wtile(a.wk_p[li], wave * 2 + 0, lane), fz[0], kt, load_wtile(a.wk_p[li], wave * 2 + 1, lane), fz[1], k1);
         kt += k1;
         if (!tok_ok) kt = zero16();             // joints >= J: zero rows (masked in the softmax anyway)
-        store_block(out + wave * kTile, lane, kt);
+        if (a.x2) x2_store(out + wave * kTile, lane, x2_split(kt * 16.0f)); else store_block(out + wave * kTile, lane, kt);
         f32x16 vt = zero16(), v1 = zero16();
         mma2_C(load_wtile(a.wv_p[li], wave * 2 + 0, lane), fz[0], vt, load_wtile(a.wv_p[li], wave * 2 + 1, lane), fz[1], v1);
         vt += v1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) vt[r] = (kap(r) + 4 * h < J) ? vt[r] : 0.f;
-        store_block(out + (2 + wave) * kTile, lane, vt);
+        if (a.x2) x2_store(out + (2 + wave) * kTile, lane, x2_split(vt * 16.0f)); else store_block(out + (2 + wave) * kTile, lane, vt);
     }
 }
 
@@ -1027,6 +1071,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     ja.pc = pc; ja.jw_p = f->jfeat_p; ja.jb = w.jfeat_b; ja.posj_T = f->posj_T; ja.jkv = f->jkv; ja.J = c->J;
     for (int i = 0; i < 3; ++i) { ja.n1w[i] = w.lay[i].n1w; ja.n1b[i] = w.lay[i].n1b; ja.wk_p[i] = f->lay[i].wk; ja.wv_p[i] = f->lay[i].wv; }
     ja.mdr_ctr = nullptr;
+    ja.x2 = f->mdr_x3 == 2;
     if (pc) {
         if (f->mdr_persist != 0) { ja.mdr_ctr = f->mdr_ctr; f->mdr_ctr_clean = true; }
         StageTimer tm(c, "mdr_joint", stream);

@@ -71,7 +71,8 @@ __device__ __forceinline__ f32x16 x3_mma(const X3& A, const X3& B, f32x16 acc) {
     return acc;
 }
 
-// ---- two-plane fp16 operands ("X2"), used ONLY for the 431x431 self-attention of the MDR layers (Q, K, V, P) ----------------
+// ---- two-plane fp16 operands ("X2"): the 431x431 self-attention of the MDR layers (Q, K, V, P), their cross-attention over the J
+// joint tokens (q, K, V, P; round 3) and the vertex regressor (upsample_x2.hip) -- the places where a result averages many terms ----
 // x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits, three partial products (hi*hi, hi*lo, lo*hi) per k-step
 // instead of six.  Unlike the exact three-way bf16 split this ROUNDS the operands (2^-23 relative), which is only acceptable
 // where the result is an average over many terms: measured in the fp64 oracle (two real fp16 planes, all other arithmetic exact)
