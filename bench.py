@@ -466,12 +466,14 @@ def main():
             # The same workload, same process, same box, with the library's A/B switches (read when a context is created).  The
             # headline's 431x431 attention core and its vertex regressor ROUND their operands to two fp16 planes (22 bits; output
             # parity demonstrated in tests/test_gpu_x3.py); `exact_split` is the build without any rounded operand, `fp32_mfma` every product on the
-            # fp32-input MFMA, `k_gat` the previous one-sample-per-workgroup encoder.
+            # fp32-input MFMA, `k_gat` the previous one-sample-per-workgroup encoder, `four MDR launches` the per-stage form of the
+            # MDR layers (bitwise the same results as the persistent launch).
             variants = {}
             for vname, env in (('headline, re-measured with the variants\' protocol (5 blocks, later in the run: clocks drift)', {}),
                                ('exact_split (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1)', {'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1'}),
                                ('three-plane vertex regressor (GATOR_UPSAMPLE_X3=1)', {'GATOR_UPSAMPLE_X3': '1'}),
                                ('fp32_mfma (GATOR_GAT_X3=0 GATOR_MDR_X3=0 GATOR_UPSAMPLE_X3=0)', {'GATOR_GAT_X3': '0', 'GATOR_MDR_X3': '0', 'GATOR_UPSAMPLE_X3': '0'}),
+                               ('four MDR launches instead of the persistent one (GATOR_MDR_PERSIST=0)', {'GATOR_MDR_PERSIST': '0'}),
                                ('k_gat encoder (GATOR_GAT8=0)', {'GATOR_GAT8': '0'})):
                 old = {k: os.environ.get(k) for k in env}
                 os.environ.update(env)
