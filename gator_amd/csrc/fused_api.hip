@@ -277,7 +277,13 @@ int fused_create(gator_ctx* c, void* stream) {
         if (f->mdr_x3) {     // split-precision image of the three layers' tile grids and the head tiles (contiguous in wbuf)
             const int64_t ntiles = (dst + 2 * kTile - f->lay[0].wq) / kTile;
             GATOR_HIP_CHECK(hipMalloc(&f->wxbuf, (size_t)ntiles * kTileX3 * sizeof(float)));
-            rc = fused_repack_x3(f->lay[0].wq, f->wxbuf, ntiles, stream);
+            if (f->mdr_x3 == 2) {     // three fp16 planes under one power-of-two scale (x3_common.h: the 4-product linears)
+                float left = 0.f;
+                rc = fused_repack_h3(f->lay[0].wq, f->wxbuf, ntiles, &f->mdr_wshift, &left, stream);
+                if (rc == GATOR_OK && left > 1e-7f) rc = fail(GATOR_EUNSUPPORTED, "MDR weights span more than fp16 x 3 planes hold exactly (residual %.2e of the largest weight): use GATOR_MDR_X3=1", left);
+            } else {
+                rc = fused_repack_x3(f->lay[0].wq, f->wxbuf, ntiles, stream);
+            }
             if (rc) return rc;
         }
         float* hbd = take(64);

@@ -191,6 +191,39 @@ __device__ __forceinline__ f32x2 gelu_f2(f32x2 x) {
     phi[1] = x[1] < 0.f ? e[1] : up[1];
     return x * phi;
 }
+// The same for a tile that holds S x its value (k = 1 / S, a power of two): returns S x GELU(value).  k only rescales the constant
+// of the first multiplication, so every rounding is the one gelu_f2 makes on the unscaled value.
+__device__ __forceinline__ f32x2 gelu_f2_scaled(f32x2 x, float k) {
+    const f32x2 a = x * (0.70710678118654752440f * k);
+    f32x2 t;
+    t[0] = fminf(fabsf(a[0]), 4.3f);
+    t[1] = fminf(fabsf(a[1]), 4.3f);
+    f32x2 r = pk_fma(f32x2(-4.435285315e-05f), t, f32x2(4.369443071e-04f));
+    r = pk_fma(r, t, f32x2(-1.460381877e-03f));
+    r = pk_fma(r, t, f32x2(-8.251648338e-04f));
+    r = pk_fma(r, t, f32x2(2.830188636e-02f));
+    r = pk_fma(r, t, f32x2(-1.485066472e-01f));
+    r = pk_fma(r, t, f32x2(-9.184098145e-01f));
+    r = pk_fma(r, t, f32x2(-1.627909326e+00f));
+    r = pk_fma(r, t, f32x2(-9.999999783e-01f));
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(r[0]);
+    e[1] = __builtin_amdgcn_exp2f(r[1]);
+    const f32x2 up = 1.0f - e;
+    f32x2 phi;
+    phi[0] = x[0] < 0.f ? e[0] : up[0];
+    phi[1] = x[1] < 0.f ? e[1] : up[1];
+    return x * phi;
+}
+__device__ __forceinline__ void gelu_tile_scaled(f32x16& v, float k) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        f32x2 p;
+        p[0] = v[r]; p[1] = v[r + 1];
+        p = gelu_f2_scaled(p, k);
+        v[r] = p[0]; v[r + 1] = p[1];
+    }
+}
 // GELU over a whole register tile
 __device__ __forceinline__ void gelu_tile(f32x16& v) {
 #pragma unroll

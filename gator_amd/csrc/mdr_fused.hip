@@ -46,6 +46,7 @@ struct MdrArgs {
     const float *head_w, *head_b;
     float *hf, *lbf;
     LayerW prev, cur;        // prev: layer whose attention/out-proj runs first; cur: layer whose tokenwise part runs
+    float lin_s, lin_inv;    // GATOR_MDR_X3=2: every token-wise linear returns lin_s x its value (x3_common.h: 4-product linears); lin_inv = 1 / lin_s
 #ifdef GATOR_DIAG
     unsigned long long* stamps;   // diagnostic build only (libgator_hip_diag.so, GATOR_MDR_STAMPS=1)
 #endif
@@ -360,10 +361,10 @@ __device__ __forceinline__ f32x16 cross_attention_head(const float* __restrict__
 // k_mdr_joint), q and the probabilities are split in registers (x 16, x 64) - 24 fp16 MFMAs of 32 cycles per tile instead of 64
 // fp32-input MFMAs of 64 cycles.  Like the 431x431 attention this rounds its operands to 22 bits; a softmax average over 17 joints.
 __device__ __forceinline__ f32x16 cross_attention_head_x2(const float* __restrict__ kj, const float* __restrict__ vjp,
-                                                          const f32x16& qh, int J, int lane) {
+                                                          const f32x16& qh, float qscale /* 16 / (the factor qh carries) */, int J, int lane) {
     const int h = lane >> 5;
     const X2 kx = x2_load(kj, lane);
-    f32x16 S = x2_mma(kx, x2_split(qh * 16.0f), zero16());                 // 256 x S^T[joint][token]
+    f32x16 S = x2_mma(kx, x2_split(qh * qscale), zero16());                // 256 x S^T[joint][token]
     const X2 vx = x2_load(vjp, lane);                                      // in flight during the softmax
     const float c = kLog2e * 0.17677669529663688110f * (1.0f / 256.0f);    // head_dim ** -0.5 (MDR.py:25), exp2 domain
     float mx = -1e30f;
@@ -425,14 +426,28 @@ __device__ __forceinline__ W2X ldw2x(const float* __restrict__ Wx, int i0, int i
 }
 __device__ __forceinline__ f32x16 lin2_T(const W2X& w, const X3 (&x)[2], f32x16 init) { return x3_mma(w.t[1], x[1], x3_mma(w.t[0], x[0], init)); }
 __device__ __forceinline__ f32x16 lin2_C(const W2X& w, const X3 (&x)[2]) { return x3_mma(x[1], w.t[1], x3_mma(x[0], w.t[0], zero16())); }
-template <bool X> struct TokOp;
-template <> struct TokOp<false> { typedef W2 W; typedef f32x16 A; };
-template <> struct TokOp<true> { typedef W2X W; typedef X3 A; };
-template <bool X> __device__ __forceinline__ typename TokOp<X>::W ldw(const float* __restrict__ Wp, int i0, int i1, int lane) {
-    if constexpr (X) return ldw2x(Wp, i0, i1, lane); else return ldw2(Wp, i0, i1, lane);
+// XA == 2: weights as two H3 tiles (three exact fp16 planes, 48 VGPRs), activations as X2 (two fp16 planes of 16 x value)
+constexpr float kActScale = 16.0f;
+struct W2H { H3 t[2]; };
+__device__ __forceinline__ W2H ldw2h(const float* __restrict__ Wx, int i0, int i1, int lane) {
+    W2H w;
+    w.t[0] = h3_load(Wx + (size_t)i0 * kTileX3, lane);
+    w.t[1] = h3_load(Wx + (size_t)i1 * kTileX3, lane);
+    return w;
 }
-template <bool X> __device__ __forceinline__ typename TokOp<X>::A mk(const f32x16& v) {
-    if constexpr (X) return x3_split(v); else return v;
+__device__ __forceinline__ f32x16 lin2_T(const W2H& w, const X2 (&x)[2], f32x16 init) { return h3_mma_wa(w.t[1], x[1], h3_mma_wa(w.t[0], x[0], init)); }
+__device__ __forceinline__ f32x16 lin2_C(const W2H& w, const X2 (&x)[2]) { return h3_mma_aw(x[1], w.t[1], h3_mma_aw(x[0], w.t[0], zero16())); }
+
+template <int XA> struct TokOp;
+template <> struct TokOp<0> { typedef W2 W; typedef f32x16 A; };
+template <> struct TokOp<1> { typedef W2X W; typedef X3 A; };
+template <> struct TokOp<2> { typedef W2H W; typedef X2 A; };
+template <int XA> __device__ __forceinline__ typename TokOp<XA>::W ldw(const float* __restrict__ Wp, int i0, int i1, int lane) {
+    if constexpr (XA == 2) return ldw2h(Wp, i0, i1, lane); else if constexpr (XA == 1) return ldw2x(Wp, i0, i1, lane); else return ldw2(Wp, i0, i1, lane);
+}
+// operand form of an accumulator tile holding `pre` x its value (pre = 1, or 1 / lin_s when it is a 4-product linear's raw output)
+template <int XA> __device__ __forceinline__ typename TokOp<XA>::A mk(const f32x16& v, float pre = 1.0f) {
+    if constexpr (XA == 2) return x2_split(v * (kActScale * pre)); else if constexpr (XA == 1) return x3_split(v); else return v;
 }
 
 // MODE 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
@@ -444,7 +459,7 @@ enum { VO_SA3B = 0, VO_N1W = 64, VO_N1B = 128, VO_PROJB = 192, VO_N2W = 256, VO_
 constexpr int kParkF4 = 8 * 256;       // f32x4 slots of the residual-stream parking area (split-precision forms only)
 
 // cooperative (256 threads); the caller puts a barrier behind it
-template <int MODE>
+template <int MODE, int XA>
 __device__ __forceinline__ void mdr_stage_vectors(const MdrArgs& a, float* VT) {
     for (int e = threadIdx.x; e < VO_TOTAL / 4; e += 256) {
         const int off = 4 * e;
@@ -456,9 +471,18 @@ __device__ __forceinline__ void mdr_stage_vectors(const MdrArgs& a, float* VT) {
             const float* tab[10] = {a.cur.n1w, a.cur.n1b, a.cur.proj_b, a.cur.n2w, a.cur.n2b, a.cur.fc2_b, a.cur.a2, a.cur.b2, a.cur.sa0_b, a.cur.sa1_b};
             src = tab[(off - VO_N1W) >> 6] + (off & 63);
         } else if (MODE < 2 && off >= VO_FC1B && off < VO_TOKW3) src = a.cur.fc1_b + (off - VO_FC1B);
-        if (src) reinterpret_cast<f32x4*>(VT)[e] = *reinterpret_cast<const f32x4*>(src);
+        if (src) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src);
+            // 4-product linears return lin_s x their value: the biases that start or join their accumulators carry the factor too
+            if (XA == 2 && (off < VO_N1W || (off >= VO_PROJB && off < VO_N2W) || (off >= VO_FC2B && off < VO_A2) || (off >= VO_SA0B && off < VO_TOKW3)))
+                v = v * a.lin_s;
+            reinterpret_cast<f32x4*>(VT)[e] = v;
+        }
     }
 }
+
+// y * k + x as packed FMAs (y: a 4-product linear's raw output, k = 1 / lin_s: a power of two, so this is exactly x + value)
+__device__ __forceinline__ f32x16 fma16(const f32x16& y, float k, const f32x16& x) { return __builtin_elementwise_fma(y, f32x16(k), x); }
 
 // one wave, one 32-token tile `id` = sample * 14 + tile of the sample
 template <int MODE, int XA>
@@ -501,16 +525,18 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
 #else
 #define MDR_STAMP(i)
 #endif
+    constexpr bool H = XA == 2;                 // 4-product linears: their raw outputs carry the factor a.lin_s
+    const float inv = H ? a.lin_inv : 1.0f;
     const int b = id / kVT, t = id % kVT;
     const size_t tile = ((size_t)b * kVT + t) * 2;          // index of this wave's first block in vf/q/k/v
     const int token = 32 * t + (lane & 31);
     const LayerW& w = a.cur;
     f32x16 vf[2];
-    typename TokOp<X>::W A, B;
-    typedef typename TokOp<X>::A Act;
+    typename TokOp<XA>::W A, B;
+    typedef typename TokOp<XA>::A Act;
     if (MODE == 0) {
-        A = ldw<X>(w.wq, 0, 1, lane);
-        B = ldw<X>(w.wq, 2, 3, lane);
+        A = ldw<XA>(w.wq, 0, 1, lane);
+        B = ldw<XA>(w.wq, 2, 3, lane);
         // verts tokens = Linear(6->64)([v431, pose3d[vj]/1000]) + pos_v   (MDR.py:126-137); the v431/bias/pos part is folded
         const int tk = token < kV ? token : kV - 1;
         float x0, x1, x2;
@@ -547,22 +573,22 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
             att[1] = self_attention_head(a.q_in + (tile + 1) * kTile, a.k_in + ((size_t)b * kVT * 2 + 1) * kTile,
                                          a.v_in + ((size_t)b * kVT * 2 + 1) * kTile, lane);
         }
-        A = ldw<X>(a.prev.sa3, 0, 1, lane);
-        B = ldw<X>(a.prev.sa3, 2, 3, lane);
+        A = ldw<XA>(a.prev.sa3, 0, 1, lane);
+        B = ldw<XA>(a.prev.sa3, 2, 3, lane);
         vf[0] = load_block(a.vf_in + (tile + 0) * kTile, lane);
         vf[1] = load_block(a.vf_in + (tile + 1) * kTile, lane);
         MDR_PIN();
         MDR_STAMP(0)
         // linears[-1] + residual (vanilla_transformer_encoder.py:94, MDR.py:143)
-        const Act attx[2] = {mk<X>(att[0]), mk<X>(att[1])};
+        const Act attx[2] = {mk<XA>(att[0]), mk<XA>(att[1])};
         const f32x16 y0 = lin2_T(A, attx, chanvec_lds(VT, VO_SA3B, h));
-        if (MODE == 1) A = ldw<X>(w.wq, 0, 1, lane); else A = ldw<X>(a.head_w, 0, 1, lane);
+        if (MODE == 1) A = ldw<XA>(w.wq, 0, 1, lane); else A = ldw<XA>(a.head_w, 0, 1, lane);
         MDR_PIN();
         const f32x16 y1 = lin2_T(B, attx, chanvec_lds(VT, VO_SA3B + 32, h));
-        if (MODE == 1) B = ldw<X>(w.wq, 2, 3, lane);
+        if (MODE == 1) B = ldw<XA>(w.wq, 2, 3, lane);
         MDR_PIN();
-        vf[0] += y0;
-        vf[1] += y1;
+        if constexpr (H) { vf[0] = fma16(y0, inv, vf[0]); vf[1] = fma16(y1, inv, vf[1]); }
+        else { vf[0] += y0; vf[1] += y1; }
     }
     if (MODE == 2) {
         if (token < kV) {
@@ -576,8 +602,9 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
                     *reinterpret_cast<f32x4*>(a.lbf + ((size_t)b * kV + token) * kE + 32 * nb + 8 * g + 4 * h) = v4;
                 }
         }
-        const Act vfx[2] = {mk<X>(vf[0]), mk<X>(vf[1])};
-        const f32x16 acc = lin2_T(A, vfx, chanvec_lds(VT, VO_HEADB, h));
+        const Act vfx[2] = {mk<XA>(vf[0]), mk<XA>(vf[1])};
+        f32x16 acc = lin2_T(A, vfx, chanvec_lds(VT, VO_HEADB, h));
+        if constexpr (H) acc = acc * inv;
         if (token < kV) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -597,30 +624,30 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         {
             f32x16 fzf[2];
             layernorm64_L(vf, VT + VO_N1W, VT + VO_N1B, h, fzf);
-            fz[0] = mk<X>(fzf[0]);
-            fz[1] = mk<X>(fzf[1]);
+            fz[0] = mk<XA>(fzf[0]);
+            fz[1] = mk<XA>(fzf[1]);
         }
         const float* jb = a.jkv + (((size_t)b * 3 + a.layer) * 4) * kTile;       // [k/v][head] tiles
         q[0] = lin2_T(A, fz, zero16());
-        A = ldw<X>(w.proj, 0, 1, lane);
+        A = ldw<XA>(w.proj, 0, 1, lane);
         MDR_PIN();
         q[1] = lin2_T(B, fz, zero16());
-        B = ldw<X>(w.proj, 2, 3, lane);
+        B = ldw<XA>(w.proj, 2, 3, lane);
         MDR_PIN();
 #pragma unroll
         for (int hd = 0; hd < 2; ++hd) {
-            if constexpr (XA == 2) o[hd] = cross_attention_head_x2(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], a.J, lane);
+            if constexpr (XA == 2) o[hd] = cross_attention_head_x2(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], 16.0f * inv, a.J, lane);
             else o[hd] = cross_attention_head(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], a.J, lane);
         }
-        const Act ox[2] = {mk<X>(o[0]), mk<X>(o[1])};
+        const Act ox[2] = {mk<XA>(o[0]), mk<XA>(o[1])};
         const f32x16 y0 = lin2_T(A, ox, chanvec_lds(VT, VO_PROJB, h));
-        A = ldw<X>(w.fc1, 0, 1, lane);                                            // MLP chunk 0: fc1 rows 0..31
+        A = ldw<XA>(w.fc1, 0, 1, lane);                                            // MLP chunk 0: fc1 rows 0..31
         MDR_PIN();
         const f32x16 y1 = lin2_T(B, ox, chanvec_lds(VT, VO_PROJB + 32, h));
-        B = ldw<X>(w.fc2, 0, 8, lane);                                            //              fc2 columns 0..31, both row blocks
+        B = ldw<XA>(w.fc2, 0, 8, lane);                                            //              fc2 columns 0..31, both row blocks
         MDR_PIN();
-        vf[0] += y0;
-        vf[1] += y1;
+        if constexpr (H) { vf[0] = fma16(y0, inv, vf[0]); vf[1] = fma16(y1, inv, vf[1]); }
+        else { vf[0] += y0; vf[1] += y1; }
     }
     MDR_STAMP(2)
     {
@@ -629,8 +656,8 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         {
             f32x16 y2f[2];
             layernorm64_L(vf, VT + VO_N2W, VT + VO_N2B, h, y2f);
-            y2[0] = mk<X>(y2f[0]);
-            y2[1] = mk<X>(y2f[1]);
+            y2[0] = mk<XA>(y2f[0]);
+            y2[1] = mk<XA>(y2f[1]);
         }
         if constexpr (X) {      // the residual stream waits in LDS while the MLP needs the registers
             park_vf(vf);
@@ -644,26 +671,34 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
             f32x16 hdn;
             if constexpr (X) {      // bias after the products: its scalar loads fly during the MFMAs instead of in front of them
                 hdn = lin2_T(A, y2, zero16());
-                if (c < 7) A = ldw<X>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<X>(w.sa0, 0, 1, lane);
+                if (c < 7) A = ldw<XA>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<XA>(w.sa0, 0, 1, lane);
                 MDR_PIN();
                 hdn += chanvec_lds(VT, VO_FC1B + 32 * c, h);
             } else {
                 hdn = lin2_T(A, y2, chanvec_lds(VT, VO_FC1B + 32 * c, h));
-                if (c < 7) A = ldw<X>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<X>(w.sa0, 0, 1, lane);
+                if (c < 7) A = ldw<XA>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<XA>(w.sa0, 0, 1, lane);
                 MDR_PIN();
             }
-            gelu_tile(hdn);
-            if constexpr (X) {
+            if constexpr (H) gelu_tile_scaled(hdn, inv); else gelu_tile(hdn);
+            if constexpr (H) {
+                const X2 hx = mk<XA>(hdn, inv);
+                acc2[0][0] = h3_mma_wa(B.t[0], hx, acc2[0][0]);
+                acc2[1][0] = h3_mma_wa(B.t[1], hx, acc2[1][0]);
+            } else if constexpr (X) {
                 const X3 hx = x3_split(hdn);
                 acc2[0][0] = x3_mma(B.t[0], hx, acc2[0][0]);
                 acc2[1][0] = x3_mma(B.t[1], hx, acc2[1][0]);
             } else {
                 mma2_T(B.t[0], hdn, acc2[0][c & 1], B.t[1], hdn, acc2[1][c & 1]);   // even / odd chunks: 2 chains of 128 products each
             }
-            if (c < 7) B = ldw<X>(w.fc2, c + 1, 8 + c + 1, lane); else B = ldw<X>(w.sa0, 2, 3, lane);
+            if (c < 7) B = ldw<XA>(w.fc2, c + 1, 8 + c + 1, lane); else B = ldw<XA>(w.sa0, 2, 3, lane);
             MDR_PIN();
         }
-        if constexpr (X) {
+        if constexpr (H) {
+            unpark_vf(vf);
+            vf[0] = fma16(acc2[0][0], inv, vf[0]);
+            vf[1] = fma16(acc2[1][0], inv, vf[1]);
+        } else if constexpr (X) {
             unpark_vf(vf);
             vf[0] += acc2[0][0];
             vf[1] += acc2[1][0];
@@ -678,29 +713,29 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
     store_block(a.vf_out + (tile + 1) * kTile, lane, vf[1]);
     // ---- in-projections of the self-attention (vanilla_transformer_encoder.py:87-89) in the consumer's operand order ----
     {
-        const Act vfx[2] = {mk<X>(vf[0]), mk<X>(vf[1])};
+        const Act vfx[2] = {mk<XA>(vf[0]), mk<XA>(vf[1])};
         f32x16 y0 = lin2_T(A, vfx, chanvec_lds(VT, VO_SA0B, h));
-        A = ldw<X>(w.sa1, 0, 1, lane);
+        A = ldw<XA>(w.sa1, 0, 1, lane);
         MDR_PIN();
         f32x16 y1 = lin2_T(B, vfx, chanvec_lds(VT, VO_SA0B + 32, h));
-        B = ldw<X>(w.sa1, 2, 3, lane);
+        B = ldw<XA>(w.sa1, 2, 3, lane);
         MDR_PIN();
         if constexpr (X) {      // the consumer's softmax works in the exp2 domain: fold log2(e) / sqrt(d_k) into Q once, here
-            constexpr float qs = kLog2e * 0.17677669529663688110f * (XA == 2 ? kX2QK : 1.0f);
+            const float qs = kLog2e * 0.17677669529663688110f * (XA == 2 ? kX2QK : 1.0f) * inv;
             y0 = y0 * qs;
             y1 = y1 * qs;
         }
         st_op<XA>(a.q_out + (tile + 0) * TQ, lane, y0);
         st_op<XA>(a.q_out + (tile + 1) * TQ, lane, y1);
         y0 = lin2_T(A, vfx, chanvec_lds(VT, VO_SA1B, h));
-        A = ldw<X>(w.sa2, 0, 1, lane);
+        A = ldw<XA>(w.sa2, 0, 1, lane);
         MDR_PIN();
         y1 = lin2_T(B, vfx, chanvec_lds(VT, VO_SA1B + 32, h));
-        B = ldw<X>(w.sa2, 2, 3, lane);
+        B = ldw<XA>(w.sa2, 2, 3, lane);
         const float bv0 = w.sa2_b[lane & 31], bv1 = w.sa2_b[32 + (lane & 31)];
         MDR_PIN();
         if (token >= kV) { y0 = zero16(); y1 = zero16(); }                   // pad keys: finite (they are masked anyway)
-        if constexpr (XA == 2) { y0 = y0 * kX2QK; y1 = y1 * kX2QK; }
+        if constexpr (XA == 2) { y0 = y0 * (kX2QK * inv); y1 = y1 * (kX2QK * inv); }
         st_op<XA>(a.k_out + (tile + 0) * TQ, lane, y0);
         st_op<XA>(a.k_out + (tile + 1) * TQ, lane, y1);
         y0 = lin2_C(A, vfx);                                                  // V in C-layout: channel on the lane
@@ -708,8 +743,8 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool ok = 32 * t + kap(r) + 4 * h < kV;
-            y0[r] = ok ? y0[r] + bv0 : 0.f;
-            y1[r] = ok ? y1[r] + bv1 : 0.f;
+            y0[r] = ok ? (H ? __builtin_fmaf(y0[r], inv, bv0) : y0[r] + bv0) : 0.f;
+            y1[r] = ok ? (H ? __builtin_fmaf(y1[r], inv, bv1) : y1[r] + bv1) : 0.f;
         }
         if constexpr (XA == 2) { y0 = y0 * kX2V; y1 = y1 * kX2V; }
         st_op<XA>(a.v_out + (tile + 0) * TQ, lane, y0);
@@ -736,7 +771,7 @@ template <int MODE, int XA>
 __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) {
     __shared__ f32x4 park[XA != 0 ? kParkF4 : 1];
     __shared__ __attribute__((aligned(16))) float VT[VO_TOTAL];
-    mdr_stage_vectors<MODE>(a, VT);
+    mdr_stage_vectors<MODE, XA>(a, VT);
     __syncthreads();
     mdr_tile<MODE, XA>(a, xcd_remap(blockIdx.x, nwg) * 4 + (threadIdx.x >> 6), VT, park);
 }
@@ -802,7 +837,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) 
         unsigned seen = kVT;
         if (MODE > 0 && live && lane == 0 && !(p.dbg & 1)) seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (staged != stage) {                                  // tickets come in stage order: at most three times per workgroup
-            mdr_stage_vectors<MODE>(a, VT);
+            mdr_stage_vectors<MODE, XA>(a, VT);
             staged = stage;
             __syncthreads();
         }
@@ -1084,6 +1119,8 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     MdrArgs a{};
     a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.xout = pc ? nullptr : x_out; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
     a.head_w = f->mdr_x3 ? f->wxbuf + (size_t)(f->head_w - f->lay[0].wq) / kTile * kTileX3 : f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = f->lbf;
+    a.lin_s = f->mdr_x3 == 2 ? std::ldexp(kActScale, f->mdr_wshift) : 1.0f;      // 4-product linears: 16 x activations, 2^wshift x weights
+    a.lin_inv = 1.0f / a.lin_s;
     const int nwg = (B * kVT + 3) / 4;
 #ifdef GATOR_DIAG
     static const bool want_stamps = getenv("GATOR_MDR_STAMPS") != nullptr;

@@ -123,7 +123,54 @@ __device__ __forceinline__ f32x16 x2_mma(const X2& A, const X2& B, f32x16 acc) {
     return acc;
 }
 
+// ---- "4-product" token-wise linears (round 3, MDR with GATOR_MDR_X3=2): activations on TWO fp16 planes, weights on THREE ---------
+// The weight side dominates the error of a rounded linear because its rounding is the same for every token and sample (emulated in
+// the fp64 oracle: all GAT linears with both operands on two planes cost 3.7e-4 mm, with only the activations rounded 9.5e-5).  So
+// the weights stay EXACT -- fp16 x 3 planes, w 2^k = hi + mid + lo with 11 + 11 + >= 2 bits, one power-of-two scale for the whole
+// weight set chosen at pack time so that max|w| 2^k < 2^14 -- and only the activations are rounded to 22 bits (two planes of
+// 16 x value).  Products: a_hi (w_hi + w_mid + w_lo) + a_lo w_hi -- 4 MFMAs per k-step instead of 6; dropped: a_lo (w_mid + w_lo),
+// 2^-22 of the product.  Emulated in the oracle for every token-wise linear of the MDR layers: vertices move by 1.3e-4 mm max /
+// 2.4e-5 mm rms (the path's own fp32 noise: 6 - 7e-4 / 8 - 9e-5).  Results come out scaled by S = 2^(4 + k); every consumer folds
+// 1 / S into a multiplication it does anyway (power of two: no rounding changes).  Same tile geometry as an X3 tile.
+struct H3 { f16x8 p[3][2]; };       // [plane hi/mid/lo][k-step]: 24 VGPRs
+__device__ __forceinline__ H3 h3_load(const float* __restrict__ tile, int lane) {
+    const f16x8* q = reinterpret_cast<const f16x8*>(tile) + lane;
+    H3 o;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) o.p[pl][s] = q[(pl * 2 + s) * 64];
+    return o;
+}
+// two planes of scale * v (scale: a power of two that also carries whatever factor the producer left in v)
+__device__ __forceinline__ X2 x2_split_scaled(const f32x16& v, float scale) { return x2_split(v * scale); }
+// acc += W . a (rows of the result = the weight's lane index); small terms first
+__device__ __forceinline__ f32x16 h3_mma_wa(const H3& W, const X2& a, f32x16 acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        acc = GATOR_MFMA_F16(W.p[0][s], a.p[1][s], acc);      // w hi  * a lo
+        acc = GATOR_MFMA_F16(W.p[2][s], a.p[0][s], acc);      // w lo  * a hi
+        acc = GATOR_MFMA_F16(W.p[1][s], a.p[0][s], acc);      // w mid * a hi
+        acc = GATOR_MFMA_F16(W.p[0][s], a.p[0][s], acc);      // w hi  * a hi
+    }
+    return acc;
+}
+// acc += a . W (rows of the result = the activation's lane index)
+__device__ __forceinline__ f32x16 h3_mma_aw(const X2& a, const H3& W, f32x16 acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        acc = GATOR_MFMA_F16(a.p[1][s], W.p[0][s], acc);
+        acc = GATOR_MFMA_F16(a.p[0][s], W.p[2][s], acc);
+        acc = GATOR_MFMA_F16(a.p[0][s], W.p[1][s], acc);
+        acc = GATOR_MFMA_F16(a.p[0][s], W.p[0][s], acc);
+    }
+    return acc;
+}
+
 // fused_pack.hip: fp32 packed tiles [g][lane][4] -> X3 tiles, same tile indices
 int fused_repack_x3(const float* src_tiles, float* dst_tiles, int64_t ntiles, void* stream);
+// ... -> H3 tiles (three fp16 planes of 2^shift * w); *shift is chosen from max|w| over all the tiles, *residual is the largest
+// |2^shift w - (hi + mid + lo)| relative to max|2^shift w| (0 unless a weight is more than 2^20 below the largest)
+int fused_repack_h3(const float* src_tiles, float* dst_tiles, int64_t ntiles, int* shift, float* residual, void* stream);
 
 }  // namespace gator
