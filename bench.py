@@ -153,23 +153,30 @@ def launch_ranks(a):
     return rc
 
 
-# MFLOP of a stage that run on TWO fp16 planes per operand (3 partial products per fp32 product: the 431x431 self-attention
-# core, QK^T + PV = 47.6 MFLOP per layer) when GATOR_MDR_X3 is 2 (the default); the rest of the stage is on three bf16 planes
-STAGE_X2_MFLOP = {'mdr_layer': 47.6, 'mdr_attn_head': 47.6, 'mdr_layers': 3 * 47.6}
+# How many 16-bit MFMA partial products each fp32 product of a stage costs (x3_common.h), as (MFLOP, products) parts, for the
+# default configuration (GATOR_MDR_X3=2, GATOR_UPSAMPLE_X3=2); every other split-precision stage runs on six (exact three-plane
+# bf16 split).  MDR stages: the 431x431 self-attention core (47.6 MFLOP per layer) and the J-joint cross-attention (1.9 per layer) on
+# two fp16 planes = 3 products; the token-wise linears with activations on two planes and weights exact on three = 4 products.
+_SA, _CA = 47.6, 1.9
+STAGE_PRODUCTS = {'mdr_layer0': [(_CA, 3), (48.7 - _CA, 4)],
+                  'mdr_layer': [(_SA + _CA, 3), (99.2 - _SA - _CA, 4)],
+                  'mdr_attn_head': [(_SA, 3), (51.4 - _SA, 4)],
+                  'mdr_layers': [(3 * _SA + 3 * _CA, 3), (298.5 - 3 * _SA - 3 * _CA, 4)],
+                  'upsample': [(53.45, 3)]}
 PEAK_X2_TFLOPS = round(PEAK_BF16_TFLOPS / 3, 1)
 
 
 def stage_pipe(stage, impl):
-    """-> (pipe name, peak TFLOP/s of fp32-equivalent work) for a profiled stage.  A stage that mixes the two split forms is
-    priced against the time-weighted ceiling of the arithmetic it executes: total / sum(part_i / peak_i)."""
+    """-> (pipe name, peak TFLOP/s of fp32-equivalent work) for a profiled stage.  A stage that mixes split forms is priced
+    against the time-weighted ceiling of the arithmetic it executes: total / sum(part_i / (2500 / products_i))."""
     sw = STAGE_X3_SWITCH.get(stage)
-    if impl == 'fused' and sw is not None and os.environ.get(sw, '2' if sw == 'GATOR_MDR_X3' else '1') != '0':
-        x2 = STAGE_X2_MFLOP.get(stage, 0.0) if os.environ.get('GATOR_MDR_X3', '2') == '2' else 0.0
-        if x2 > 0:
-            tot = STAGE_MFLOP[stage]
-            peak = tot / (x2 / PEAK_X2_TFLOPS + (tot - x2) / PEAK_X3_TFLOPS)
-            return ('bf16 MFMA, exact 3-plane split (6 partial products) for %.1f MFLOP + fp16 MFMA, 2-plane split (3 partial '
-                    'products) for the %.1f MFLOP attention core' % (tot - x2, x2)), round(peak, 1)
+    mode = os.environ.get(sw, '2' if sw in ('GATOR_MDR_X3', 'GATOR_UPSAMPLE_X3') else '1') if sw else '0'
+    if impl == 'fused' and sw is not None and mode != '0':
+        parts = STAGE_PRODUCTS.get(stage) if mode == '2' else None
+        if parts:
+            tot = sum(m for m, _ in parts)
+            peak = tot / sum(m * k / PEAK_BF16_TFLOPS for m, k in parts)
+            return ('16-bit MFMA, split precision: ' + ' + '.join('%.1f MFLOP on %d partial products' % (m, k) for m, k in parts)), round(peak, 1)
         return 'bf16 MFMA, split precision (3 planes, %d partial products per fp32 product)' % X3_PRODUCTS, PEAK_X3_TFLOPS
     if stage == 'upsample_bf16':
         return 'bf16 MFMA', PEAK_BF16_TFLOPS
