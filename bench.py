@@ -162,7 +162,9 @@ STAGE_PRODUCTS = {'mdr_layer0': [(_CA, 3), (48.7 - _CA, 4)],
                   'mdr_layer': [(_SA + _CA, 3), (99.2 - _SA - _CA, 4)],
                   'mdr_attn_head': [(_SA, 3), (51.4 - _SA, 4)],
                   'mdr_layers': [(3 * _SA + 3 * _CA, 3), (298.5 - 3 * _SA - 3 * _CA, 4)],
-                  'upsample': [(53.45, 3)]}
+                  'upsample': [(53.45, 3)],
+                  # k_gat8 (B < 1024): the 16 token-wise linears per block on 4 products, the J x J operators on the fp32-input MFMA (= 16)
+                  'gat': [(54.4, 4), (56.66 - 54.4, 16)]}
 PEAK_X2_TFLOPS = round(PEAK_BF16_TFLOPS / 3, 1)
 
 
@@ -173,6 +175,8 @@ def stage_pipe(stage, impl):
     mode = os.environ.get(sw, '2' if sw in ('GATOR_MDR_X3', 'GATOR_UPSAMPLE_X3') else '1') if sw else '0'
     if impl == 'fused' and sw is not None and mode != '0':
         parts = STAGE_PRODUCTS.get(stage) if mode == '2' else None
+        if stage == 'gat':      # the four-product form is k_gat8's (GATOR_GAT8_H4, default on); k_gat / k_gat_tiled run six
+            parts = STAGE_PRODUCTS['gat'] if (os.environ.get('GATOR_GAT8', '1') != '0' and os.environ.get('GATOR_GAT8_H4', '1') != '0') else None
         if parts:
             tot = sum(m for m, _ in parts)
             peak = tot / sum(m * k / PEAK_BF16_TFLOPS for m, k in parts)
@@ -477,7 +481,8 @@ def main():
             # MDR layers (bitwise the same results as the persistent launch).
             variants = {}
             for vname, env in (('headline, re-measured with the variants\' protocol (5 blocks, later in the run: clocks drift)', {}),
-                               ('exact_split (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1)', {'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1'}),
+                               ('exact_split (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0)', {'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1', 'GATOR_GAT8_H4': '0'}),
+                               ('six-product encoder (GATOR_GAT8_H4=0)', {'GATOR_GAT8_H4': '0'}),
                                ('three-plane vertex regressor (GATOR_UPSAMPLE_X3=1)', {'GATOR_UPSAMPLE_X3': '1'}),
                                ('fp32_mfma (GATOR_GAT_X3=0 GATOR_MDR_X3=0 GATOR_UPSAMPLE_X3=0)', {'GATOR_GAT_X3': '0', 'GATOR_MDR_X3': '0', 'GATOR_UPSAMPLE_X3': '0'}),
                                ('four MDR launches instead of the persistent one (GATOR_MDR_PERSIST=0)', {'GATOR_MDR_PERSIST': '0'}),

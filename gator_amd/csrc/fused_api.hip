@@ -128,8 +128,11 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
             GATOR_HIP_CHECK(hipMalloc(&f->gxbuf, (size_t)ntiles * kTileX3 * sizeof(float)));
             int rc = fused_repack_x3(f->gblk[0].qkv, f->gxbuf, ntiles, stream);
             if (rc) return rc;
+            f->gxbuf_tiles = ntiles;
             const char* g8 = getenv("GATOR_GAT8");
             f->gat8 = !(g8 && atoi(g8) == 0);
+            const char* g8h = getenv("GATOR_GAT8_H4");
+            f->gat8_h4 = !(g8h && atoi(g8h) == 0);
             if (f->gat8) {
                 rc = gat8_build_stream(f, stream);
                 if (rc) return rc;

@@ -191,6 +191,9 @@ __device__ __forceinline__ f32x2 gelu_f2(f32x2 x) {
     phi[1] = x[1] < 0.f ? e[1] : up[1];
     return x * phi;
 }
+// y * k + x as packed FMAs (y: a 4-product linear's raw output, k = 1 / lin_s: a power of two, so this is exactly x + value)
+__device__ __forceinline__ f32x16 fma16(const f32x16& y, float k, const f32x16& x) { return __builtin_elementwise_fma(y, f32x16(k), x); }
+
 // The same for a tile that holds S x its value (k = 1 / S, a power of two): returns S x GELU(value).  k only rescales the constant
 // of the first multiplication, so every rounding is the one gelu_f2 makes on the unscaled value.
 __device__ __forceinline__ f32x2 gelu_f2_scaled(f32x2 x, float k) {

@@ -31,6 +31,8 @@
 #include "x3_common.h"
 
 #include <algorithm>
+#include <cmath>
+#include <type_traits>
 #include <cstdlib>
 #include <vector>
 
@@ -60,6 +62,7 @@ struct Gat8Args {
     float* feat;
     int tapB;
     float* blk_tap;
+    float lin_inv;                   // H4 form: 1 / (16 x 2^weight shift), the factor every raw product tile carries
     int pf_n, pf_loads;              // L2 warm-up of the next block's weights: workgroups per XCD that share it, 8 KiB touches per helper wave (0: off)
 #ifdef GATOR_DIAG
     unsigned long long* stamps;      // [2 roles][kDepth][23 steps][work, wait]
@@ -115,7 +118,7 @@ __device__ __forceinline__ float rsum128(const f32x16 (&x)[4]) {
 
 // gelu_f2 (fused_common.h) over a whole register tile, the eight pairs advanced together: same operations per element, so the same
 // bits; only the instruction order differs (one pair after the other is a chain of 12 dependent packed operations, 8 times)
-__device__ __forceinline__ void gelu_tile8(f32x16& v) {
+__device__ __forceinline__ void gelu_tile8(f32x16& v) {     // (operates on true-scale values in both forms)
     f32x2 x[8], t[8], r[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -204,6 +207,34 @@ __device__ __forceinline__ void tile_mma_refill(X3& w, const X3& b, f32x16& acc,
     }
 #undef GAT8_MM
 }
+// The four-product form (x3_common.h: weights exact on three fp16 planes, activations on two): w_hi a_lo | w_lo a_hi, w_mid a_hi,
+// w_hi a_hi -- 8 MFMAs per tile; the refill of a plane still follows the last MFMA that reads it.
+template <bool CL>
+__device__ __forceinline__ void tile_mma_refill(H3& w, const X2& b, f32x16& acc, const float* __restrict__ wp, int lane) {
+    const f16x8* q = reinterpret_cast<const f16x8*>(wp) + lane;
+#define GAT8_MM(wpl, bpl, s) acc = CL ? GATOR_MFMA_F16(b.p[bpl][s], w.p[wpl][s], acc) : GATOR_MFMA_F16(w.p[wpl][s], b.p[bpl][s], acc)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        GAT8_MM(0, 1, s);                                  // w hi  * a lo
+        GAT8_MM(2, 0, s);                                  // w lo  * a hi
+        __builtin_amdgcn_sched_barrier(0);
+        w.p[2][s] = q[(2 * 2 + s) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        GAT8_MM(1, 0, s);                                  // w mid * a hi
+        __builtin_amdgcn_sched_barrier(0);
+        w.p[1][s] = q[(1 * 2 + s) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        GAT8_MM(0, 0, s);                                  // w hi  * a hi
+        __builtin_amdgcn_sched_barrier(0);
+        w.p[0][s] = q[(0 * 2 + s) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef GAT8_MM
+}
+// operand / weight tile access of the two forms
+__device__ __forceinline__ void ld_tile(X3& o, const float* p, int lane) { o = x3_load(p, lane); }
+__device__ __forceinline__ void ld_tile(X2& o, const float* p, int lane) { o = x2_load(p, lane); }
+__device__ __forceinline__ void ld_tile(H3& o, const float* p, int lane) { o = h3_load(p, lane); }
 
 // ---- product wave: one unit = the K = 128 contraction of one 32-channel output block (4 weight tiles) --------------------------
 // CL = false: weights as A operand -> T-layout accumulator (token on the lane); CL = true: activations as A -> C-layout.
@@ -211,15 +242,15 @@ __device__ __forceinline__ void tile_mma_refill(X3& w, const X3& b, f32x16& acc,
 // `b` = the unit's first operand tile, already requested: where that tile was complete two barriers ago (Y for k / v / h0 / h1, Y2
 // for the later fc1 units, the hidden blocks for fc2) the caller reads it BEFORE the barrier that opens the step, so the matrix
 // pipe does not idle through an LDS round trip after every barrier.
-template <int S0, bool CL>
-__device__ __forceinline__ void unit4(X3 (&W)[kNT], const float* __restrict__& wp, X3 b, const float* o1, const float* o2, const float* o3,
+template <int S0, bool CL, class WT, class OT>
+__device__ __forceinline__ void unit4(WT (&W)[kNT], const float* __restrict__& wp, OT b, const float* o1, const float* o2, const float* o3,
                                       float* raw, int lane) {
     const float* ops[4] = {o1, o1, o2, o3};
     f32x16 acc = zero16();
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-        X3 bn = b;
-        if (kb < 3) bn = x3_load(ops[kb + 1], lane);
+        OT bn = b;
+        if (kb < 3) ld_tile(bn, ops[kb + 1], lane);
         tile_mma_refill<CL>(W[(S0 + kb) % kNT], b, acc, wp, lane);
         wp += kTileX3;
         b = bn;
@@ -227,16 +258,29 @@ __device__ __forceinline__ void unit4(X3 (&W)[kNT], const float* __restrict__& w
     store_block(raw, lane, acc);
 }
 // one tile: partial hop-2 linear (linears[1], 128 -> 16) over k block `w` of SB; C-layout
-template <int S0>
-__device__ __forceinline__ void unit1(X3 (&W)[kNT], const float* __restrict__& wp, const float* o0, float* raw, int lane) {
+template <int S0, class OT, class WT>
+__device__ __forceinline__ void unit1(WT (&W)[kNT], const float* __restrict__& wp, const float* o0, float* raw, int lane) {
     f32x16 acc = zero16();
-    const X3 b = x3_load(o0, lane);
+    OT b;
+    ld_tile(b, o0, lane);
     tile_mma_refill<true>(W[S0 % kNT], b, acc, wp, lane);
     wp += kTileX3;
     store_block(raw, lane, acc);
 }
 
+// H4: the token-wise products on four partial products (weights H3, operands X2; raw tiles carry 1 / a.lin_inv) instead of six
+template <bool H4>
 __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
+    typedef typename std::conditional<H4, H3, X3>::type WT;
+    typedef typename std::conditional<H4, X2, X3>::type OT;
+    const float inv = H4 ? a.lin_inv : 1.0f;
+    // operand tile of a true-scale register tile; pick-up of a raw product tile with what is added to it
+    auto st_opnd = [&](float* dst, int lane_, const f32x16& v) {
+        if constexpr (H4) x2_store(dst, lane_, x2_split(v * 16.0f)); else x3_store(dst, lane_, x3_split(v));
+    };
+    auto pick = [&](const float* raw, int lane_, const f32x16& add) {
+        if constexpr (H4) return fma16(load_block(raw, lane_), inv, add); else return load_block(raw, lane_) + add;
+    };
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* A = lds + kA;
     float* Bq = lds + kBq;
@@ -291,10 +335,10 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
 
     if (wave < 4) {
         // =========================================== product waves ===========================================================
-        X3 W[kNT];                                                          // the head of the weight stream (held back until here: five tiles
+        WT W[kNT];                                                          // the head of the weight stream (held back until here: five tiles
         const float* __restrict__ wp = a.wstream + (size_t)w * kWaveTiles * kTileX3;     // live across the embedding would spill)
 #pragma unroll
-        for (int s = 0; s < kNT; ++s) { W[s] = x3_load(wp, lane); wp += kTileX3; }
+        for (int s = 0; s < kNT; ++s) { ld_tile(W[s], wp, lane); wp += kTileX3; }
         asm volatile("" ::: "memory");
 #ifdef GATOR_DIAG
         unsigned long long* st_out = (a.stamps && b == 0 && t == 0) ? a.stamps : nullptr;
@@ -308,57 +352,58 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             bi_ = bi;
 #endif
             const float *Y0 = A, *Y1 = A + kTileX3, *Y2 = A + 2 * kTileX3, *Y3 = A + 3 * kTileX3;
-            X3 pre = x3_load(Y0, lane);
+            OT pre;
+            ld_tile(pre, Y0, lane);
             unit4<0, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             // q  (T)
-            pre = x3_load(Y0, lane);
+            ld_tile(pre, Y0, lane);
             GAT8_BAR(1);
             unit4<4, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             // k  (T)
-            pre = x3_load(Y0, lane);
+            ld_tile(pre, Y0, lane);
             GAT8_BAR(2);
             unit4<3, true>(W, wp, pre, Y1, Y2, Y3, R0w, lane);              // v  (C)
-            pre = x3_load(Y0, lane);
+            ld_tile(pre, Y0, lane);
             GAT8_BAR(3);
             unit4<2, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             // h0 = y W[0]  (T: its MGCN term is token-wise)
-            pre = x3_load(Y0, lane);
+            ld_tile(pre, Y0, lane);
             GAT8_BAR(4);
             unit4<1, true>(W, wp, pre, Y1, Y2, Y3, R0w, lane);              // h1 = y W[1]  (C)
             GAT8_BAR(5);
-            pre = x3_load(Bq, lane);
+            ld_tile(pre, Bq, lane);
             unit4<0, false>(W, wp, pre, Bq + kTileX3, Bq + 2 * kTileX3, Bq + 3 * kTileX3, R1w, lane);                   // proj(AT)
             GAT8_BAR(6);
             GAT8_BAR(7);                                                    // helpers: SB = proj + attention bias + MGCN
-            pre = x3_load(Bq + 4 * kTileX3, lane);
+            ld_tile(pre, Bq + 4 * kTileX3, lane);
             unit4<4, true>(W, wp, pre, Bq + 5 * kTileX3, Bq + 6 * kTileX3, Bq + 7 * kTileX3, R0w, lane);                // linears[0](SB)  (C)
-            unit1<3>(W, wp, Bq + (4 + w) * kTileX3, X + w * kTile, lane);                                              // linears[1], k block w
+            unit1<3, OT>(W, wp, Bq + (4 + w) * kTileX3, X + w * kTile, lane);                                              // linears[1], k block w
             GAT8_BAR(8);
             GAT8_BAR(9);                                                    // helpers: hop aggregations -> FB
-            pre = x3_load(Bq + 8 * kTileX3, lane);
+            ld_tile(pre, Bq + 8 * kTileX3, lane);
             unit4<4, false>(W, wp, pre, Bq + 9 * kTileX3, Bq + 10 * kTileX3, Bq + 11 * kTileX3, R1w, lane);             // linearback(FB), k < 128
             GAT8_BAR(10);
             GAT8_BAR(11);                                                   // helpers: residual
             GAT8_BAR(12);                                                   // helpers: Y2 = LN2(x)
-            pre = x3_load(Y0, lane);
+            ld_tile(pre, Y0, lane);
             unit4<3, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             // fc1, hidden block 4w
-            pre = x3_load(Y0, lane);
+            ld_tile(pre, Y0, lane);
             GAT8_BAR(13);
             unit4<2, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 1
-            pre = x3_load(Y0, lane);
+            ld_tile(pre, Y0, lane);
             GAT8_BAR(14);
             unit4<1, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             //      4w + 2
-            pre = x3_load(Y0, lane);
+            ld_tile(pre, Y0, lane);
             GAT8_BAR(15);
             unit4<0, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 3
-            pre = x3_load(Bq, lane);                                        // (hidden blocks 4w' were complete at barrier 14)
+            ld_tile(pre, Bq, lane);                                        // (hidden blocks 4w' were complete at barrier 14)
             GAT8_BAR(16);
             // fc2: unit u contracts over hidden blocks {4w' + u}: tiles 3w' + u of B for u < 3, tile w' of A for u = 3
             unit4<4, false>(W, wp, pre, Bq + 3 * kTileX3, Bq + 6 * kTileX3, Bq + 9 * kTileX3, R0w, lane);
-            pre = x3_load(Bq + 1 * kTileX3, lane);
+            ld_tile(pre, Bq + 1 * kTileX3, lane);
             GAT8_BAR(17);
             unit4<3, false>(W, wp, pre, Bq + 4 * kTileX3, Bq + 7 * kTileX3, Bq + 10 * kTileX3, R1w, lane);
-            pre = x3_load(Bq + 2 * kTileX3, lane);
+            ld_tile(pre, Bq + 2 * kTileX3, lane);
             GAT8_BAR(18);
             unit4<2, false>(W, wp, pre, Bq + 5 * kTileX3, Bq + 8 * kTileX3, Bq + 11 * kTileX3, R0w, lane);
-            pre = x3_load(Y0, lane);                                        // (hidden blocks 4w' + 3, complete at barrier 17)
+            ld_tile(pre, Y0, lane);                                        // (hidden blocks 4w' + 3, complete at barrier 17)
             GAT8_BAR(19);
             unit4<1, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);
             GAT8_BAR(20);
@@ -383,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
     {
         const float* vec = a.blk[0].vecs;
         const f32x16 y = ln_own(X, xw, load_chanvec_T(vec, V_N1W + 32 * w, h), load_chanvec_T(vec, V_N1B + 32 * w, h), lane);
-        x3_store(A + w * kTileX3, lane, x3_split(y));
+        st_opnd(A + w * kTileX3, lane, y);
     }
     GAT8_BAR(0);
 #pragma unroll 1
@@ -399,12 +444,12 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         const f32x16 ba = load_block(a.biasT + (size_t)(2 * w) * kTile, lane), bb = load_block(a.biasT + (size_t)(2 * w + 1) * kTile, lane);
         GAT8_BAR(1);
         // ---- step 2: q
-        const f32x16 q = load_block(R0w, lane) + bq;
+        const f32x16 q = pick(R0w, lane, bq);
         GAT8_BAR(2);
         // ---- step 3: k; scores and softmax of heads 2w, 2w+1 (modules.py:121-133): S^T[key][query], query on the lane
         f32x16 sa = zero16(), sb = zero16();
         {
-            const f32x16 k = load_block(R1w, lane) + bk;
+            const f32x16 k = pick(R1w, lane, bk);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 sa = GATOR_MFMA(k[r], q[r], sa);                                    // head 2w:   channels 0..15 of the block
@@ -452,7 +497,8 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         f32x16 O = zero16(), Ob = zero16();
         const bool lo = tok < 16;
         {
-            const f32x16 v = load_block(R0w, lane);
+            f32x16 v = load_block(R0w, lane);
+            if constexpr (H4) v = v * inv;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const float vv = v[r] + vb;
@@ -462,13 +508,14 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             GAT8_BAR(4);
             const f32x16 mdt = load_block(kb.mdT + (size_t)w * kTile, lane);        // (constants are requested about one step before their use)
             f32x16 h0 = load_block(R1w, lane);
+            if constexpr (H4) h0 = h0 * inv;
 #pragma unroll
             for (int r = 8; r < 16; ++r) {
                 const float vv = v[r] + vb;
                 O = GATOR_MFMA(lo ? vv : 0.f, sa[r], O);
                 Ob = GATOR_MFMA(lo ? 0.f : vv, sb[r], Ob);
             }
-            x3_store(Bq + w * kTileX3, lane, x3_split(O + Ob));                      // AT[w]
+            st_opnd(Bq + w * kTileX3, lane, O + Ob);                                // AT[w]
             O = h0 * mdt;                                                          // diag(A)[t] * M[t][n] * h0[t][n]  (O re-used)
         }
         const f32x16 mct = load_block(kb.mc + (size_t)w * kTile, lane), aoff = load_block(kb.aoffT, lane);
@@ -477,15 +524,17 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         // ---- step 6: h1; MGCN (modules.py:243-255): sum_j (M.h1)[j][n] Aoff[t][j] as one MFMA product + the token-wise term
         f32x16 g_out;
         {
-            const f32x16 h1 = load_block(R0w, lane) * mct;
+            f32x16 h1 = load_block(R0w, lane);
+            if constexpr (H4) h1 = h1 * inv;
+            h1 = h1 * mct;
             g_out = dot16(h1, aoff, bg) + O;
         }
         const f32x16 bp = load_chanvec_T(vec, V_PROJB + 32 * w, h);
         GAT8_BAR(6);
         // ---- step 7: SB = proj(attention) + bias + MGCN
         {
-            const f32x16 acc = load_block(R1w, lane) + bp;
-            x3_store(Bq + (4 + w) * kTileX3, lane, x3_split(acc + g_out));
+            const f32x16 acc = pick(R1w, lane, bp);
+            st_opnd(Bq + (4 + w) * kTileX3, lane, acc + g_out);
         }
         GAT8_BAR(7);
         // constants of the X_Feat steps
@@ -495,11 +544,12 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         GAT8_BAR(8);
         // ---- step 9: X_Feat (modules.py:158-177): hop<=1 aggregation of linears[0], hop==2 aggregation of linears[1]
         {
-            const f32x16 u0 = load_block(R0w, lane) + b0;
+            const f32x16 u0 = pick(R0w, lane, f32x16(b0));
             f32x16 u1 = (load_block(X, lane) + load_block(X + kTile, lane)) + (load_block(X + 2 * kTile, lane) + load_block(X + 3 * kTile, lane));
+            if constexpr (H4) u1 = u1 * inv;
             f32x16 f0 = zero16(), f1a = zero16();
             dot16x2(u0, m1, f0, u1, m2, f1a);
-            x3_store(Bq + (8 + w) * kTileX3, lane, x3_split(f0));                  // FB[w]
+            st_opnd(Bq + (8 + w) * kTileX3, lane, f0);                            // FB[w]
             f1 += f1a;
         }
         const f32x16 bback = load_chanvec_T(vec, V_BACKB + 32 * w, h);
@@ -520,49 +570,47 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         const f32x16 n2w = load_chanvec_T(vec, V_N2W + 32 * w, h), n2b = load_chanvec_T(vec, V_N2B + 32 * w, h);
         GAT8_BAR(10);
         // ---- step 11: residual
-        xw += (load_block(R1w, lane) + tl) + tl2;
+        xw += pick(R1w, lane, tl) + tl2;
         store_block(X + w * kTile, lane, xw);
         GAT8_BAR(11);
         // ---- step 12: Y2 = LN2(x)
-        x3_store(A + w * kTileX3, lane, x3_split(ln_own(X, xw, n2w, n2b, lane)));
+        st_opnd(A + w * kTileX3, lane, ln_own(X, xw, n2w, n2b, lane));
         GAT8_BAR(12);
         // ---- steps 13-17: MLP hidden blocks 4w + j: bias, GELU, split (modules.py:188-196)
         f32x16 fb0 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 0), h), fb1 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 1), h);
         GAT8_BAR(13);
         {
-            f32x16 hd = load_block(R0w, lane) + fb0;
+            f32x16 hd = pick(R0w, lane, fb0);
             gelu_tile8(hd);
-            x3_store(Bq + (3 * w + 0) * kTileX3, lane, x3_split(hd));
+            st_opnd(Bq + (3 * w + 0) * kTileX3, lane, hd);
         }
         fb0 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 2), h);
         GAT8_BAR(14);
         {
-            f32x16 hd = load_block(R1w, lane) + fb1;
+            f32x16 hd = pick(R1w, lane, fb1);
             GAT8_SUB(0);
             gelu_tile8(hd);
             GAT8_SUB(1);
-            const X3 sp = x3_split(hd);
-            GAT8_SUB(2);
-            x3_store(Bq + (3 * w + 1) * kTileX3, lane, sp);
+            st_opnd(Bq + (3 * w + 1) * kTileX3, lane, hd);
             GAT8_SUB(3);
         }
         fb1 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 3), h);
         GAT8_BAR(15);
         {
-            f32x16 hd = load_block(R0w, lane) + fb0;
+            f32x16 hd = pick(R0w, lane, fb0);
             gelu_tile8(hd);
-            x3_store(Bq + (3 * w + 2) * kTileX3, lane, x3_split(hd));
+            st_opnd(Bq + (3 * w + 2) * kTileX3, lane, hd);
         }
         GAT8_BAR(16);
         {
-            f32x16 hd = load_block(R1w, lane) + fb1;
+            f32x16 hd = pick(R1w, lane, fb1);
             gelu_tile8(hd);
-            x3_store(A + w * kTileX3, lane, x3_split(hd));                         // (Y2 is dead: fc1 finished before barrier 16)
+            st_opnd(A + w * kTileX3, lane, hd);                                    // (Y2 is dead: fc1 finished before barrier 16)
         }
         const f32x16 bfc2 = load_chanvec_T(vec, V_FC2B + 32 * w, h);
         GAT8_BAR(17);
         // ---- steps 18-21: the four partial sums of fc2, residual
-        f32x16 c01 = load_block(R0w, lane) + bfc2;
+        f32x16 c01 = pick(R0w, lane, bfc2);
         // L2 warm-up (the helpers idle through the fc2 steps).  Between two launches of this kernel the rest of the forward moves
         // ~1 GB, so the weights start in HBM; all workgroups of an XCD walk them in step, so every tile would be an HBM-latency
         // miss for all of them at once (measured on the skeleton: 120 -> 140 us with cold weights).  Each workgroup pulls its
@@ -579,7 +627,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
                 glds4(reinterpret_cast<const float*>(wsrc + min(first + i * 8192 + lane * 128, lim)), dummy);
         }
         GAT8_BAR(18);
-        c01 += load_block(R1w, lane);
+        c01 = pick(R1w, lane, c01);
         if (warm) {                                  // this helper's share of the next block's tables and vectors, one lane per line
             const int l32 = lane & 31;
             glds4(h == 0 ? nx.mdT + (size_t)w * kTile + l32 * 32 : nx.mc + (size_t)w * kTile + l32 * 32, dummy);
@@ -589,13 +637,14 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         }
         GAT8_BAR(19);
         f32x16 c23 = load_block(R0w, lane);
+        if constexpr (H4) c23 = c23 * inv;
         // LayerNorm weights of what follows: the next block's norm1, or the encoder's final norm
         const bool last = bi + 1 == kDepth;
         const float* nvec = last ? a.norm_w : a.blk[bi + 1 < kDepth ? bi + 1 : bi].vecs + V_N1W;
         const float* nvecb = last ? a.norm_b : a.blk[bi + 1 < kDepth ? bi + 1 : bi].vecs + V_N1B;
         const f32x16 nw = load_chanvec_T(nvec, 32 * w, h), nb = load_chanvec_T(nvecb, 32 * w, h);
         GAT8_BAR(20);
-        c23 += load_block(R1w, lane);
+        c23 = pick(R1w, lane, c23);
         xw += c01 + c23;
         store_block(X + w * kTile, lane, xw);
         if (a.blk_tap && tok < J) {          // debug tap (off in timed runs): this wave's channel block of the block output
@@ -613,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         {
             f32x16 y = ln_own(X, xw, nw, nb, lane);
             if (!last) {
-                x3_store(A + w * kTileX3, lane, x3_split(y));
+                st_opnd(A + w * kTileX3, lane, y);
             } else {
                 gelu_tile8(y);
                 if (tok < J) {
@@ -643,7 +692,8 @@ __global__ void k_gather_tiles(const float* __restrict__ src, const int* __restr
 constexpr size_t kGat8Lds = (size_t)kGat8LdsFloats * sizeof(float);
 
 int gat8_prepare_device() {
-    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     return GATOR_OK;
 }
 
@@ -679,10 +729,22 @@ int gat8_build_stream(FusedState* f, void* stream) {
     GATOR_HIP_CHECK(hipMalloc(&d_idx, idx.size() * sizeof(int)));
     GATOR_HIP_CHECK(hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
     GATOR_HIP_CHECK(hipMalloc(&f->g8stream, (size_t)kStreamFloats * sizeof(float)));
-    k_gather_tiles<<<(unsigned)idx.size(), 128, 0, (hipStream_t)stream>>>(f->gxbuf, d_idx, f->g8stream);
+    const float* image = f->gxbuf;
+    float* h3 = nullptr;
+    if (f->gat8_h4) {      // the four-product form streams three fp16 planes of 2^shift * w instead of the three bf16 planes
+        const int64_t ntiles = (int64_t)(f->gxbuf_tiles);
+        float left = 0.f;
+        GATOR_HIP_CHECK(hipMalloc(&h3, (size_t)ntiles * kTileX3 * sizeof(float)));
+        int rc = fused_repack_h3(f->gblk[0].qkv, h3, ntiles, &f->gat8_wshift, &left, stream);
+        if (rc == GATOR_OK && left > 1e-7f) rc = fail(GATOR_EUNSUPPORTED, "GAT weights span more than fp16 x 3 planes hold exactly: use GATOR_GAT8_H4=0");
+        if (rc) { (void)hipFree(h3); return rc; }
+        image = h3;
+    }
+    k_gather_tiles<<<(unsigned)idx.size(), 128, 0, (hipStream_t)stream>>>(image, d_idx, f->g8stream);
     GATOR_HIP_CHECK(hipGetLastError());
     GATOR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     GATOR_HIP_CHECK(hipFree(d_idx));
+    if (h3) GATOR_HIP_CHECK(hipFree(h3));
     return GATOR_OK;
 }
 
@@ -723,7 +785,9 @@ int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* 
         GATOR_HIP_CHECK(hipMemset(a.stamps, 0, kSt * sizeof(unsigned long long)));
     }
 #endif
-    k_gat8<<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    a.lin_inv = std::ldexp(1.0f, -(4 + f->gat8_wshift));
+    if (f->gat8_h4) k_gat8<true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else k_gat8<false><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     GATOR_HIP_CHECK(hipGetLastError());
 #ifdef GATOR_DIAG
     if (a.stamps) {     // diagnostic build: synchronous read-back; blocks 1..5 averaged (block 0 carries the cold start)

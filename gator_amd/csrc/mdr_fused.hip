@@ -481,9 +481,6 @@ __device__ __forceinline__ void mdr_stage_vectors(const MdrArgs& a, float* VT) {
     }
 }
 
-// y * k + x as packed FMAs (y: a 4-product linear's raw output, k = 1 / lin_s: a power of two, so this is exactly x + value)
-__device__ __forceinline__ f32x16 fma16(const f32x16& y, float k, const f32x16& x) { return __builtin_elementwise_fma(y, f32x16(k), x); }
-
 // one wave, one 32-token tile `id` = sample * 14 + tile of the sample
 template <int MODE, int XA>
 __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const float* VT, f32x4* park) {

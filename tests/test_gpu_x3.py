@@ -13,10 +13,11 @@ from tests.helpers import build_model, oracle_setup
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ('GATOR_GAT_X3', 'GATOR_MDR_X3', 'GATOR_UPSAMPLE_X3')
+SWITCHES = ('GATOR_GAT_X3', 'GATOR_MDR_X3', 'GATOR_UPSAMPLE_X3')      # + GATOR_GAT8_H4: the encoder's linears on 4 products (default) or the exact 6
 
 
-def _run(monkeypatch, name, x, off, mdr_mode='1', up_mode='1'):
+def _run(monkeypatch, name, x, off, mdr_mode='1', up_mode='1', gat_h4='0'):
+    monkeypatch.setenv('GATOR_GAT8_H4', gat_h4)
     for k in SWITCHES:
         on = mdr_mode if k == 'GATOR_MDR_X3' else (up_mode if k == 'GATOR_UPSAMPLE_X3' else '1')
         monkeypatch.setenv(k, '0' if k in off else on)
@@ -34,11 +35,13 @@ def test_x3_and_fp32_mfma_paths_both_meet_the_bar(monkeypatch, name, B):
     ref, rp = go.gator_forward(sd, c, x, torch.float64)
     ref, rp = ref.numpy(), rp.numpy()
     outs = {}
-    # 'default' = exact bf16 x 3 split for the token-wise linears + the 431x431 self-attention and the vertex regressor on two
-    # fp16 planes (GATOR_MDR_X3=2, GATOR_UPSAMPLE_X3=2); 'upsample x3' = the default with the exact three-plane regressor
+    # 'default' = token-wise linears of the encoder and the MDR layers on four partial products (weights exact, activations on two
+    # fp16 planes), both attentions and the vertex regressor on two fp16 planes (GATOR_GAT8_H4=1, GATOR_MDR_X3=2, GATOR_UPSAMPLE_X3=2);
+    # 'upsample x3' = the default with the exact three-plane regressor; 'all x3' = no rounded operand anywhere
     for label, off in (('default', ()), ('all x3', ()), ('upsample x3', ()), ('gat fp32', ('GATOR_GAT_X3',)), ('mdr fp32', ('GATOR_MDR_X3',)),
                        ('upsample fp32', ('GATOR_UPSAMPLE_X3',)), ('all fp32', SWITCHES)):
-        v, p = _run(monkeypatch, name, x, off, '2' if label in ('default', 'upsample x3') else '1', '2' if label == 'default' else '1')
+        dflt = label in ('default', 'upsample x3')
+        v, p = _run(monkeypatch, name, x, off, '2' if dflt else '1', '2' if label == 'default' else '1', '1' if dflt else '0')
         e = np.abs(v - ref).max() * 1e3
         print('\n[%s B=%d] %-14s max |verts - fp64| = %.2e mm, pose3d %.2e mm' % (name, B, label, e, np.abs(p - rp).max()))
         assert e <= 1e-3, label
