@@ -497,7 +497,8 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
         else if (B >= f->gat_tiled_min_batch) {
             const int round = f->n_cu * gat_tiled_samples_per_wg(c->J);
             n_tiled = (B / round) * round;
-            if (B - n_tiled > 3 * f->n_cu) n_tiled = B;
+            // the remainder: k_gat8 takes ~0.18 ms per n_cu samples (four partial products), a partial round of the tiled kernel ~0.85 ms
+            if (B - n_tiled > 4 * f->n_cu) n_tiled = B;
         }
     }
     const bool tiled = n_tiled > 0;

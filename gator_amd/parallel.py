@@ -66,7 +66,7 @@ class ShardedForward:
         self.encoder = encoder
         self._pinned = None
 
-    TILED_MIN_BATCH = 1024                      # the library's own threshold (fused_state.h: gat_tiled_min_batch)
+    TILED_MIN_BATCH = 1025                      # the library's own rule (fused_api.hip): up to 4 x 256 samples the one-sample-per-workgroup encoder is faster
 
     def _pin_encoder(self, calls_batch):
         """world > 1: one encoder kernel for every call of this run (see the module docstring)."""

@@ -119,8 +119,9 @@ def test_config4_single_process_b8192(monkeypatch):
     idx = [0, 1023, 1024, 4095, 7167, 7168, 8191]
     ref, rp = go.gator_forward(sd, c, x[idx].cpu(), torch.float64)
     assert np.abs(v[idx].cpu().numpy().astype(np.float64) - ref.numpy()).max() * 1e3 <= 1e-3
-    vs, ps = m(x[3072:4096].contiguous())                        # rank 3's shard of an 8-way split
-    assert torch.equal(vs, v[3072:4096]) and torch.equal(ps, p[3072:4096])     # both run entirely on the tiled encoder
+    vs, ps = m(x[3072:4096].contiguous())                        # rank 3's shard of an 8-way split, unpinned: up to 4 x 256 samples the per-call
+    # policy takes the one-sample-per-workgroup encoder, the big batch's rows sit on the tiled one -> fp32 noise, not bits
+    assert float((vs - v[3072:4096]).abs().max()) * 1e3 <= 1.5e-3 and float((ps - p[3072:4096]).abs().max()) <= 1e-3
     del v2
     # What ShardedForward does with 8 ranks x 1 024 samples: ONE pinned encoder for every call (gator_set_encoder), so that ALL eight
     # shards - whatever their position - reproduce the rows of the single-process batch bit for bit, also for shard sizes at which
@@ -138,6 +139,9 @@ def test_config4_single_process_b8192(monkeypatch):
     m.set_encoder('auto')
     run = ShardedForward(m, 8, 3, object())                      # (no collective is issued: only the pin is exercised)
     run._pin_encoder(1024)
+    assert run._pinned == 'sample'
+    run = ShardedForward(m, 8, 3, object())
+    run._pin_encoder(1025)
     assert run._pinned == 'tiled'
     vs, ps = m(x[3072:4096].contiguous())
     assert torch.equal(vs, v[3072:4096])

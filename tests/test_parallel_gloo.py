@@ -121,7 +121,7 @@ def test_encoder_pin_follows_the_local_batch():
     """world > 1: the pinned kernel is the one the library would use for the calls this run makes (local batch, or the micro-batch),
     decided once; an explicit choice wins."""
     from gator_amd.parallel import ShardedForward
-    for kw, B, want in (({}, 1024, 'tiled'), ({}, 1023, 'sample'), ({'micro_batch': 256}, 2048, 'sample'), ({'encoder': 'sample'}, 4096, 'sample')):
+    for kw, B, want in (({}, 1025, 'tiled'), ({}, 1024, 'sample'), ({'micro_batch': 256}, 2048, 'sample'), ({'encoder': 'sample'}, 4096, 'sample')):
         m = _FakeModel()
         run = ShardedForward(m, 8, 3, object(), **kw)
         run._pin_encoder(min(B, run.micro or B))
