@@ -1137,6 +1137,9 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     const double R = (double)nwg / f->n_cu;
     const bool auto_persist = R >= 3.0 && (std::ceil(R) - R) / R >= 0.04;
     bool persist = f->mdr_persist < 0 ? auto_persist : f->mdr_persist > 0;
+    // the queues are per XCD and a workgroup serves the queue of the XCD it runs on: that drains every queue only when the device is
+    // the whole 8-XCD part (a partitioned device shows fewer CUs; its workgroups would all sit on one XCD)
+    if (f->n_cu != 256) persist = false;
 #ifdef GATOR_DIAG
     if (want_stamps) persist = false;       // the stamps describe the per-stage launches
 #endif
