@@ -128,7 +128,6 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
             GATOR_HIP_CHECK(hipMalloc(&f->gxbuf, (size_t)ntiles * kTileX3 * sizeof(float)));
             int rc = fused_repack_x3(f->gblk[0].qkv, f->gxbuf, ntiles, stream);
             if (rc) return rc;
-            f->gxbuf_tiles = ntiles;
             const char* g8 = getenv("GATOR_GAT8");
             f->gat8 = !(g8 && atoi(g8) == 0);
             const char* g8h = getenv("GATOR_GAT8_H4");

@@ -60,7 +60,6 @@ struct FusedState : FusedWs {
     bool gat8 = true;                   // one-sample-per-workgroup encoder: the two-role kernel k_gat8 (GATOR_GAT8=0: k_gat)
     bool gat8_h4 = true;                // ... with its token-wise products on four partial products (x3_common.h; GATOR_GAT8_H4=0: the exact six)
     int gat8_wshift = 0;                // its weight stream holds three fp16 planes of 2^gat8_wshift * w
-    int64_t gxbuf_tiles = 0;            // tiles in gxbuf
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
     int mdr_persist = -1;               // the four MDR stages as ONE persistent launch (k_mdr_persist): -1 by batch size (launch_mdr), GATOR_MDR_PERSIST=0 never, =1 always
     int mdr_wshift = 0;                 // GATOR_MDR_X3=2: wxbuf holds three fp16 planes of 2^mdr_wshift * w

@@ -680,11 +680,12 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
     }
 }
 
-// one workgroup per destination tile: dst tile i <- src tile idx[i]  (6 KiB = 384 x 16 B)
+// one workgroup per destination tile: dst tile i <- src tile idx[i]  (TILE floats: 6 KiB X3 tiles or 4 KiB fp32 tiles)
+template <int TILE>
 __global__ void k_gather_tiles(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst) {
-    const f32x4* s = reinterpret_cast<const f32x4*>(src + (size_t)idx[blockIdx.x] * kTileX3);
-    f32x4* d = reinterpret_cast<f32x4*>(dst + (size_t)blockIdx.x * kTileX3);
-    for (int e = threadIdx.x; e < kTileX3 / 4; e += blockDim.x) d[e] = s[e];
+    const f32x4* s = reinterpret_cast<const f32x4*>(src + (size_t)idx[blockIdx.x] * TILE);
+    f32x4* d = reinterpret_cast<f32x4*>(dst + (size_t)blockIdx.x * TILE);
+    for (int e = threadIdx.x; e < TILE / 4; e += blockDim.x) d[e] = s[e];
 }
 
 }  // namespace
@@ -729,18 +730,17 @@ int gat8_build_stream(FusedState* f, void* stream) {
     GATOR_HIP_CHECK(hipMalloc(&d_idx, idx.size() * sizeof(int)));
     GATOR_HIP_CHECK(hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
     GATOR_HIP_CHECK(hipMalloc(&f->g8stream, (size_t)kStreamFloats * sizeof(float)));
-    const float* image = f->gxbuf;
     float* h3 = nullptr;
-    if (f->gat8_h4) {      // the four-product form streams three fp16 planes of 2^shift * w instead of the three bf16 planes
-        const int64_t ntiles = (int64_t)(f->gxbuf_tiles);
-        float left = 0.f;
-        GATOR_HIP_CHECK(hipMalloc(&h3, (size_t)ntiles * kTileX3 * sizeof(float)));
-        int rc = fused_repack_h3(f->gblk[0].qkv, h3, ntiles, &f->gat8_wshift, &left, stream);
+    if (f->gat8_h4) {      // the four-product form streams three fp16 planes of 2^shift * w: the fp32 tiles are put in stream order
+        float left = 0.f;  // first, so that the shift comes from exactly the weights the kernel multiplies (not the tables in between)
+        GATOR_HIP_CHECK(hipMalloc(&h3, idx.size() * kTile * sizeof(float)));
+        k_gather_tiles<kTile><<<(unsigned)idx.size(), 128, 0, (hipStream_t)stream>>>(f->gblk[0].qkv, d_idx, h3);
+        int rc = fused_repack_h3(h3, f->g8stream, (int64_t)idx.size(), &f->gat8_wshift, &left, stream);
         if (rc == GATOR_OK && left > 1e-7f) rc = fail(GATOR_EUNSUPPORTED, "GAT weights span more than fp16 x 3 planes hold exactly: use GATOR_GAT8_H4=0");
-        if (rc) { (void)hipFree(h3); return rc; }
-        image = h3;
+        if (rc) { (void)hipFree(h3); (void)hipFree(d_idx); return rc; }
+    } else {
+        k_gather_tiles<kTileX3><<<(unsigned)idx.size(), 128, 0, (hipStream_t)stream>>>(f->gxbuf, d_idx, f->g8stream);
     }
-    k_gather_tiles<<<(unsigned)idx.size(), 128, 0, (hipStream_t)stream>>>(image, d_idx, f->g8stream);
     GATOR_HIP_CHECK(hipGetLastError());
     GATOR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     GATOR_HIP_CHECK(hipFree(d_idx));
