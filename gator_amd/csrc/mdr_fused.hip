@@ -791,7 +791,6 @@ constexpr int kCtrError = 8, kCtrDone = 16;       // ctr: [0..7] tickets per XCD
 struct MdrPersistArgs {
     MdrArgs st[4];
     unsigned* ctr;
-    int dbg;          // experiments (GATOR_MDR_PERSIST_DBG): 1 no dependency wait, 2 no L1 invalidate
 };
 template <int XA>
 __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) {
@@ -832,14 +831,14 @@ __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) 
         // tile) hides behind the staging below instead of standing in front of the tile
         const unsigned* d = p.ctr + kCtrDone + (size_t)(MODE > 0 ? stage - 1 : 0) * B + smp;
         unsigned seen = kVT;
-        if (MODE > 0 && live && lane == 0 && !(p.dbg & 1)) seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE > 0 && live && lane == 0) seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (staged != stage) {                                  // tickets come in stage order: at most three times per workgroup
             mdr_stage_vectors<MODE, XA>(a, VT);
             staged = stage;
             __syncthreads();
         }
         if (!live) return;
-        if (MODE > 0 && !(p.dbg & 1)) {
+        if (MODE > 0) {
             if (lane == 0) {
                 int budget = 1 << 24;                           // ~6 s of polling
                 while (seen < (unsigned)kVT && --budget > 0) {
@@ -1177,9 +1176,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         pa.ctr = f->mdr_ctr;
         if (!ctr_clean) GATOR_HIP_CHECK(hipMemsetAsync(f->mdr_ctr, 0, (kCtrDone + (size_t)3 * B) * sizeof(unsigned), st));
         StageTimer tm(c, "mdr_layers", stream);
-        static const int dbg = getenv("GATOR_MDR_PERSIST_DBG") ? atoi(getenv("GATOR_MDR_PERSIST_DBG")) : 0;
-        pa.dbg = dbg & 3;
-        const int grid = (dbg & 4) ? f->n_cu : 2 * f->n_cu;       // two workgroups per CU is what the registers allow; any grid drains the queues
+        const int grid = 2 * f->n_cu;       // two workgroups per CU is what the registers allow; any grid drains the queues
         if (f->mdr_x3 == 2) k_mdr_persist<2><<<grid, 256, 0, st>>>(pa);
         else if (f->mdr_x3 == 1) k_mdr_persist<1><<<grid, 256, 0, st>>>(pa);
         else k_mdr_persist<0><<<grid, 256, 0, st>>>(pa);
