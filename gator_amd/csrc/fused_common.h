@@ -278,6 +278,19 @@ __device__ __forceinline__ f32x16 chanvec_select(const SVec& s, int h) {
     return v;
 }
 
+// per-channel vector from the workgroup's LDS table (k_mdr_layer): 4 ds_read_b128 with two distinct addresses each, against 32
+// scalar loads + 16 v_mov + 16 v_cndmask for the scalar-cache form -- 30 such vectors per tile were 9 % of the kernel's VALU work
+__device__ __forceinline__ f32x16 chanvec_lds(const float* V, int off, int h) {
+    f32x16 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(V + off + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * g + j] = t[j];
+    }
+    return v;
+}
+
 // XCD-aware bijective remap of a 1-D grid: blocks that share an XCD (equal blockIdx % 8) get CONTIGUOUS logical ids,
 // so the workgroups of one sample hit one L2.  Speed only -- never correctness (cdna_hip_programming.md T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

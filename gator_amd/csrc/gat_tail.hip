@@ -64,6 +64,11 @@ __device__ __forceinline__ float row_sum32x2(const f32x16& a, const f32x16& b) {
 __global__ __launch_bounds__(256) void k_gat_joint(const JointTailArgs a) {
     __shared__ float XO[64];
     __shared__ __attribute__((aligned(16))) float JF[2 * kTile];
+    // every per-channel vector the joint-token part needs, fetched by one vector load per thread at the start (in flight during the
+    // lifter sums; published by the barrier that follows them).  Through the scalar cache, as before, each of the 18 vectors was an
+    // exposed round trip in the middle of the chain: 6.6 of the launch's 20 us.
+    enum { VJ_JFB = 0, VJ_JF5 = 64, VJ_N1W = 384, VJ_N1B = 576, VJ_TOTAL = 768 };      // n1w / n1b: [3 layers][64]
+    __shared__ __attribute__((aligned(16))) float VJ[VJ_TOTAL];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J, tok = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     if (a.mdr_ctr) {
@@ -80,6 +85,12 @@ __global__ __launch_bounds__(256) void k_gat_joint(const JointTailArgs a) {
         return load_wtile(kv ? a.j_wv_p[li] : a.j_wk_p[li], nb * 2 + i, lane);
     };
     if (a.jkv) {
+        if (t < VJ_TOTAL / 4) {
+            const int off = 4 * t;
+            const float* src = off < VJ_JF5 ? a.jf_b + off : off < VJ_N1W ? a.jf5 + (off - VJ_JF5)
+                               : off < VJ_N1B ? a.j_n1w[(off - VJ_N1W) >> 6] + (off & 63) : a.j_n1b[(off - VJ_N1B) >> 6] + (off & 63);
+            reinterpret_cast<f32x4*>(VJ)[t] = *reinterpret_cast<const f32x4*>(src);
+        }
         if (wave < 2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) jw[i] = load_wtile(a.jf_p, wave * 4 + i, lane);
@@ -116,10 +127,10 @@ __global__ __launch_bounds__(256) void k_gat_joint(const JointTailArgs a) {
     __syncthreads();
     // jf = Linear(133->64)(cat(pose2d, pose3d/1000, feat)) + pos_j   (GATOR.py:19, MDR.py:130-134)
     if (wave < 2) {
-        f32x16 acc = load_chanvec_S(a.jf_b, 32 * wave, h) + posj, ac1 = zero16();
+        f32x16 acc = chanvec_lds(VJ, VJ_JFB + 32 * wave, h) + posj, ac1 = zero16();
         const float pin[5] = {p2x, p2y, XO[tkj * 3] / 1000.f, XO[tkj * 3 + 1] / 1000.f, XO[tkj * 3 + 2] / 1000.f};
 #pragma unroll
-        for (int i = 0; i < 5; ++i) acc += load_chanvec_S(a.jf5 + i * 64, 32 * wave, h) * pin[i];
+        for (int i = 0; i < 5; ++i) acc += chanvec_lds(VJ, VJ_JF5 + i * 64 + 32 * wave, h) * pin[i];
         mma2_T(jw[0], ft[0], acc, jw[1], ft[1], ac1);
         mma2_T(jw[2], ft[2], acc, jw[3], ft[3], ac1);
         store_block(JF + wave * kTile, lane, acc + ac1);
@@ -139,8 +150,8 @@ __global__ __launch_bounds__(256) void k_gat_joint(const JointTailArgs a) {
         const WTile nw0 = job_tile(jn, 0), nw1 = job_tile(jn, 1);
         asm volatile("" ::: "memory");
         f32x16 fz[2];
-        fz[0] = d0 * rstd * load_chanvec_S(a.j_n1w[li], 0, h) + load_chanvec_S(a.j_n1b[li], 0, h);
-        fz[1] = d1 * rstd * load_chanvec_S(a.j_n1w[li], 32, h) + load_chanvec_S(a.j_n1b[li], 32, h);
+        fz[0] = d0 * rstd * chanvec_lds(VJ, VJ_N1W + 64 * li, h) + chanvec_lds(VJ, VJ_N1B + 64 * li, h);
+        fz[1] = d1 * rstd * chanvec_lds(VJ, VJ_N1W + 64 * li + 32, h) + chanvec_lds(VJ, VJ_N1B + 64 * li + 32, h);
         float* out = a.jkv + (((size_t)b * 3 + li) * 4 + kv * 2 + nb) * kTile;
         f32x16 r0 = zero16(), r1 = zero16();
         if (kv == 0) {

@@ -71,18 +71,6 @@ __device__ __forceinline__ void layernorm64(const f32x16 (&x)[2], const float* _
     y[1] = d1 * rstd * load_chanvec_S(w, 32, h) + load_chanvec_S(b, 32, h);
 }
 
-// per-channel vector from the workgroup's LDS table (k_mdr_layer): 4 ds_read_b128 with two distinct addresses each, against 32
-// scalar loads + 16 v_mov + 16 v_cndmask for the scalar-cache form -- 30 such vectors per tile were 9 % of the kernel's VALU work
-__device__ __forceinline__ f32x16 chanvec_lds(const float* V, int off, int h) {
-    f32x16 v;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(V + off + 8 * g + 4 * h);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[4 * g + j] = t[j];
-    }
-    return v;
-}
 __device__ __forceinline__ void layernorm64_L(const f32x16 (&x)[2], const float* w, const float* b, int h, f32x16 (&y)[2]) {
     const float mean = row_sum64(x[0], x[1]) * (1.0f / 64.0f);
     f32x16 d0 = x[0] - mean, d1 = x[1] - mean;
