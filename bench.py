@@ -481,7 +481,8 @@ def main():
             # MDR layers (bitwise the same results as the persistent launch).
             variants = {}
             for vname, env in (('headline, re-measured with the variants\' protocol (5 blocks, later in the run: clocks drift)', {}),
-                               ('exact_split (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0)', {'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1', 'GATOR_GAT8_H4': '0'}),
+                               ('exact_split (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 GATOR_GAT_TILED_H4=0)',
+                                {'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1', 'GATOR_GAT8_H4': '0', 'GATOR_GAT_TILED_H4': '0'}),
                                ('six-product encoder (GATOR_GAT8_H4=0)', {'GATOR_GAT8_H4': '0'}),
                                ('three-plane vertex regressor (GATOR_UPSAMPLE_X3=1)', {'GATOR_UPSAMPLE_X3': '1'}),
                                ('fp32_mfma (GATOR_GAT_X3=0 GATOR_MDR_X3=0 GATOR_UPSAMPLE_X3=0)', {'GATOR_GAT_X3': '0', 'GATOR_MDR_X3': '0', 'GATOR_UPSAMPLE_X3': '0'}),

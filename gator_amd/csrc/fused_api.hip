@@ -128,6 +128,15 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
             GATOR_HIP_CHECK(hipMalloc(&f->gxbuf, (size_t)ntiles * kTileX3 * sizeof(float)));
             int rc = fused_repack_x3(f->gblk[0].qkv, f->gxbuf, ntiles, stream);
             if (rc) return rc;
+            const char* th = getenv("GATOR_GAT_TILED_H4");
+            f->gat_tiled_h4 = !(th && atoi(th) == 0);
+            if (f->gat_tiled_h4) {
+                float left = 0.f;
+                GATOR_HIP_CHECK(hipMalloc(&f->gxbuf_h3, (size_t)ntiles * kTileX3 * sizeof(float)));
+                rc = fused_repack_h3(f->gblk[0].qkv, f->gxbuf_h3, ntiles, &f->gat_tiled_wshift, &left, stream);
+                if (rc == GATOR_OK && left > 1e-7f) rc = fail(GATOR_EUNSUPPORTED, "GAT weights span more than fp16 x 3 planes hold exactly: use GATOR_GAT_TILED_H4=0");
+                if (rc) return rc;
+            }
             const char* g8 = getenv("GATOR_GAT8");
             f->gat8 = !(g8 && atoi(g8) == 0);
             const char* g8h = getenv("GATOR_GAT8_H4");
@@ -356,6 +365,7 @@ void fused_destroy(gator_ctx* c) {
     if (c->fused->wbuf) (void)hipFree(c->fused->wbuf);
     if (c->fused->gbuf) (void)hipFree(c->fused->gbuf);
     if (c->fused->gxbuf) (void)hipFree(c->fused->gxbuf);
+    if (c->fused->gxbuf_h3) (void)hipFree(c->fused->gxbuf_h3);
     if (c->fused->g8stream) (void)hipFree(c->fused->g8stream);
     if (c->fused->wxbuf) (void)hipFree(c->fused->wxbuf);
     if (c->fused->up_w16) (void)hipFree(c->fused->up_w16);

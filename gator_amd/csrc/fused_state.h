@@ -56,6 +56,9 @@ struct FusedState : FusedWs {
     bool gat_split_tail = true;         // full forward: lifter + joint tokens as batched launches (GATOR_GAT_TAIL=0: inside k_gat)
     bool gat_x3 = true;                 // GAT linears on split-precision bf16 MFMA (GATOR_GAT_X3=0: fp32-input MFMA)
     float* gxbuf = nullptr;             // X3 tiles of the GAT block weights, tile-for-tile image of gbuf from gblk[0].qkv on
+    float* gxbuf_h3 = nullptr;          // the same grids as three fp16 planes of 2^gat_tiled_wshift * w (k_gat_tiled's four-product form)
+    bool gat_tiled_h4 = true;           // GATOR_GAT_TILED_H4=0: the sample-tiled encoder on the exact six products
+    int gat_tiled_wshift = 0;
     float* g8stream = nullptr;          // the same tiles as four per-wave streams in consumption order (gat_roles.hip)
     bool gat8 = true;                   // one-sample-per-workgroup encoder: the two-role kernel k_gat8 (GATOR_GAT8=0: k_gat)
     bool gat8_h4 = true;                // ... with its token-wise products on four partial products (x3_common.h; GATOR_GAT8_H4=0: the exact six)

@@ -21,6 +21,9 @@
 #include "fused_state.h"
 #include "x3_common.h"
 
+#include <cmath>
+#include <type_traits>
+
 namespace gator {
 namespace {
 
@@ -48,6 +51,7 @@ struct TiledArgs {
     const float *norm_w, *norm_b;
     TiledBlk blk[kDepth];
     float *feat, *blk_tap;
+    float lin_s, lin_inv;           // H4 form: the token-wise products return lin_s x their value (x3_common.h: 4-product linears)
 };
 
 // LDS carve-up (floats)
@@ -172,13 +176,16 @@ __device__ __forceinline__ void glds16(const float* gsrc, const float* lds_dst) 
 
 // N weight tiles of a ring slot, one product each: tile i+1 is read from LDS while tile i feeds its 12 MFMAs, and never earlier
 // (unfenced, hipcc hoists all of a group's LDS reads to its top: 5 x 24 registers on top of the 300 the state needs -> scratch).
-template <int N, class F>
+__device__ __forceinline__ void ld_wtile(X3& o, const float* p, int lane) { o = x3_load(p, lane); }
+__device__ __forceinline__ void ld_wtile(H3& o, const float* p, int lane) { o = h3_load(p, lane); }
+template <int N, class WT, class F>
 __device__ __forceinline__ void for_tiles(const float* slot, int lane, F&& f) {
-    X3 cur = x3_load(slot, lane);
+    WT cur;
+    ld_wtile(cur, slot, lane);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        X3 nxt = cur;
-        if (i + 1 < N) nxt = x3_load(slot + (i + 1) * kTileX3, lane);
+        WT nxt = cur;
+        if (i + 1 < N) ld_wtile(nxt, slot + (i + 1) * kTileX3, lane);
         f(i, cur);
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
@@ -215,8 +222,29 @@ __device__ __forceinline__ int group_tiles(const TiledBlk& w, int g, const float
     return 4;
 }
 
-template <int J>
+// H4: token-wise products on four partial products (weights H3 in the ring, operands X2 in registers): every accumulator of such a
+// product - and every exchange image, bias and aggregate made from one - carries the factor a.lin_s; the residual stream, the
+// LayerNorms and the GELU's result do not.
+template <int J, bool H4>
 __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
+    typedef typename std::conditional<H4, H3, X3>::type WT;
+    typedef typename std::conditional<H4, X2, X3>::type OT;
+    const float inv = H4 ? a.lin_inv : 1.0f;
+    auto sp = [&](const f32x16& v, float pre) -> OT {       // operand form of a register tile that holds 1 / pre x its value
+        if constexpr (H4) return x2_split(v * (16.0f * pre)); else return x3_split(v);
+    };
+    auto mm = [&](const WT& wt, const OT& x, const f32x16& acc) -> f32x16 {
+        if constexpr (H4) return h3_mma_wa(wt, x, acc); else return x3_mma(wt, x, acc);
+    };
+    // the block's vector table: biases that start an accumulator carry lin_s
+    auto stage_vecs = [&](const float* vecs, float* Vd, int tid_) {
+        for (int e = tid_; e < TV_TOTAL / 4; e += 256) {
+            f32x4 v = reinterpret_cast<const f32x4*>(vecs)[e];
+            const int off = 4 * e;
+            if (H4 && ((off >= TV_QKVB && off < TV_N2W) || off >= TV_FC1B)) v = v * a.lin_s;
+            reinterpret_cast<f32x4*>(Vd)[e] = v;
+        }
+    };
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *RING = lds + oRING, *EXK = lds + oEXK, *EXV = lds + oEXV, *V = lds + oVEC;
     float *TBIAS = lds + oBIAS, *TAOFF = lds + oAOFF, *TM1 = lds + oM1, *TM2 = lds + oM2, *TADIAG = lds + oADIAG, *TL1B = lds + oL1B, *MT = lds + oMT;
@@ -266,9 +294,9 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
     for (int e = tid; e < kDepth * J * J; e += 256) TAOFF[(e / J) * kTabS + e % J] = a.adj_off[e];
     for (int e = tid; e < J * J; e += 256) { TM1[(e / J) * kTabS + e % J] = a.m1[e]; TM2[(e / J) * kTabS + e % J] = a.m2[e]; }
     for (int e = tid; e < kDepth * J; e += 256) TADIAG[(e / J) * 32 + e % J] = a.adj_diag[e];
-    for (int e = tid; e < kDepth * 16; e += 256) TL1B[e] = a.blk[e >> 4].lin1_b[e & 15];
+    for (int e = tid; e < kDepth * 16; e += 256) TL1B[e] = a.blk[e >> 4].lin1_b[e & 15] * (H4 ? a.lin_s : 1.0f);
     for (int e = tid; e < J * kC / 4; e += 256) reinterpret_cast<f32x4*>(MT)[e] = reinterpret_cast<const f32x4*>(a.blk[0].M)[e];
-    for (int e = tid; e < TV_TOTAL / 4; e += 256) reinterpret_cast<f32x4*>(V)[e] = reinterpret_cast<const f32x4*>(a.blk[0].vecs)[e];
+    stage_vecs(a.blk[0].vecs, V, tid);
 
     // ---- embedding: GraphLinear(2->64) . GroupNorm(4,64) . GELU . GraphLinear(64->128) + pos (GAT.py:135-144) -------------
     f32x16 x[4];
@@ -343,13 +371,13 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
         // ================= phase 1: x_hat = LN1(x); per channel block nb: q,k,v (attention), h0,h1 (MGCN), then proj =================
         f32x16 pacc[4];                                                      // s = proj(attn) + proj.bias + MGCN + gcn.bias
         {
-            X3 ys[4];
+            OT ys[4];
             __syncthreads();                                                 // V of this block (written behind the previous block's last barrier) is visible
             {
                 f32x16 yf[4];
                 ln128<false>(x, V, TV_N1W, TV_N1B, h, yf);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ys[i] = x3_split(yf[i]);
+                for (int i = 0; i < 4; ++i) ys[i] = sp(yf[i], 1.0f);
             }
             adiag = TADIAG[bi * 32 + j];
 #pragma unroll
@@ -361,11 +389,11 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
                     const float* slot = begin_group();
-                    for_tiles<4>(slot, lane, [&](int i, const X3& wt) {
-                        if (i == 0) q = x3_mma(wt, ys[kb], q);
-                        if (i == 1) k = x3_mma(wt, ys[kb], k);
-                        if (i == 2) v = x3_mma(wt, ys[kb], v);
-                        if (i == 3) h1 = x3_mma(wt, ys[kb], h1);
+                    for_tiles<4, WT>(slot, lane, [&](int i, const WT& wt) {
+                        if (i == 0) q = mm(wt, ys[kb], q);
+                        if (i == 1) k = mm(wt, ys[kb], k);
+                        if (i == 2) v = mm(wt, ys[kb], v);
+                        if (i == 3) h1 = mm(wt, ys[kb], h1);
                     });
                 }
                 // exchange images of this channel block: K and V rows of every token slot
@@ -374,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
                 f32x16 h0 = zero16();
                 {
                     const float* slot = begin_group();                       // W0 tiles; the barrier publishes K and V
-                    for_tiles<4>(slot, lane, [&](int kb, const X3& wt) { h0 = x3_mma(wt, ys[kb], h0); });
+                    for_tiles<4, WT>(slot, lane, [&](int kb, const WT& wt) { h0 = mm(wt, ys[kb], h0); });
                 }
                 // ---- attention of head 2 nb + h for this lane's query token (modules.py:121-138) ----
                 f32x16 att;
@@ -394,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) s = fmaf(qh[4 * g + i], kv[i], s);
                         }
-                        s = (s * 0.25f + brow[jp]) * kLog2eT;                // q k^T * head_dim**-0.5 + hop/path bias
+                        s = (s * (0.25f * inv * inv) + brow[jp]) * kLog2eT;  // q k^T * head_dim**-0.5 + hop/path bias (q, k carry lin_s)
                         sc[jp] = s;
                         mx = fmaxf(mx, s);
                     }
@@ -422,8 +450,8 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
                 ex_write(EXK, t, h, mblk * h1);                              // M . h1 takes its place
                 // ---- proj: contribution of channel block nb of the attention output to all four output blocks ----
                 {
-                    const X3 ax = x3_split(att);
-                    for_tiles<4>(slot, lane, [&](int i, const X3& wt) { pacc[i] = x3_mma(wt, ax, pacc[i]); });
+                    const OT ax = sp(att, inv);                                // (att = P . V' carries lin_s like V')
+                    for_tiles<4, WT>(slot, lane, [&](int i, const WT& wt) { pacc[i] = mm(wt, ax, pacc[i]); });
                 }
                 __syncthreads();                                             // publishes the M . h1 image
                 // ---- MGCN (modules.py:243-255): diag(A) (M . h0) + offdiag(A) (M . h1) on this lane's 16 channels ----
@@ -443,9 +471,9 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
             float c1[J], c2[J];
             table_row<J>(TM1, j, c1);
             table_row<J>(TM2, j, c2);
-            X3 ss[4];
+            OT ss[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ss[i] = x3_split(pacc[i]);
+            for (int i = 0; i < 4; ++i) ss[i] = sp(pacc[i], inv);
             f32x16 xb[4];                                                    // linearback output; added to the residual once
 #pragma unroll
             for (int i = 0; i < 4; ++i) xb[i] = chanvec_L(V, TV_BACKB + 32 * i, h);
@@ -454,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
                 {   // linears[0], output block nb
                     const float* slot = begin_group();
                     f32x16 u0 = chanvec_L(V, TV_LIN0B + 32 * nb, h);
-                    for_tiles<4>(slot, lane, [&](int kb, const X3& wt) { u0 = x3_mma(wt, ss[kb], u0); });
+                    for_tiles<4, WT>(slot, lane, [&](int kb, const WT& wt) { u0 = mm(wt, ss[kb], u0); });
                     ex_write(EXK, t, h, u0);
                 }
                 if (nb == 0) {   // linears[1] (128 -> 16): rows >= 16 of its tiles are zero
@@ -462,33 +490,33 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
                     f32x16 u1;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { const int c = kap(r) + 4 * h; u1[r] = c < 16 ? TL1B[bi * 16 + (c & 15)] : 0.f; }
-                    for_tiles<4>(slot, lane, [&](int kb, const X3& wt) { u1 = x3_mma(wt, ss[kb], u1); });
+                    for_tiles<4, WT>(slot, lane, [&](int kb, const WT& wt) { u1 = mm(wt, ss[kb], u1); });
                     ex_write(EXV, t, h, u1);
                 }
                 {   // hop<=1 aggregation of block nb, then its contribution to linearback
                     const float* slot = begin_group();                       // the barrier publishes u0 (and u1)
-                    const X3 fx = x3_split(aggregate<J>(EXK, base, h, c1));
+                    const OT fx = sp(aggregate<J>(EXK, base, h, c1), inv);
                     __builtin_amdgcn_sched_barrier(0);
-                    for_tiles<4>(slot, lane, [&](int i, const X3& wt) { xb[i] = x3_mma(wt, fx, xb[i]); });
+                    for_tiles<4, WT>(slot, lane, [&](int i, const WT& wt) { xb[i] = mm(wt, fx, xb[i]); });
                 }
             }
             {   // hop==2 aggregation of the 16-wide branch: k-block 4 of linearback
                 const float* slot = begin_group();
-                const X3 fx = x3_split(aggregate<J>(EXV, base, h, c2));
+                const OT fx = sp(aggregate<J>(EXV, base, h, c2), inv);
                 __builtin_amdgcn_sched_barrier(0);
-                for_tiles<4>(slot, lane, [&](int i, const X3& wt) { xb[i] = x3_mma(wt, fx, xb[i]); });
+                for_tiles<4, WT>(slot, lane, [&](int i, const WT& wt) { xb[i] = mm(wt, fx, xb[i]); });
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] += xb[i];
+            for (int i = 0; i < 4; ++i) { if constexpr (H4) x[i] = fma16(xb[i], inv, x[i]); else x[i] += xb[i]; }
         }
         // ================= phase 3: MLP (modules.py:188-196) + residual =================
         {
-            X3 y2[4];
+            OT y2[4];
             {
                 f32x16 yf[4];
                 ln128<false>(x, V, TV_N2W, TV_N2B, h, yf);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) y2[i] = x3_split(yf[i]);
+                for (int i = 0; i < 4; ++i) y2[i] = sp(yf[i], 1.0f);
             }
             f32x16 xm[4];                                                    // fc2 output; added to the residual once
 #pragma unroll
@@ -497,14 +525,14 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
             for (int c = 0; c < 16; ++c) {
                 const float* s1 = begin_group();
                 f32x16 hd = chanvec_L(V, TV_FC1B + 32 * c, h);
-                for_tiles<4>(s1, lane, [&](int kb, const X3& wt) { hd = x3_mma(wt, y2[kb], hd); });
-                gelu_tile(hd);
-                const X3 hx = x3_split(hd);
+                for_tiles<4, WT>(s1, lane, [&](int kb, const WT& wt) { hd = mm(wt, y2[kb], hd); });
+                if constexpr (H4) gelu_tile_scaled(hd, inv); else gelu_tile(hd);
+                const OT hx = sp(hd, inv);
                 const float* s2 = begin_group();
-                for_tiles<4>(s2, lane, [&](int i, const X3& wt) { xm[i] = x3_mma(wt, hx, xm[i]); });
+                for_tiles<4, WT>(s2, lane, [&](int i, const WT& wt) { xm[i] = mm(wt, hx, xm[i]); });
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] += xm[i];
+            for (int i = 0; i < 4; ++i) { if constexpr (H4) x[i] = fma16(xm[i], inv, x[i]); else x[i] += xm[i]; }
         }
         if (a.blk_tap && valid) {
             float* dst = a.blk_tap + ((size_t)bi * a.Btap * J + gtok) * kC + 4 * h;
@@ -521,7 +549,7 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
         // next block's vectors: every read of V of this block is done once all waves pass this barrier
         if (bi + 1 < kDepth) {
             __syncthreads();
-            for (int e = tid; e < TV_TOTAL / 4; e += 256) reinterpret_cast<f32x4*>(V)[e] = reinterpret_cast<const f32x4*>(a.blk[bi + 1].vecs)[e];
+            stage_vecs(a.blk[bi + 1].vecs, V, tid);
             for (int e = tid; e < J * kC / 4; e += 256) reinterpret_cast<f32x4*>(MT)[e] = reinterpret_cast<const f32x4*>(a.blk[bi + 1].M)[e];
         }
     }
@@ -554,8 +582,11 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
 int gat_tiled_samples_per_wg(int J) { return kTT / J; }
 
 int gat_tiled_prepare_device() {
-    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat_tiled<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTiledLdsFloats * sizeof(float))));
-    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat_tiled<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTiledLdsFloats * sizeof(float))));
+    const int ldsb = (int)(kTiledLdsFloats * sizeof(float));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat_tiled<17, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat_tiled<19, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat_tiled<17, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat_tiled<19, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
     return GATOR_OK;
 }
 
@@ -571,7 +602,8 @@ int launch_gat_tiled(gator_ctx* c, FusedState* f, const float* pose2d, int B, fl
     for (int i = 0; i < kDepth; ++i) {
         const GatBlockPk& p = f->gblk[i];
         TiledBlk& q = a.blk[i];
-        auto sel = [&](const float* t) { return f->gxbuf + (size_t)(t - f->gblk[0].qkv) / kTile * kTileX3; };
+        const float* image = f->gat_tiled_h4 ? f->gxbuf_h3 : f->gxbuf;
+        auto sel = [&](const float* t) { return image + (size_t)(t - f->gblk[0].qkv) / kTile * kTileX3; };
         q.qkv = sel(p.qkv); q.proj = sel(p.proj); q.w0 = sel(p.w0); q.w1 = sel(p.w1); q.lin0 = sel(p.lin0); q.lin1 = sel(p.lin1);
         q.back = sel(p.back); q.fc1 = sel(p.fc1); q.fc2 = sel(p.fc2);
         q.vecs = f->g_vecs + (size_t)i * 2048;
@@ -587,8 +619,15 @@ int launch_gat_tiled(gator_ctx* c, FusedState* f, const float* pose2d, int B, fl
     }
     const int nwg = (B + a.S - 1) / a.S;
     const size_t ldsb = kTiledLdsFloats * sizeof(float);
-    if (c->J == 17) k_gat_tiled<17><<<nwg, 256, ldsb, (hipStream_t)stream>>>(a);
-    else k_gat_tiled<19><<<nwg, 256, ldsb, (hipStream_t)stream>>>(a);
+    a.lin_s = f->gat_tiled_h4 ? std::ldexp(16.0f, f->gat_tiled_wshift) : 1.0f;
+    a.lin_inv = 1.0f / a.lin_s;
+    if (f->gat_tiled_h4) {
+        if (c->J == 17) k_gat_tiled<17, true><<<nwg, 256, ldsb, (hipStream_t)stream>>>(a);
+        else k_gat_tiled<19, true><<<nwg, 256, ldsb, (hipStream_t)stream>>>(a);
+    } else {
+        if (c->J == 17) k_gat_tiled<17, false><<<nwg, 256, ldsb, (hipStream_t)stream>>>(a);
+        else k_gat_tiled<19, false><<<nwg, 256, ldsb, (hipStream_t)stream>>>(a);
+    }
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;
 }

@@ -25,8 +25,10 @@ def test_scale_free_parity(fixture, gain, x3, monkeypatch):
             monkeypatch.setenv(k, x3)
     if x3 == 'default':
         monkeypatch.delenv('GATOR_GAT8_H4', raising=False)
+        monkeypatch.delenv('GATOR_GAT_TILED_H4', raising=False)
     else:
         monkeypatch.setenv('GATOR_GAT8_H4', '0')             # '1': no rounded operand anywhere
+        monkeypatch.setenv('GATOR_GAT_TILED_H4', '0')
     z = load_golden(fixture)
     zz, m = build_model(str(z['variant']), 'fused', upsample_gain=gain)
     sub = torch.from_numpy(z['vertex_subset'].astype(np.int64)).cuda()

@@ -18,6 +18,7 @@ SWITCHES = ('GATOR_GAT_X3', 'GATOR_MDR_X3', 'GATOR_UPSAMPLE_X3')      # + GATOR_
 
 def _run(monkeypatch, name, x, off, mdr_mode='1', up_mode='1', gat_h4='0'):
     monkeypatch.setenv('GATOR_GAT8_H4', gat_h4)
+    monkeypatch.setenv('GATOR_GAT_TILED_H4', gat_h4)
     for k in SWITCHES:
         on = mdr_mode if k == 'GATOR_MDR_X3' else (up_mode if k == 'GATOR_UPSAMPLE_X3' else '1')
         monkeypatch.setenv(k, '0' if k in off else on)
