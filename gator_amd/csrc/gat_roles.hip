@@ -40,9 +40,17 @@ namespace gator {
 namespace {
 
 constexpr float kLog2e8 = 1.4426950408889634f;
-constexpr int kNT = 5;                                  // weight tiles in flight per product wave (65 tiles per block = 13 x 5)
-constexpr int kBlkTiles = 65;                           // q k v h0 h1 proj lin0 (4 each) + lin1 (1) + back (4) + fc1 (16) + fc2 (16)
-constexpr int kWaveTiles = kBlkTiles * kDepth;          // 390 per product wave
+#ifndef GAT8_NT
+#define GAT8_NT 5
+#endif
+constexpr int kNT = GAT8_NT;                            // weight tiles in flight per product wave.  6 (one dummy tile per block, +28 VGPRs) was measured:
+                                                        // no change (188 - 192 us either way on one box), so the stream is not short of bytes in flight
+constexpr int kUseTiles = 65;                           // q k v h0 h1 proj lin0 (4 each) + lin1 (1) + back (4) + fc1 (16) + fc2 (16)
+constexpr int kPadTiles = (kNT - kUseTiles % kNT) % kNT;       // dummy tiles behind a block so that every block starts at slot 0
+constexpr int kBlkTiles = kUseTiles + kPadTiles;
+// tile offsets of the units inside a block (their slot = offset mod kNT, compile-time)
+enum { OFF_Q = 0, OFF_K = 4, OFF_V = 8, OFF_H0 = 12, OFF_H1 = 16, OFF_PROJ = 20, OFF_LIN0 = 24, OFF_LIN1 = 28, OFF_BACK = 29, OFF_FC1 = 33, OFF_FC2 = 49 };
+constexpr int kWaveTiles = kBlkTiles * kDepth;          // per product wave
 constexpr int kStreamFloats = (4 * kWaveTiles + kNT) * kTileX3;
 
 // offsets into a block's vector table (fused_api.hip packs them in this order, 2048 floats per block)
@@ -268,6 +276,16 @@ __device__ __forceinline__ void unit1(WT (&W)[kNT], const float* __restrict__& w
     store_block(raw, lane, acc);
 }
 
+// consume the kPadTiles dummy tiles behind a block: their slots get the tiles kNT positions further down (the next block's)
+template <int S0, class WT>
+__device__ __forceinline__ void skip_pad(WT (&W)[kNT], const float* __restrict__& wp, int lane) {
+#pragma unroll
+    for (int i = 0; i < kPadTiles; ++i) {
+        ld_tile(W[(S0 + i) % kNT], wp, lane);
+        wp += kTileX3;
+    }
+}
+
 // H4: the token-wise products on four partial products (weights H3, operands X2; raw tiles carry 1 / a.lin_inv) instead of six
 template <bool H4>
 __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
@@ -354,58 +372,59 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             const float *Y0 = A, *Y1 = A + kTileX3, *Y2 = A + 2 * kTileX3, *Y3 = A + 3 * kTileX3;
             OT pre;
             ld_tile(pre, Y0, lane);
-            unit4<0, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             // q  (T)
+            unit4<OFF_Q % kNT, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             // q  (T)
             ld_tile(pre, Y0, lane);
             GAT8_BAR(1);
-            unit4<4, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             // k  (T)
+            unit4<OFF_K % kNT, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             // k  (T)
             ld_tile(pre, Y0, lane);
             GAT8_BAR(2);
-            unit4<3, true>(W, wp, pre, Y1, Y2, Y3, R0w, lane);              // v  (C)
+            unit4<OFF_V % kNT, true>(W, wp, pre, Y1, Y2, Y3, R0w, lane);              // v  (C)
             ld_tile(pre, Y0, lane);
             GAT8_BAR(3);
-            unit4<2, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             // h0 = y W[0]  (T: its MGCN term is token-wise)
+            unit4<OFF_H0 % kNT, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             // h0 = y W[0]  (T: its MGCN term is token-wise)
             ld_tile(pre, Y0, lane);
             GAT8_BAR(4);
-            unit4<1, true>(W, wp, pre, Y1, Y2, Y3, R0w, lane);              // h1 = y W[1]  (C)
+            unit4<OFF_H1 % kNT, true>(W, wp, pre, Y1, Y2, Y3, R0w, lane);              // h1 = y W[1]  (C)
             GAT8_BAR(5);
             ld_tile(pre, Bq, lane);
-            unit4<0, false>(W, wp, pre, Bq + kTileX3, Bq + 2 * kTileX3, Bq + 3 * kTileX3, R1w, lane);                   // proj(AT)
+            unit4<OFF_PROJ % kNT, false>(W, wp, pre, Bq + kTileX3, Bq + 2 * kTileX3, Bq + 3 * kTileX3, R1w, lane);                   // proj(AT)
             GAT8_BAR(6);
             GAT8_BAR(7);                                                    // helpers: SB = proj + attention bias + MGCN
             ld_tile(pre, Bq + 4 * kTileX3, lane);
-            unit4<4, true>(W, wp, pre, Bq + 5 * kTileX3, Bq + 6 * kTileX3, Bq + 7 * kTileX3, R0w, lane);                // linears[0](SB)  (C)
-            unit1<3, OT>(W, wp, Bq + (4 + w) * kTileX3, X + w * kTile, lane);                                              // linears[1], k block w
+            unit4<OFF_LIN0 % kNT, true>(W, wp, pre, Bq + 5 * kTileX3, Bq + 6 * kTileX3, Bq + 7 * kTileX3, R0w, lane);                // linears[0](SB)  (C)
+            unit1<OFF_LIN1 % kNT, OT>(W, wp, Bq + (4 + w) * kTileX3, X + w * kTile, lane);                                              // linears[1], k block w
             GAT8_BAR(8);
             GAT8_BAR(9);                                                    // helpers: hop aggregations -> FB
             ld_tile(pre, Bq + 8 * kTileX3, lane);
-            unit4<4, false>(W, wp, pre, Bq + 9 * kTileX3, Bq + 10 * kTileX3, Bq + 11 * kTileX3, R1w, lane);             // linearback(FB), k < 128
+            unit4<OFF_BACK % kNT, false>(W, wp, pre, Bq + 9 * kTileX3, Bq + 10 * kTileX3, Bq + 11 * kTileX3, R1w, lane);             // linearback(FB), k < 128
             GAT8_BAR(10);
             GAT8_BAR(11);                                                   // helpers: residual
             GAT8_BAR(12);                                                   // helpers: Y2 = LN2(x)
             ld_tile(pre, Y0, lane);
-            unit4<3, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             // fc1, hidden block 4w
+            unit4<(OFF_FC1 + 0) % kNT, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             // fc1, hidden block 4w
             ld_tile(pre, Y0, lane);
             GAT8_BAR(13);
-            unit4<2, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 1
+            unit4<(OFF_FC1 + 4) % kNT, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 1
             ld_tile(pre, Y0, lane);
             GAT8_BAR(14);
-            unit4<1, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             //      4w + 2
+            unit4<(OFF_FC1 + 8) % kNT, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             //      4w + 2
             ld_tile(pre, Y0, lane);
             GAT8_BAR(15);
-            unit4<0, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 3
+            unit4<(OFF_FC1 + 12) % kNT, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 3
             ld_tile(pre, Bq, lane);                                        // (hidden blocks 4w' were complete at barrier 14)
             GAT8_BAR(16);
             // fc2: unit u contracts over hidden blocks {4w' + u}: tiles 3w' + u of B for u < 3, tile w' of A for u = 3
-            unit4<4, false>(W, wp, pre, Bq + 3 * kTileX3, Bq + 6 * kTileX3, Bq + 9 * kTileX3, R0w, lane);
+            unit4<(OFF_FC2 + 0) % kNT, false>(W, wp, pre, Bq + 3 * kTileX3, Bq + 6 * kTileX3, Bq + 9 * kTileX3, R0w, lane);
             ld_tile(pre, Bq + 1 * kTileX3, lane);
             GAT8_BAR(17);
-            unit4<3, false>(W, wp, pre, Bq + 4 * kTileX3, Bq + 7 * kTileX3, Bq + 10 * kTileX3, R1w, lane);
+            unit4<(OFF_FC2 + 4) % kNT, false>(W, wp, pre, Bq + 4 * kTileX3, Bq + 7 * kTileX3, Bq + 10 * kTileX3, R1w, lane);
             ld_tile(pre, Bq + 2 * kTileX3, lane);
             GAT8_BAR(18);
-            unit4<2, false>(W, wp, pre, Bq + 5 * kTileX3, Bq + 8 * kTileX3, Bq + 11 * kTileX3, R0w, lane);
+            unit4<(OFF_FC2 + 8) % kNT, false>(W, wp, pre, Bq + 5 * kTileX3, Bq + 8 * kTileX3, Bq + 11 * kTileX3, R0w, lane);
             ld_tile(pre, Y0, lane);                                        // (hidden blocks 4w' + 3, complete at barrier 17)
             GAT8_BAR(19);
-            unit4<1, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);
+            unit4<(OFF_FC2 + 12) % kNT, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);
+            skip_pad<(OFF_FC2 + 16) % kNT>(W, wp, lane);                          // the block's dummy tiles: refill their slots, no product
             GAT8_BAR(20);
             GAT8_BAR(21);                                                   // helpers: residual
             GAT8_BAR(22);                                                   // helpers: Y = LN1(x) of the next block | final norm
@@ -723,6 +742,7 @@ int gat8_build_stream(FusedState* f, void* stream) {
                 for (int kb = 0; kb < 4; ++kb) *o++ = fc1 + ((4 * w + j) * 4 + kb);    // fc1, hidden block 4w + j
             for (int u = 0; u < 4; ++u)
                 for (int wq = 0; wq < 4; ++wq) *o++ = fc2 + (w * 16 + 4 * wq + u);     // fc2, hidden blocks {4w' + u}
+            for (int i = 0; i < kPadTiles; ++i) *o++ = qkv;                             // dummy: loaded into a slot, never multiplied
         }
         if (o - idx.data() != (ptrdiff_t)(w + 1) * kWaveTiles) return fail(GATOR_EINVAL, "gat8_build_stream: tile count");
     }
