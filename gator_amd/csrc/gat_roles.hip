@@ -239,6 +239,12 @@ __device__ __forceinline__ void tile_mma_refill(H3& w, const X2& b, f32x16& acc,
     }
 #undef GAT8_MM
 }
+// one k-step of the two-plane product (x3_common.h: x2_mma does both): lo*hi | hi*lo | hi*hi
+__device__ __forceinline__ f32x16 x2_mma_step(const X2& A, const X2& B, int s, f32x16 acc) {
+    acc = GATOR_MFMA_F16(A.p[1][s], B.p[0][s], acc);
+    acc = GATOR_MFMA_F16(A.p[0][s], B.p[1][s], acc);
+    return GATOR_MFMA_F16(A.p[0][s], B.p[0][s], acc);
+}
 // operand / weight tile access of the two forms
 __device__ __forceinline__ void ld_tile(X3& o, const float* p, int lane) { o = x3_load(p, lane); }
 __device__ __forceinline__ void ld_tile(X2& o, const float* p, int lane) { o = x2_load(p, lane); }
@@ -469,16 +475,28 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         f32x16 sa = zero16(), sb = zero16();
         {
             const f32x16 k = pick(R1w, lane, bk);
+            float sscale = 0.25f;
+            if constexpr (H4) {      // q, k on two fp16 planes of 16 x value: a head's 16 channels are exactly one k-step (registers 0..7 | 8..15)
+                const X2 kx = x2_split(k * 16.0f), qx = x2_split(q * 16.0f);
+                sa = GATOR_MFMA_F16(kx.p[1][0], qx.p[0][0], sa);
+                sb = GATOR_MFMA_F16(kx.p[1][1], qx.p[0][1], sb);
+                sa = GATOR_MFMA_F16(kx.p[0][0], qx.p[1][0], sa);
+                sb = GATOR_MFMA_F16(kx.p[0][1], qx.p[1][1], sb);
+                sa = GATOR_MFMA_F16(kx.p[0][0], qx.p[0][0], sa);
+                sb = GATOR_MFMA_F16(kx.p[0][1], qx.p[0][1], sb);
+                sscale = 0.25f / 256.0f;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                sa = GATOR_MFMA(k[r], q[r], sa);                                    // head 2w:   channels 0..15 of the block
-                sb = GATOR_MFMA(k[r + 8], q[r + 8], sb);                            // head 2w+1: channels 16..31
+                for (int r = 0; r < 8; ++r) {
+                    sa = GATOR_MFMA(k[r], q[r], sa);                                // head 2w:   channels 0..15 of the block
+                    sb = GATOR_MFMA(k[r + 8], q[r + 8], sb);                        // head 2w+1: channels 16..31
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const bool ok = kap(r) + 4 * h < J;
-                sa[r] = ok ? (sa[r] * 0.25f + ba[r]) * kLog2e8 : -1e30f;             // q k^T * head_dim**-0.5 + hop/path bias
-                sb[r] = ok ? (sb[r] * 0.25f + bb[r]) * kLog2e8 : -1e30f;
+                sa[r] = ok ? (sa[r] * sscale + ba[r]) * kLog2e8 : -1e30f;            // q k^T * head_dim**-0.5 + hop/path bias
+                sb[r] = ok ? (sb[r] * sscale + bb[r]) * kLog2e8 : -1e30f;
             }
             float ma, mb, la, lb;
             {   // row maxima and sums as trees (four independent partials each)
@@ -518,23 +536,43 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         {
             f32x16 v = load_block(R0w, lane);
             if constexpr (H4) v = v * inv;
+            X2 va, vbx, pa, pb;      // H4: V of head 2w (channel lanes 0..15) / head 2w+1 (16..31) and the two probability tiles on two planes
+            if constexpr (H4) {
+                const X2 vx = x2_split((v + vb) * 16.0f);
+                const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float vv = v[r] + vb;
-                O = GATOR_MFMA(lo ? vv : 0.f, sa[r], O);
-                Ob = GATOR_MFMA(lo ? 0.f : vv, sb[r], Ob);
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) { va.p[pl][ks] = lo ? vx.p[pl][ks] : z; vbx.p[pl][ks] = lo ? z : vx.p[pl][ks]; }
+                pa = x2_split(sa * 64.0f);
+                pb = x2_split(sb * 64.0f);
+                O = x2_mma_step(va, pa, 0, O);
+                Ob = x2_mma_step(vbx, pb, 0, Ob);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float vv = v[r] + vb;
+                    O = GATOR_MFMA(lo ? vv : 0.f, sa[r], O);
+                    Ob = GATOR_MFMA(lo ? 0.f : vv, sb[r], Ob);
+                }
             }
             GAT8_BAR(4);
             const f32x16 mdt = load_block(kb.mdT + (size_t)w * kTile, lane);        // (constants are requested about one step before their use)
             f32x16 h0 = load_block(R1w, lane);
             if constexpr (H4) h0 = h0 * inv;
+            if constexpr (H4) {
+                O = x2_mma_step(va, pa, 1, O);
+                Ob = x2_mma_step(vbx, pb, 1, Ob);
+                x2_store(Bq + w * kTileX3, lane, x2_split((O + Ob) * (16.0f / 1024.0f)));      // AT[w]: O carries 16 x 64
+            } else {
 #pragma unroll
-            for (int r = 8; r < 16; ++r) {
-                const float vv = v[r] + vb;
-                O = GATOR_MFMA(lo ? vv : 0.f, sa[r], O);
-                Ob = GATOR_MFMA(lo ? 0.f : vv, sb[r], Ob);
+                for (int r = 8; r < 16; ++r) {
+                    const float vv = v[r] + vb;
+                    O = GATOR_MFMA(lo ? vv : 0.f, sa[r], O);
+                    Ob = GATOR_MFMA(lo ? 0.f : vv, sb[r], Ob);
+                }
+                st_opnd(Bq + w * kTileX3, lane, O + Ob);                            // AT[w]
             }
-            st_opnd(Bq + w * kTileX3, lane, O + Ob);                                // AT[w]
             O = h0 * mdt;                                                          // diag(A)[t] * M[t][n] * h0[t][n]  (O re-used)
         }
         const f32x16 mct = load_block(kb.mc + (size_t)w * kTile, lane), aoff = load_block(kb.aoffT, lane);
@@ -565,11 +603,29 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         {
             const f32x16 u0 = pick(R0w, lane, f32x16(b0));
             f32x16 u1 = (load_block(X, lane) + load_block(X + kTile, lane)) + (load_block(X + 2 * kTile, lane) + load_block(X + 3 * kTile, lane));
-            if constexpr (H4) u1 = u1 * inv;
-            f32x16 f0 = zero16(), f1a = zero16();
-            dot16x2(u0, m1, f0, u1, m2, f1a);
-            st_opnd(Bq + (8 + w) * kTileX3, lane, f0);                            // FB[w]
-            f1 += f1a;
+            if constexpr (H4) {
+                // the hop masks are 0 / 1: one exact fp16 plane; the aggregated tiles on two planes like every other operand of this
+                // form -> 2 x 4 fp16 MFMAs (256 cycles) instead of 32 fp32-input ones (2 048) in a step the product waves wait through
+                const X2 u0x = x2_split(u0 * 16.0f), u1x = x2_split(u1 * (16.0f * inv));
+                f32x16 f0 = zero16(), f1a = zero16();
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    f16x8 m1h, m2h;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { m1h[j] = (_Float16)m1[8 * s + j]; m2h[j] = (_Float16)m2[8 * s + j]; }
+                    f0 = GATOR_MFMA_F16(u0x.p[1][s], m1h, f0);
+                    f1a = GATOR_MFMA_F16(u1x.p[1][s], m2h, f1a);
+                    f0 = GATOR_MFMA_F16(u0x.p[0][s], m1h, f0);
+                    f1a = GATOR_MFMA_F16(u1x.p[0][s], m2h, f1a);
+                }
+                x2_store(Bq + (8 + w) * kTileX3, lane, x2_split(f0));              // FB[w]: f0 already carries the operand scale 16
+                f1 = fma16(f1a, 1.0f / 16.0f, f1);
+            } else {
+                f32x16 f0 = zero16(), f1a = zero16();
+                dot16x2(u0, m1, f0, u1, m2, f1a);
+                st_opnd(Bq + (8 + w) * kTileX3, lane, f0);                        // FB[w]
+                f1 += f1a;
+            }
         }
         const f32x16 bback = load_chanvec_T(vec, V_BACKB + 32 * w, h);
         f32x4 wb40, wb41;                                                          // linearback's k block 4 (fp32 tile): only k < 16 is live
