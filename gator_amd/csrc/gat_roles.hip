@@ -20,12 +20,13 @@
 // LayerNorm twice).  Both roles live in disjoint branches of one kernel so that neither pays the other's registers; the barriers
 // are numbered GAT8_BAR(n) in both and tests/test_host_cpu.py checks that the two sequences are identical.
 //
-// LDS (144 KiB): A = 4 operand tiles (Y = LN1(x) | Y2 = LN2(x) | hidden blocks 4w+3), B = 12 operand tiles (AT | SB | FB, later
+// LDS (149 KiB): A = 4 operand tiles (Y = LN1(x) | Y2 = LN2(x) | hidden blocks 4w+3), B = 12 operand tiles (AT | SB | FB, later
 // hidden blocks 4w+j, j < 3), R0 / R1 = 2 x 4 raw tiles (product wave w writes R[step & 1][w], helper w reads it in the next
-// step), X = the residual stream as 4 fp32 tiles (for the LayerNorm statistics; between LayerNorms it carries the four partial
-// hop-2 linears).  Arithmetic, operand formats and summation structure are k_gat's (x3_common.h: exact three-way bf16 split, six
-// partial products, fp32 accumulation); the results agree with it to fp32 rounding (the MLP's four partial sums group the hidden
-// blocks differently), not bit for bit.
+// step), X = 4 fp32 tiles: the embedding's output (first LayerNorm), then the four partial hop-2 linears; ST = per-wave LayerNorm
+// statistics.  k_gat8<false>: arithmetic and operand formats are k_gat's (x3_common.h: exact three-way bf16 split, six partial
+// products, fp32 accumulation); it agrees with k_gat to fp32 rounding (the MLP's four partial sums group the hidden blocks
+// differently, the LayerNorm variance is combined from per-wave statistics), not bit for bit.  k_gat8<true> (default): the token-wise
+// products on four partial products, the J x J attention and the hop aggregations on fp16 planes.
 #include "fused_common.h"
 #include "fused_state.h"
 #include "x3_common.h"
@@ -84,7 +85,8 @@ constexpr int kBq = kA + 4 * kTileX3;                   // 12 operand tiles
 constexpr int kR = kBq + 12 * kTileX3;                  // R0 (4 raw tiles) | R1 (4 raw tiles)
 constexpr int kXo = kR + 8 * kTile;                     // 4 fp32 tiles
 constexpr int kDummy = kXo + 4 * kTile;                 // 4 x 1 KiB landing window of the L2 warm-up (never read)
-constexpr int kGat8LdsFloats = kDummy + 1024;           // 37 888 floats = 148 KiB
+constexpr int kStat = kDummy + 1024;                     // [4 helper waves][32 tokens][mean, M2] of the wave's 32 channels (LayerNorm statistics)
+constexpr int kGat8LdsFloats = kStat + 256;             // 149 KiB
 
 #ifdef GATOR_DIAG
 // diagnostic library only (python -m gator_amd.build --diag; GATOR_GAT_STAMPS=1): per role, block and step the cycles spent working
@@ -171,6 +173,40 @@ __device__ __forceinline__ f32x16 ln_own(const float* X, const f32x16& xw, const
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) { x[kb] = x[kb] - mean; x[kb] = x[kb] * x[kb]; }
     const float rstd = 1.0f / sqrtf(rsum128(x) * (1.0f / 128.0f) + 1e-5f);
+    return (xw - mean) * rstd * wv + bv;
+}
+
+// LayerNorm(128) inside the block loop without a second pass over the residual stream: the wave that updates its 32 channels of a
+// token leaves their (mean, sum of squared deviations) in LDS, and the four pairs of a token are combined exactly (Chan et al.):
+// M2 = sum M2_w + 32 sum (mean_w - mean)^2.  ln_own re-read all four tiles and reduced twice in a step the product waves wait through.
+__device__ __forceinline__ void tile_stats(const f32x16& xw, float* st_w, int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s += (xw[4 * q] + xw[4 * q + 1]) + (xw[4 * q + 2] + xw[4 * q + 3]);
+    s += xhalf(s);
+    const float m = s * (1.0f / 32.0f);
+    float p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        p[q] = 0.f;
+#pragma unroll
+        for (int r = 4 * q; r < 4 * q + 4; ++r) { const float d = xw[r] - m; p[q] += d * d; }
+    }
+    float m2 = (p[0] + p[1]) + (p[2] + p[3]);
+    m2 += xhalf(m2);
+    if (lane < 32) { st_w[2 * lane] = m; st_w[2 * lane + 1] = m2; }
+}
+__device__ __forceinline__ f32x16 ln_stats(const float* ST, const f32x16& xw, const f32x16& wv, const f32x16& bv, int lane) {
+    const int tok = lane & 31;
+    float m[4], q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { m[i] = ST[i * 64 + 2 * tok]; q[i] = ST[i * 64 + 2 * tok + 1]; }
+    const float mean = ((m[0] + m[1]) + (m[2] + m[3])) * 0.25f;
+    float dev = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float d = m[i] - mean; dev += d * d; }
+    const float m2 = ((q[0] + q[1]) + (q[2] + q[3])) + 32.0f * dev;
+    const float rstd = 1.0f / sqrtf(m2 * (1.0f / 128.0f) + 1e-5f);
     return (xw - mean) * rstd * wv + bv;
 }
 
@@ -646,10 +682,10 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         GAT8_BAR(10);
         // ---- step 11: residual
         xw += pick(R1w, lane, tl) + tl2;
-        store_block(X + w * kTile, lane, xw);
+        tile_stats(xw, lds + kStat + w * 64, lane);
         GAT8_BAR(11);
         // ---- step 12: Y2 = LN2(x)
-        st_opnd(A + w * kTileX3, lane, ln_own(X, xw, n2w, n2b, lane));
+        st_opnd(A + w * kTileX3, lane, ln_stats(lds + kStat, xw, n2w, n2b, lane));
         GAT8_BAR(12);
         // ---- steps 13-17: MLP hidden blocks 4w + j: bias, GELU, split (modules.py:188-196)
         f32x16 fb0 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 0), h), fb1 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 1), h);
@@ -721,7 +757,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         GAT8_BAR(20);
         c23 = pick(R1w, lane, c23);
         xw += c01 + c23;
-        store_block(X + w * kTile, lane, xw);
+        tile_stats(xw, lds + kStat + w * 64, lane);
         if (a.blk_tap && tok < J) {          // debug tap (off in timed runs): this wave's channel block of the block output
             float* dst = a.blk_tap + (((size_t)bi * a.tapB + b) * J + tok) * kC + 32 * w + 4 * h;
 #pragma unroll
@@ -735,7 +771,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         GAT8_BAR(21);
         // ---- step 22: Y = LN1(x) for the next block; after the last block LN -> GELU -> feat (GAT.py:148-150)
         {
-            f32x16 y = ln_own(X, xw, nw, nb, lane);
+            f32x16 y = ln_stats(lds + kStat, xw, nw, nb, lane);
             if (!last) {
                 st_opnd(A + w * kTileX3, lane, y);
             } else {
