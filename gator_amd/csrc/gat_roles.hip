@@ -499,6 +499,20 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
 #endif
         const Gat8Blk& kb = a.blk[bi];
         const float* vec = kb.vecs;
+        // L2 warm-up.  Between two launches of this kernel the rest of the forward moves ~1 GB, so the weights start in HBM; all
+        // workgroups of an XCD walk them in step, so every tile would be an HBM-latency miss for all of them at once (175 -> 195 us
+        // without it).  Each workgroup pulls its 1/n-th of the NEXT block's four streams into its XCD's L2 one block ahead, and this
+        // helper's share of that block's tables.  One dword per 128-byte line: a wave instruction touches 64 lines = 8 KiB and costs the
+        // issuing wave ~350 cycles, so the touches sit in the steps where the helper has slack against its product wave (2 and 18).
+        const bool warm = bi + 1 < kDepth && a.pf_loads > 0;
+        const float* dummy = lds + kDummy + w * 256;
+        const Gat8Blk& nx = a.blk[bi + 1 < kDepth ? bi + 1 : bi];
+        auto warm_weights = [&](int i0, int i1) {
+            const char* wsrc = reinterpret_cast<const char*>(a.wstream + ((size_t)w * kWaveTiles + (size_t)(bi + 1) * kBlkTiles) * kTileX3);
+            const int share = a.pf_loads * 8192, first = ((b >> 3) % a.pf_n) * share, lim = kBlkTiles * kTileX3 * 4 - 128;
+            for (int i = i0; i < i1; ++i)
+                glds4(reinterpret_cast<const float*>(wsrc + min(first + i * 8192 + lane * 128, lim)), dummy);
+        };
         // ---- step 1: constants of the attention (nothing to pick up yet)
         const f32x16 bq = load_chanvec_T(vec, V_QKVB + 32 * w, h), bk = load_chanvec_T(vec, V_QKVB + 128 + 32 * w, h);
         const float vb = vec[V_QKVB + 256 + 32 * w + tok];
@@ -506,6 +520,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         GAT8_BAR(1);
         // ---- step 2: q
         const f32x16 q = pick(R0w, lane, bq);
+        if (warm) warm_weights(0, (a.pf_loads + 1) / 2);
         GAT8_BAR(2);
         // ---- step 3: k; scores and softmax of heads 2w, 2w+1 (modules.py:121-133): S^T[key][query], query on the lane
         f32x16 sa = zero16(), sb = zero16();
@@ -722,23 +737,9 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         GAT8_BAR(17);
         // ---- steps 18-21: the four partial sums of fc2, residual
         f32x16 c01 = pick(R0w, lane, bfc2);
-        // L2 warm-up (the helpers idle through the fc2 steps).  Between two launches of this kernel the rest of the forward moves
-        // ~1 GB, so the weights start in HBM; all workgroups of an XCD walk them in step, so every tile would be an HBM-latency
-        // miss for all of them at once (measured on the skeleton: 120 -> 140 us with cold weights).  Each workgroup pulls its
-        // 1/n-th of the NEXT block's four streams into its XCD's L2 one block ahead, and this helper's share of that block's tables.
-        const bool warm = bi + 1 < kDepth && a.pf_loads > 0;
-        const float* dummy = lds + kDummy + w * 256;
-        const Gat8Blk& nx = a.blk[bi + 1 < kDepth ? bi + 1 : bi];
-        if (warm) {
-            // one dword per 128-byte line: a wave instruction touches 64 lines = 8 KiB (an LDS-DMA instruction costs the issuing wave
-            // 60-180 cycles whatever it moves, so 1 KiB contiguous copies would eat the idle steps: 30 instructions against 4)
-            const char* wsrc = reinterpret_cast<const char*>(a.wstream + ((size_t)w * kWaveTiles + (size_t)(bi + 1) * kBlkTiles) * kTileX3);
-            const int share = a.pf_loads * 8192, first = ((b >> 3) % a.pf_n) * share, lim = kBlkTiles * kTileX3 * 4 - 128;
-            for (int i = 0; i < a.pf_loads; ++i)
-                glds4(reinterpret_cast<const float*>(wsrc + min(first + i * 8192 + lane * 128, lim)), dummy);
-        }
         GAT8_BAR(18);
         c01 = pick(R1w, lane, c01);
+        if (warm) warm_weights((a.pf_loads + 1) / 2, a.pf_loads);
         if (warm) {                                  // this helper's share of the next block's tables and vectors, one lane per line
             const int l32 = lane & 31;
             glds4(h == 0 ? nx.mdT + (size_t)w * kTile + l32 * 32 : nx.mc + (size_t)w * kTile + l32 * 32, dummy);
