@@ -77,7 +77,12 @@ int gator_create(const gator_tensor* tensors, int32_t n_tensors, const gator_con
 int gator_destroy(gator_ctx* ctx);
 
 /* Replaces: GATOR.forward (lib/models/GATOR.py:16-22).
- *   pose2d [B,J,2] f32 device, contiguous  ->  verts [B,6890,3] f32 (metres), pose3d [B,J,3] f32 (mm). */
+ *   pose2d [B,J,2] f32 device, contiguous  ->  verts [B,6890,3] f32 (metres), pose3d [B,J,3] f32 (mm).
+ * fp32 in, fp32 out, fp32 accumulation; within 1e-3 mm of the fp64 evaluation of the reference (tests/).  The products themselves run
+ * on the 16-bit MFMA with split operands: weights are always carried exactly (three planes); by default activations, the attention
+ * operands and the vertex regressor's operands are rounded to 22 bits (two fp16 planes), which costs less than the fp32 rounding noise
+ * the reference forward has itself.  Environment switches read at gator_create select the forms without any rounded operand
+ * (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 GATOR_GAT_TILED_H4=0) or the fp32-input MFMA (=0). */
 int gator_forward_f32(gator_ctx* ctx, const float* pose2d, int32_t batch, float* verts, float* pose3d, void* stream);
 
 /* BASELINE config 3: same forward with the vertex regressor (upsample_conv, lib/models/MDR.py:122,167-168) on bf16 MFMA
