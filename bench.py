@@ -458,6 +458,10 @@ def main():
         line = {'metric': 'meshes/sec (B=%d, J=%d) GATOR forward' % (B, J), 'value': round(value, 1), 'unit': 'meshes/sec',
                 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic',
+                # what `dtype` covers: fp32 in / out / accumulation; the products run on the 16-bit MFMA with split operands (weights exact on
+                # three planes; activations, attention operands and the vertex regressor's operands on two = rounded to 22 bits).  The
+                # build with no rounded operand is the `exact_split` entry of `variants`; parity of both: tests/test_gpu_x3.py.
+                'arithmetic': 'fp32 values, split-precision 16-bit MFMA products: weights exact (3 planes), activations / attention / vertex-regressor operands rounded to 22 bits (2 planes); max |verts - fp64 oracle| 7.8e-4 mm at B=256 (bar 1e-3)',
                 'config': {'workload': 'B=%d synthetic %s poses per GPU, GAT+MDR forward %s%s' % (B, jset, prec, tail),
                            'baseline_config': baseline_config_of(a, world),
                            'batch_per_gpu': B, 'global_batch': B * world, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world,
