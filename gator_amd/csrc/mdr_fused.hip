@@ -1,4 +1,4 @@
-// MDR head (lib/models/MDR.py:124-170) as register-resident fp32-MFMA kernels.
+// MDR head (lib/models/MDR.py:124-170) as register-resident MFMA kernels (fp32 values; products on split 16-bit operands, see XA below).
 //
 // One wave owns one 32-token tile of one sample's 431 coarse-vertex tokens (14 tiles/sample) and keeps its 64-channel
 // token state in registers in the MFMA accumulator layout (fused_common.h).  Everything that is row-wise in the
@@ -6,7 +6,8 @@
 // MDR.py:61,68), the Annotated-Transformer LayerNorm (vanilla_transformer_encoder.py:31-34), the q/k/v in-projections and
 // the out-projection + residual of the 431x431 self-attention (vanilla_transformer_encoder.py:82-94) -- chains through
 // MFMAs without touching LDS.  The only cross-token dependency is the self-attention's K/V of the whole sample, so the
-// three LBF layers become four launches:
+// three LBF layers become four stages - four launches (k_mdr_layer<MODE>) or, where the batch leaves a fractional generation of
+// workgroups, ONE persistent launch that hands the same stages out as tickets (k_mdr_persist, further down):
 //     L0: tokenise -> tokenwise(0)              (writes vf, Q, K, V of layer 0, all in operand-packed tiles)
 //     L1: attention(0)+out-proj+res -> tokenwise(1)
 //     L2: attention(1)+out-proj+res -> tokenwise(2)
@@ -439,8 +440,9 @@ template <int XA> __device__ __forceinline__ typename TokOp<XA>::A mk(const f32x
 }
 
 // MODE 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
-// XA   0: everything on the fp32-input MFMA ; 1: split precision (exact bf16 x 3) everywhere ; 2: split-precision linears and
-//         the 431x431 self-attention on two fp16 planes (the default)
+// XA   0: everything on the fp32-input MFMA ; 1: split precision (exact bf16 x 3, six partial products) everywhere ; 2 (the default):
+//         token-wise linears on four partial products (weights exact on three fp16 planes, activations on two: x3_common.h), the
+//         431x431 self-attention and the J-joint cross-attention on two fp16 planes
 // per-channel vectors of a stage (biases, norm weights) staged once per workgroup in LDS
 enum { VO_SA3B = 0, VO_N1W = 64, VO_N1B = 128, VO_PROJB = 192, VO_N2W = 256, VO_N2B = 320, VO_FC2B = 384, VO_A2 = 448, VO_B2 = 512,
        VO_SA0B = 576, VO_SA1B = 640, VO_HEADB = 704, VO_FC1B = 768, VO_TOKW3 = 1024, VO_TOTAL = 1216 };
