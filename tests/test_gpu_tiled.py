@@ -38,8 +38,10 @@ def test_tiled_encoder_vs_oracle(monkeypatch, name, B):
     assert e <= 1e-3 and ep <= 1e-3
 
 
+@pytest.mark.parametrize('h4', ['1', '0'])
 @pytest.mark.parametrize('name', ['h36m17_bn', 'coco19_alpha'])
-def test_tiled_block_taps_and_feat_match_reference(monkeypatch, name):
+def test_tiled_block_taps_and_feat_match_reference(monkeypatch, name, h4):
+    monkeypatch.setenv('GATOR_GAT_TILED_H4', h4)      # four partial products (default) | the exact six
     z, m = _model(monkeypatch, name, '1')
     B, J = z['pose2d'].shape[:2]
     x = torch.from_numpy(z['pose2d']).cuda()
