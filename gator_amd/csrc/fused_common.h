@@ -31,7 +31,19 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }   // lane <-> lane^32
+// lane <-> lane ^ 32 through gfx950's v_permlane32_swap (one VALU instruction; __shfl_xor is a ds_bpermute: an LDS round trip the
+// wave waits out, and these exchanges sit on the critical path of every row reduction - 28 of them per attention head).
+// The swap returns, in every lane l, the values held by lane l & 31 and by lane 32 + (l & 31).
+struct HalfPair { float lo, hi; };
+__device__ __forceinline__ HalfPair xhalves(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return HalfPair{__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ float xhalf(float v) {
+    const HalfPair q = xhalves(v);
+    return (threadIdx.x & 32) ? q.lo : q.hi;
+}
 
 // one packed (nb,kb) weight tile = 4 float4 per lane
 struct WTile { f32x4 g[4]; };
