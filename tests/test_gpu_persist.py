@@ -59,3 +59,26 @@ def test_persistent_stage_entry_point_and_changing_batches(monkeypatch):
         x = torch.from_numpy(synthetic.synthetic_pose2d(B, 17, seed=B)).cuda()
         a, b = m(x), m0(x)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), B
+
+
+@pytest.mark.timeout(300)
+def test_persistent_launch_survives_random_batch_sizes(monkeypatch):
+    """400 back-to-back forwards with the persistent launch forced on and batch sizes drawn from 1..699 (every queue shape: empty
+    XCD queues, ragged last tickets, counters re-zeroed by the joint-token kernel for a different B each time).  A tripped poll
+    budget would surface as NaN vertices (k_mdr_head poisons its output), a broken dependency as a mismatch with the four launches."""
+    monkeypatch.setenv('GATOR_MDR_PERSIST', '1')
+    z, m = build_model('h36m17_bn', 'fused')
+    monkeypatch.setenv('GATOR_MDR_PERSIST', '0')
+    z0, m0 = build_model('h36m17_bn', 'fused')
+    g = torch.Generator().manual_seed(0)
+    xs = {}
+    for it in range(400):
+        B = int(torch.randint(1, 700, (1,), generator=g))
+        if B not in xs:
+            xs[B] = torch.from_numpy(synthetic.synthetic_pose2d(B, 17, seed=B)).cuda()
+        v, p = m(xs[B])
+        if it % 40 == 0:
+            v0, p0 = m0(xs[B])
+            assert torch.isfinite(v).all() and torch.equal(v, v0) and torch.equal(p, p0), (it, B)
+    torch.cuda.synchronize()
+    assert torch.isfinite(v).all()
