@@ -17,16 +17,20 @@ both sides and reduced with MAX over ranks; the line reports the MEDIAN block (`
 
 roofline  : the dominant kernel of the forward (largest share of device time), timed live with HIP events recorded by the
             library on the launch stream (gator_profile_*); algorithmic (fp32) FLOPs per stage from SURVEY Appendix D.
-            `peak` is the MFMA peak of the pipe that kernel computes on: the fused kernels run their products on the bf16
-            MFMA with every fp32 operand split exactly into three bf16 planes and six partial products per fp32 product
-            (x3_common.h), so their ceiling is the dense bf16 peak / 6 = 416.7 TFLOP/s of fp32-equivalent work; a stage
-            switched back to the fp32-input MFMA (GATOR_*_X3=0) is priced against 157.3 TFLOP/s.
+            `peak` is the ceiling of the arithmetic that kernel EXECUTES: every product runs on the 16-bit MFMA (2.5 PFLOP/s dense)
+            from split fp32 operands (x3_common.h) -- token-wise linears on four partial products (weights exact on three fp16
+            planes, activations rounded to two), attention cores and the vertex regressor on three (both operands on two planes) --
+            so a stage's ceiling is its FLOPs / sum(part_i x products_i / 2500) (STAGE_PRODUCTS below; 714 TFLOP/s of fp32-equivalent
+            work for the MDR layers); a stage switched to the exact three-plane bf16 split (six products) is priced against 416.7, one
+            switched back to the fp32-input MFMA (GATOR_*_X3=0) against 157.3 TFLOP/s.
             `traffic_ratio` = HBM-side bytes of the WHOLE forward per mesh (committed PMC digest of this command: FETCH_SIZE x 2 +
             WRITE_SIZE over every launch of a step) / the 83 020 compulsory bytes of SURVEY 8(d); `frac_of_dense_16bit_peak_2500` =
             executed MFMA FLOP of the dominant kernel (PMC instruction counts) / live duration / 2.5 PFLOP/s.
 variants   : (N = 1) the same workload in the same process with the library's A/B switches: no rounded operand anywhere
             (GATOR_MDR_X3=1), every product on the fp32-input MFMA, the previous encoder kernel; and the headline re-measured with
             the variants' protocol.  clocks: sclk / mclk levels and power cap from sysfs.
+parity     : (N = 1, with the cpu_baseline leg) max |verts - fp64 oracle| in mm of the first 32 samples of the TIMED batch, measured
+            after the timed region; the statistical margin over >= 16k samples is tests/error_budget.py -> profiles/r04_error_budget.*.
 --config   : BASELINE.json presets (2: B=256 J=17 fp32; 3: B=2048 J=19 bf16; 4: 1024 per GPU + all-gather, 8 GPUs = B 8192; 5: evaluation
             mode, all-reduce only); `config.baseline_config` names the BASELINE config a run is.
 cpu_baseline: the oracle (torch-CPU restatement of the reference forward, kind "port") timed on this box's host cores with
@@ -65,8 +69,9 @@ _VF, _QKV = 14 * 2 * 4096, 3 * 14 * 2 * 4096          # Q/K/V as two fp16 planes
 STAGE_BYTES = {'mdr_layer0': _VF + _QKV, 'mdr_layer': 2 * (_VF + _QKV), 'mdr_attn_head': _VF + _QKV + 431 * 32 * 4 + 431 * 64 * 4,
                'mdr_layers': 6 * (_VF + _QKV) + 431 * 32 * 4 + 431 * 64 * 4,
                'upsample': 3 * 431 * 2 * 3 + 6890 * 3 * 4, 'gat': 136 + 17 * 128 * 4 + 204 + 12 * 4096}
-STAGE_KERNEL = {'gat': 'k_gat', 'mdr_layer0': 'k_mdr_layer<0,', 'mdr_layer': 'k_mdr_layer<1,',
-                'mdr_attn_head': 'k_mdr_layer<2,', 'mdr_layers': 'k_mdr_persist', 'upsample': 'k_upsample_x'}
+# kernel of a profiled stage in the PMC digest: (name prefix, characters that may follow it) -- 'k_gat8<...' but not k_gat_joint / k_gat_lifter
+STAGE_KERNEL = {'gat': ('k_gat8', '<'), 'mdr_layer0': ('k_mdr_layer<0,', None), 'mdr_layer': ('k_mdr_layer<1,', None),
+                'mdr_attn_head': ('k_mdr_layer<2,', None), 'mdr_layers': ('k_mdr_persist', '<'), 'upsample': ('k_upsample_x2', '<(')}
 # BASELINE.json `configs`, 1-based as VERDICT.md numbers them (config 1 is the reference's own CPU demo): per-GPU presets
 BASELINE_CONFIGS = {
     2: dict(batch=256, joints=17, precision='f32', mode='gather', gpus=1,
@@ -163,8 +168,10 @@ STAGE_PRODUCTS = {'mdr_layer0': [(_CA, 3), (48.7 - _CA, 4)],
                   'mdr_attn_head': [(_SA, 3), (51.4 - _SA, 4)],
                   'mdr_layers': [(3 * _SA + 3 * _CA, 3), (298.5 - 3 * _SA - 3 * _CA, 4)],
                   'upsample': [(53.45, 3)],
-                  # k_gat8 (B < 1024): the 16 token-wise linears per block on 4 products, the J x J operators on the fp32-input MFMA (= 16)
-                  'gat': [(54.4, 4), (56.66 - 54.4, 16)]}
+                  # k_gat8 (B <= 1024): the 16 token-wise linears per block on 4 products; of the J x J operators the attention
+                  # (QK^T + PV, 0.89 MFLOP) on two fp16 planes = 3 products, the hop aggregations (0.50) against exact 0/1 fp16 masks = 2,
+                  # the MGCN adjacency product (0.89) on the fp32-input MFMA (= 16 in units of the 16-bit rate)
+                  'gat': [(54.4, 4), (0.89, 3), (0.50, 2), (56.66 - 54.4 - 0.89 - 0.50, 16)]}
 PEAK_X2_TFLOPS = round(PEAK_BF16_TFLOPS / 3, 1)
 
 
@@ -216,7 +223,7 @@ def pmc_digest(B):
     round first; None for other batch sizes."""
     if B != 256:
         return None, None
-    for name in ('r03_pmc_summary_B256.json', 'r02_pmc_summary_B256.json', 'r01_pmc_summary_B256.json'):
+    for name in ('r04_pmc_summary_B256.json', 'r03_pmc_summary_B256.json', 'r02_pmc_summary_B256.json', 'r01_pmc_summary_B256.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             return json.load(open(path)), name
@@ -224,9 +231,10 @@ def pmc_digest(B):
 
 
 def pmc_row(rows, stage):
-    want = STAGE_KERNEL.get(stage, '')
+    want, follow = STAGE_KERNEL.get(stage, ('', None))
     for row in rows or []:
-        if want and row['kernel'].startswith(want):
+        k = row['kernel']
+        if want and k.startswith(want) and (follow is None or len(k) == len(want) or k[len(want)] in follow):
             return row
     return None
 
@@ -328,6 +336,24 @@ def cpu_baseline(model, base, alpha, J):
             'per_batch': {str(k): round(v, 1) for k, v in per_b.items()}}
 
 
+def parity_check(model, base, alpha, J, x, verts, n=32):
+    """The checker leg beside cpu_baseline (never timed, never the product path): the fp64 oracle on the first `n` samples of the
+    batch that was timed, against the vertices the timed forward wrote for them."""
+    import numpy as np
+    import torch
+    from gator_amd import synthetic
+    from oracle import gator_oracle as go
+    n = min(n, x.shape[0])
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    c = go.Consts(J, synthetic.model_j_regressor(J), base, alpha)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref, _ = go.gator_forward(sd, c, x[:n].cpu(), torch.float64)
+    err = np.abs(verts[:n].cpu().numpy().astype(np.float64) - ref.numpy()) * 1e3
+    return {'max_err_mm': float('%.3e' % err.max()), 'rms_err_mm': float('%.3e' % np.sqrt((err ** 2).mean())), 'samples': int(n),
+            'coordinates': int(err.size), 'against': 'fp64 oracle (torch-CPU restatement of the reference forward), first %d samples of the timed batch' % n,
+            'bar_mm': 1e-3}
+
+
 def main():
     a = parse()
     in_group = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
@@ -408,6 +434,8 @@ def main():
                 'collective': 'all_gather [%d,6890,3]+[%d,%d,3] f32' % (B * world, B * world, J) if a.mode == 'gather'
                 else 'all_reduce of 4 error sums',
                 'bytes_per_rank': int(B * (6890 * 3 + J * 3) * 4) if a.mode == 'gather' else 32}
+        # what the overlap needs from xGMI: every rank receives the other ranks' shards within one step's compute time
+        comm['ingress_GBps_needed_to_hide'] = round(comm['bytes_per_rank'] * (world - 1) / max(c_ms, 1e-9) / 1e6, 1)
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = B * world * a.steps / dt
@@ -445,7 +473,8 @@ def main():
                         'kernel_traffic_over_designed': round(traffic / (designed * B), 3) if (traffic and designed) else None,
                         'pmc_digest': digest,
                         'avg_launch_ms': round(avg_s * 1e3, 4), 'pipe': pipe,
-                        'stages_ms': {k: round(v[0] / v[1], 4) for k, v in prof.items()}}
+                        'stages_ms': {k: round(v[0] / v[1], 4) for k, v in prof.items()},
+                        'stages_note': 'HIP-event brackets on every 4th timed step; a bracketed step runs ~2 % slower, so the stages sum to slightly more than ms_per_step'}
         if roof is None:   # no per-kernel events available (bring-up path): price the whole forward
             roof = {'bound': 'mfma', 'kernel': 'whole forward', 'achieved': round(per_gpu_tf, 2), 'peak': PEAK_F32_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(per_gpu_tf / PEAK_F32_TFLOPS, 4), 'traffic': None}
@@ -461,7 +490,7 @@ def main():
                 # what `dtype` covers: fp32 in / out / accumulation; the products run on the 16-bit MFMA with split operands (weights exact on
                 # three planes; activations, attention operands and the vertex regressor's operands on two = rounded to 22 bits).  The
                 # build with no rounded operand is the `exact_split` entry of `variants`; parity of both: tests/test_gpu_x3.py.
-                'arithmetic': 'fp32 values, split-precision 16-bit MFMA products: weights exact (3 planes), activations / attention / vertex-regressor operands rounded to 22 bits (2 planes); max |verts - fp64 oracle| 7.8e-4 mm at B=256 (bar 1e-3)',
+                'arithmetic': 'fp32 values, split-precision 16-bit MFMA products: weights exact (3 planes), activations / attention / vertex-regressor operands rounded to 22 bits (2 planes); measured error of this run: `parity`',
                 'config': {'workload': 'B=%d synthetic %s poses per GPU, GAT+MDR forward %s%s' % (B, jset, prec, tail),
                            'baseline_config': baseline_config_of(a, world),
                            'batch_per_gpu': B, 'global_batch': B * world, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world,
@@ -520,6 +549,8 @@ def main():
             d2 = sorted(block(lambda: m2(x), a.steps)[0] for _ in range(5))[2]
             line['subbatch_streams_2'] = {'value': round(B * a.steps / d2, 1), 'ms_per_step': round(d2 / a.steps * 1e3, 4)}
         if world == 1 and not a.no_cpu_baseline:
+            if a.mode == 'gather' and a.precision == 'f32':
+                line['parity'] = parity_check(model, base, alpha, J, x, out[0])
             line['cpu_baseline'] = cpu_baseline(model, base, alpha, J)
         result = json.dumps(line)
     else:

@@ -35,6 +35,7 @@ _P, _I, _L = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
 SIGNATURES = {
     'gator_create': (_I, [ctypes.POINTER(GatorTensor), _I, ctypes.POINTER(GatorConfig), ctypes.POINTER(_P)]),
     'gator_destroy': (_I, [_P]),
+    'gator_device_status': (_I, [_P, _I]),
     'gator_forward_f32': (_I, [_P, _P, _I, _P, _P, _P]),
     'gator_forward_bf16': (_I, [_P, _P, _I, _P, _P, _P]),
     'gator_upsample_bf16': (_I, [_P, _P, _I, _P, _P]),

@@ -193,6 +193,7 @@ extern "C" int gator_destroy(gator_ctx* c) {
     prof_clear(c, true);
     if (c->ws) (void)hipFree(c->ws);
     if (c->arena) (void)hipFree(c->arena);
+    if (c->status_host) (void)hipHostFree(c->status_host);
     delete c;
     return GATOR_OK;
 }
@@ -214,6 +215,17 @@ extern "C" int gator_create(const gator_tensor* tensors, int32_t n, const gator_
     c->prefix_gat = both ? "pose_lifter." : "";
     c->prefix_mdr = both ? "pose2mesh." : "";
     (void)hipGetDevice(&c->device);
+    {   // sticky device status word: pinned, device-visible host memory (no synchronisation needed to read it)
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            if (hp) (void)hipHostFree(hp);
+            delete c;
+            return fail(GATOR_ENOMEM, "gator_create: hipHostMalloc of the status word failed");
+        }
+        c->status_host = (unsigned*)hp;
+        c->status_dev = (unsigned*)dp;
+        *c->status_host = 0u;
+    }
     // arena: one device allocation holding a private copy of every tensor (256-B aligned), + folded constants
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
@@ -265,8 +277,31 @@ extern "C" int gator_create(const gator_tensor* tensors, int32_t n, const gator_
     return GATOR_OK;
 }
 
+// What a kernel left in the ctx's sticky status word (an EARLIER call's failure: nothing here synchronises).  Reported once, then cleared.
+static int take_device_status(gator_ctx* c, const char* fn) {
+    const unsigned st = c->status_host ? __atomic_exchange_n(c->status_host, 0u, __ATOMIC_RELAXED) : 0u;
+    if (st == DEV_PERSIST_INCOMPLETE)
+        return fail(GATOR_EDEVICE, "%s: an earlier forward on this ctx did not complete its persistent MDR launch (a sample's stage tiles were never "
+                                   "finished: hang guard or an unserved queue); its vertices were set to NaN.  GATOR_MDR_PERSIST=0 selects the four-launch form", fn);
+    if (st == DEV_NONFINITE)
+        return fail(GATOR_EDEVICE, "%s: an earlier forward on this ctx produced non-finite or out-of-range coarse vertices (|vert431| must stay below 4094 m, "
+                                   "and every activation that feeds a token-wise linear below 4094: they travel as fp16 planes of 16 x value).  "
+                                   "GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 GATOR_GAT_TILED_H4=0 select the bf16 forms without that range limit", fn);
+    return GATOR_OK;
+}
+
+extern "C" int gator_device_status(gator_ctx* c, int32_t sync) {
+    if (!c) return fail(GATOR_EINVAL, "gator_device_status: null ctx");
+    if (sync) {
+        GATOR_HIP_CHECK(hipSetDevice(c->device));
+        GATOR_HIP_CHECK(hipDeviceSynchronize());
+    }
+    return take_device_status(c, "gator_device_status");
+}
+
 static int check_fwd(gator_ctx* c, const void* a, const void* b, int B, const char* fn) {
     if (!c || !a || !b || B <= 0) return fail(GATOR_EINVAL, "%s: null pointer or batch <= 0", fn);
+    if (int st = take_device_status(c, fn)) return st;
     c->profiling = c->prof_stride > 0 && (c->prof_calls++ % c->prof_stride) == 0;
     GATOR_HIP_CHECK(hipSetDevice(c->device));
     c->clear_taps();        // a tap never outlives the forward that produced it (workspaces may be re-allocated below)

@@ -35,7 +35,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
                  o_q = take(9 * tiles / 2), o_k = take(9 * tiles / 2), o_v = take(9 * tiles / 2) /* THREE tile sets each (k_mdr_persist writes every set once per forward); q/k/v sized for X3 tiles (1.5x) */, o_jkv = take((size_t)cap * 12 * kTile),
                  o_hf = take((size_t)cap * kV * 32), o_lbf = take((size_t)cap * kV * kE), o_feat = take((size_t)cap * J * kC),
                  o_xout = take((size_t)cap * J * 3), o_pc = take((size_t)cap * J * 133),
-                 o_vcp3 = take(std::max(upsample_x3_vcp_elems(cap), upsample_x2_vcp_elems(cap)) / 2), o_lpart = take(gat_tail_part_floats(cap, J)), o_ctr = take(16 + (size_t)3 * cap);
+                 o_vcp3 = take(std::max(upsample_x3_vcp_elems(cap), upsample_x2_vcp_elems(cap)) / 2), o_lpart = take(gat_tail_part_floats(cap, J)), o_ctr = take(32 + (size_t)4 * cap);
     GATOR_HIP_CHECK(hipMalloc(&f->ws, n * sizeof(float)));
     GATOR_HIP_CHECK(hipMemset(f->ws, 0, n * sizeof(float)));
     GATOR_HIP_CHECK(hipDeviceSynchronize());      // the memset runs on the null stream; a non-blocking stream would not wait for it

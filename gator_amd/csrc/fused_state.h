@@ -36,7 +36,7 @@ struct FusedWs {
     float *feat = nullptr, *xout = nullptr, *pc = nullptr;
     float *lpart = nullptr;             // [MT][J][2][kTile] lifter partial tiles (gat_tail.hip)
     bool mdr_ctr_clean = false;         // the joint-token kernel queued before launch_mdr has zeroed mdr_ctr for it
-    unsigned* mdr_ctr = nullptr;        // k_mdr_persist: [8] tickets per XCD, [8] flags, [3][cap] tiles done per (stage, sample)
+    unsigned* mdr_ctr = nullptr;        // k_mdr_persist: [8] tickets per queue, [8] flags, [8] queue owners, [8] spare, [4][cap] tiles done per (stage, sample)
     void* vcp16 = nullptr;              // bf16 packed vert431 for the bf16 vertex GEMM (cap-sized)
     int vcp16_cap = 0;
 };

@@ -58,6 +58,9 @@ struct Weights {
 enum TapId { TAP_FEAT = 0, TAP_MDR_LBF2, TAP_VERT431, TAP_GAT_BLOCKS, TAP_COUNT };
 struct Tap { const float* p = nullptr; int64_t n = 0; };
 
+// Sticky device status word of a ctx (host-mapped memory written by kernels, read by the host at the next API call / gator_device_status)
+enum DeviceStatus { DEV_OK = 0, DEV_PERSIST_INCOMPLETE = 1, DEV_NONFINITE = 2 };
+
 struct FusedState;   // packed weights + workspace of the fused path (fused_*.hip)
 struct ProfRec { const char* name; void* start; void* stop; };
 
@@ -88,6 +91,8 @@ struct gator_ctx {
     void clear_taps() { for (auto& t : taps) t = gator::Tap{}; }
     void set_tap(int id, const float* p, int64_t n) { taps[id].p = p; taps[id].n = n; }
     gator::FusedState* fused = nullptr;
+    unsigned* status_host = nullptr;   // sticky device status (gator::DeviceStatus): pinned host word the kernels write ...
+    unsigned* status_dev = nullptr;    // ... through this device pointer
     // measurement hook (gator_profile_*): (stage name, start event, stop event) per launch
     bool profiling = false;       // StageTimer records only when set; forwards toggle it from prof_stride
     int prof_stride = 0, prof_calls = 0;   // record every prof_stride-th forward (0 = off)

@@ -777,7 +777,14 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
 //   * tickets are handed out in dependency order and a workgroup holds a ticket only while it runs, so every wait is for a unit
 //     that some running workgroup already owns: no deadlock whatever the residency.  A poll budget (~6 s) turns a would-be hang (a bug)
 //     into a flag in ctr[kCtrError] and garbage output instead of a dead GPU.
-constexpr int kCtrError = 8, kCtrDone = 16;       // ctr: [0..7] tickets per XCD, [8] error flag, [16 + stage * B + b] tiles done
+// Which XCD serves a queue is decided at run time: a workgroup CLAIMS a queue (compare-and-swap on ctr[kCtrOwner + q]) before it
+// takes tickets from it, its own XCD's queue first.  Normally every queue is claimed by its own XCD within the first microsecond.  If
+// an XCD received no workgroup at all (a CU mask, reserved CUs, a partitioned device), its queue is still unowned when the others
+// have drained theirs, and the first XCD to get there adopts it -- ALL of it, so that a sample's tiles are still produced and
+// consumed through ONE L2 (the hand-off below has no cache maintenance and relies on exactly that).  Workgroups of any other XCD
+// leave an owned queue alone.  No sample is left uncomputed whatever the placement; only locality depends on it.
+constexpr int kCtrError = 8, kCtrOwner = 16, kCtrDone = 32;   // ctr: [0..7] tickets per queue, [8] error flag, [16..23] owner (1 + XCD) per queue,
+                                                              //      [32 + stage * B + b] tiles done, stage 0..3
 struct MdrPersistArgs {
     MdrArgs st[4];
     unsigned* ctr;
@@ -789,78 +796,88 @@ __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) 
     __shared__ int s_unit;
     const int B = p.st[0].B, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned xcc;                                                // the XCD this workgroup REALLY runs on picks its queue
+    unsigned xcc;                                                // the XCD this workgroup REALLY runs on
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const int xcd = (int)(xcc & 7u);
-    const int nb = xcd < B ? (B - xcd + 7) >> 3 : 0;            // samples of this XCD: xcd, xcd + 8, ...
-    const int ntile = nb * kVT, units = (ntile + 3) >> 2;       // per stage
-    if (units == 0) return;
-    auto ticket = [&]() {
-        __syncthreads();                                        // everyone is done with s_unit (and, at a stage change, with VT)
-        if (threadIdx.x == 0) s_unit = (int)atomicAdd(p.ctr + xcd, 1u);
-        __syncthreads();
-        return __builtin_amdgcn_readfirstlane(s_unit);          // a scalar: stage, tile and sample ids stay out of the VGPRs
-    };
     int staged = -1;                                            // the stage whose channel vectors are in VT
-    // one ticket: (stage the channel vectors,) wait for the sample's previous stage, run the tile, publish it
-    auto run = [&](auto mode, int stage, int unit) {
-        constexpr int MODE = decltype(mode)::value;
-        // the stage's arguments (p.st[stage]) through a pointer into the kernel-argument segment that the optimiser cannot see
-        // through: otherwise every argument load of the body is loop-invariant, hoisted in front of the ticket loop and held in
-        // SGPRs across it (106 SGPRs, spills into VGPRs, scratch)
-        typedef const __attribute__((address_space(4))) MdrArgs* KArgPtr;
-        typedef const __attribute__((address_space(4))) char* KBytePtr;
-        unsigned aoff = (unsigned)offsetof(MdrPersistArgs, st) + (unsigned)__builtin_amdgcn_readfirstlane(stage) * (unsigned)sizeof(MdrArgs);
-        asm volatile("" : "+s"(aoff));
-        KArgPtr ap = (KArgPtr)((KBytePtr)__builtin_amdgcn_kernarg_segment_ptr() + aoff);
-        const MdrArgs& a = *(const MdrArgs*)ap;
-        const int lt = 4 * (unit - stage * units) + wave;
-        const bool live = lt < ntile;                           // (wave-uniform) a ticket's last waves may have nothing left
-        const int smp = xcd + 8 * (lt / kVT), id = smp * kVT + lt % kVT;
-        // the completion count of the sample's previous stage is requested FIRST: its L2 round trip (1 - 2 us under load, once per
-        // tile) hides behind the staging below instead of standing in front of the tile
-        const unsigned* d = p.ctr + kCtrDone + (size_t)(MODE > 0 ? stage - 1 : 0) * B + smp;
-        unsigned seen = kVT;
-        if (MODE > 0 && live && lane == 0) seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (staged != stage) {                                  // tickets come in stage order: at most three times per workgroup
-            mdr_stage_vectors<MODE, XA>(a, VT);
-            staged = stage;
+#pragma unroll 1
+    for (int qi = 0; qi < 8; ++qi) {
+        const int q = (xcd + qi) & 7;                           // queue q: samples q, q + 8, ...; own XCD's first
+        const int nb = q < B ? (B - q + 7) >> 3 : 0;
+        const int ntile = nb * kVT, units = (ntile + 3) >> 2;   // per stage
+        if (units == 0) continue;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned me = 1u + (unsigned)xcd, prev = atomicCAS(p.ctr + kCtrOwner + q, 0u, me);
+            s_unit = (prev == 0u || prev == me) ? 1 : 0;
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(s_unit) == 0) continue;      // another XCD serves this queue
+        auto ticket = [&]() {
+            __syncthreads();                                    // everyone is done with s_unit (and, at a stage change, with VT)
+            if (threadIdx.x == 0) s_unit = (int)atomicAdd(p.ctr + q, 1u);
             __syncthreads();
-        }
-        if (!live) return;
-        if (MODE > 0) {
-            if (lane == 0) {
-                int budget = 1 << 24;                           // ~6 s of polling
-                while (seen < (unsigned)kVT && --budget > 0) {
-                    __builtin_amdgcn_s_sleep(8);
-                    seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (budget <= 0) atomicExch(p.ctr + kCtrError, 1u + stage);
+            return __builtin_amdgcn_readfirstlane(s_unit);      // a scalar: stage, tile and sample ids stay out of the VGPRs
+        };
+        // one ticket: (stage the channel vectors,) wait for the sample's previous stage, run the tile, publish it
+        auto run = [&](auto mode, int stage, int unit) {
+            constexpr int MODE = decltype(mode)::value;
+            // the stage's arguments (p.st[stage]) through a pointer into the kernel-argument segment that the optimiser cannot see
+            // through: otherwise every argument load of the body is loop-invariant, hoisted in front of the ticket loop and held in
+            // SGPRs across it (106 SGPRs, spills into VGPRs, scratch)
+            typedef const __attribute__((address_space(4))) MdrArgs* KArgPtr;
+            typedef const __attribute__((address_space(4))) char* KBytePtr;
+            unsigned aoff = (unsigned)offsetof(MdrPersistArgs, st) + (unsigned)__builtin_amdgcn_readfirstlane(stage) * (unsigned)sizeof(MdrArgs);
+            asm volatile("" : "+s"(aoff));
+            KArgPtr ap = (KArgPtr)((KBytePtr)__builtin_amdgcn_kernarg_segment_ptr() + aoff);
+            const MdrArgs& a = *(const MdrArgs*)ap;
+            const int lt = 4 * (unit - stage * units) + wave;
+            const bool live = lt < ntile;                       // (wave-uniform) a ticket's last waves may have nothing left
+            const int smp = q + 8 * (lt / kVT), id = smp * kVT + lt % kVT;
+            // the completion count of the sample's previous stage is requested FIRST: its L2 round trip (1 - 2 us under load, once per
+            // tile) hides behind the staging below instead of standing in front of the tile
+            const unsigned* d = p.ctr + kCtrDone + (size_t)(MODE > 0 ? stage - 1 : 0) * B + smp;
+            unsigned seen = kVT;
+            if (MODE > 0 && live && lane == 0) seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (staged != stage) {                              // tickets come in stage order: at most four times per queue
+                mdr_stage_vectors<MODE, XA>(a, VT);
+                staged = stage;
+                __syncthreads();
             }
-            // Acquire among CUs that share an L2, with NO cache invalidate: every tile of the three tile sets is written exactly once
-            // per launch (launch_mdr) and read only behind its completion count, and the L1 starts a launch empty, so neither
-            // the L1 nor the L2 can hold an older copy of what is read from here on.  (The agent-scope fence pair instead --
-            // `buffer_wbl2 sc1` / `buffer_inv sc1` at each of ~10k tile starts -- measured +240 us per forward; `buffer_inv sc1`
-            // alone +30 us.)  The compiler barrier keeps the tile's loads behind the poll.
-            asm volatile("" ::: "memory");
-        }
-        mdr_tile<MODE, XA>(a, id, VT, park);
-        if (MODE < 2) {
+            if (!live) return;
+            if (MODE > 0) {
+                if (lane == 0) {
+                    int budget = 1 << 24;                       // ~6 s of polling
+                    while (seen < (unsigned)kVT && --budget > 0) {
+                        __builtin_amdgcn_s_sleep(8);
+                        seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (budget <= 0) atomicExch(p.ctr + kCtrError, 1u + stage);
+                }
+                // Acquire among CUs that share an L2, with NO cache invalidate: every tile of the three tile sets is written exactly once
+                // per launch (launch_mdr) and read only behind its completion count, and the L1 starts a launch empty, so neither
+                // the L1 nor the L2 can hold an older copy of what is read from here on.  (The agent-scope fence pair instead --
+                // `buffer_wbl2 sc1` / `buffer_inv sc1` at each of ~10k tile starts -- measured +240 us per forward; `buffer_inv sc1`
+                // alone +30 us.)  The compiler barrier keeps the tile's loads behind the poll.
+                asm volatile("" ::: "memory");
+            }
+            mdr_tile<MODE, XA>(a, id, VT, park);
             // Release to the same L2: the L1 is write-through, so once the stores are acknowledged (vmcnt 0) every CU of the XCD
-            // sees them; then the count goes up (an atomic executed in that L2).
+            // sees them; then the count goes up (an atomic executed in that L2).  The last stage counts too: k_mdr_head refuses a
+            // sample whose 14 head-feature tiles were not all written (launch_mdr).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(p.ctr + kCtrDone + (size_t)stage * B + smp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // Tickets come in stage order, so within a queue a workgroup's stages only ever go up: three plain loops, one tile body each
+        // (one loop with a switch keeps all three bodies' state alive at once: 256 VGPRs + 760 B of scratch).
+        int unit = ticket();
+        for (; unit < units; unit = ticket()) run(std::integral_constant<int, 0>(), 0, unit);
+        for (; unit < 3 * units; unit = ticket()) {
+            const int stage = unit >= 2 * units ? 2 : 1;
+            run(std::integral_constant<int, 1>(), stage, unit);
         }
-    };
-    // Tickets come in stage order, so a workgroup's stages only ever go up: three plain loops, one tile body each (one loop with a
-    // switch keeps all three bodies' state alive at once: 256 VGPRs + 760 B of scratch).
-    int unit = ticket();
-    for (; unit < units; unit = ticket()) run(std::integral_constant<int, 0>(), 0, unit);
-    for (; unit < 3 * units; unit = ticket()) {
-        const int stage = unit >= 2 * units ? 2 : 1;
-        run(std::integral_constant<int, 1>(), stage, unit);
+        for (; unit < 4 * units; unit = ticket()) run(std::integral_constant<int, 2>(), 3, unit);
     }
-    for (; unit < 4 * units; unit = ticket()) run(std::integral_constant<int, 2>(), 3, unit);
 }
 
 // Joint tokens: jf = Linear(133->64)(pose_combine) + pos_j (MDR.py:130-134); per layer k = wk(LN1(jf)), v = wv(LN1(jf))
@@ -882,8 +899,8 @@ __global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     if (a.mdr_ctr) {
-        if (t < 3) a.mdr_ctr[16 + (size_t)t * gridDim.x + b] = 0u;
-        if (b == 0 && t >= 64 && t < 80) a.mdr_ctr[t - 64] = 0u;
+        if (t < 4) a.mdr_ctr[32 + (size_t)t * gridDim.x + b] = 0u;      // kCtrDone
+        if (b == 0 && t >= 64 && t < 96) a.mdr_ctr[t - 64] = 0u;         // tickets, error flag, queue owners
     }
     for (int e = t; e < 5 * kTile; e += 128) {
         const int j4 = e & 3, ln = (e >> 2) & 63, g = (e >> 8) & 3, kb = e >> 10;
@@ -935,6 +952,8 @@ struct HeadArgs {
     size_t vcp3_plane;
     _Float16* vcp2;         // non-null: write the scaled hi/lo fp16 planes of the two-plane vertex GEMM (upsample_x2.hip) instead
     const unsigned* persist_err;   // non-null: k_mdr_persist's hang-guard flag; if it is set the outputs are poisoned with NaN (loud, not silent)
+    const unsigned* done3;         // non-null: k_mdr_persist's per-sample count of finished last-stage tiles; a sample short of 14 was not computed -> NaN
+    unsigned* status;              // the ctx's sticky device status word (host-mapped; internal.h: DeviceStatus), read by the next API call
     int alpha;
 };
 // One workgroup per sample, three short phases with a barrier between them.  The kernel is a LATENCY chain, not a throughput one
@@ -1025,7 +1044,11 @@ __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a
     }
     __syncthreads();
     const int mt = b >> 5, sl = b & 31;
-    const bool poisoned = a.persist_err && *a.persist_err != 0u;
+    const bool poisoned = (a.persist_err && *a.persist_err != 0u) || (a.done3 && a.done3[b] != (unsigned)kVT);
+    // |vert431| must stay below 4 094 m for the two-plane vertex regressor (16 x value in an fp16 plane); any non-finite value -- e.g.
+    // an activation beyond +-4 094 that overflowed an fp16 operand plane somewhere upstream -- ends up here as NaN too
+    const float limit = a.vcp2 ? 4094.0f : 3.0e38f;
+    bool bad = false;
     if (tok) {
         if (!HOIST) load_rows();
         float av[20];
@@ -1046,6 +1069,7 @@ __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a
             for (int m = 0; m < 20; ++m) o += (p[m] * il) * bc[m][c];
             float val = sc * o + cc[c];
             if (poisoned) val = __builtin_nanf("");
+            bad = bad || !(fabsf(val) < limit);
             a.vc[((size_t)b * kV + v) * 3 + c] = val;
             if (a.vcp2) {       // two fp16 planes of 2^4 * val, in k_upsample_x2's operand order [mt/4][v/16][mt%4][l'][plane][lane][v%8]
                 const float sv = val * 16.0f;
@@ -1066,6 +1090,8 @@ __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a
             }
         }
     }
+    if (a.status && __any(bad) && lane == 0)      // sticky, host-visible: the next API call on the ctx (or gator_device_status) reports it
+        __hip_atomic_store(a.status, poisoned ? (unsigned)DEV_PERSIST_INCOMPLETE : (unsigned)DEV_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 LayerW make_layer(const FusedState* f, const gator_ctx* c, int li) {
@@ -1126,9 +1152,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     const double R = (double)nwg / f->n_cu;
     const bool auto_persist = R >= 3.0 && (std::ceil(R) - R) / R >= 0.04;
     bool persist = f->mdr_persist < 0 ? auto_persist : f->mdr_persist > 0;
-    // the queues are per XCD and a workgroup serves the queue of the XCD it runs on: that drains every queue only when the device is
-    // the whole 8-XCD part (a partitioned device shows fewer CUs; its workgroups would all sit on one XCD)
-    if (f->n_cu != 256) persist = false;
+    // (any device shape drains all eight queues: a queue whose own XCD has no workgroup is adopted by another one, k_mdr_persist)
 #ifdef GATOR_DIAG
     if (want_stamps) persist = false;       // the stamps describe the per-stage launches
 #endif
@@ -1164,9 +1188,11 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     }
     if (persist) {      // the four stages as one launch (k_mdr_persist): tickets and per-sample completion counts start from zero
         pa.ctr = f->mdr_ctr;
-        if (!ctr_clean) GATOR_HIP_CHECK(hipMemsetAsync(f->mdr_ctr, 0, (kCtrDone + (size_t)3 * B) * sizeof(unsigned), st));
+        if (!ctr_clean) GATOR_HIP_CHECK(hipMemsetAsync(f->mdr_ctr, 0, (kCtrDone + (size_t)4 * B) * sizeof(unsigned), st));
         StageTimer tm(c, "mdr_layers", stream);
-        const int grid = 2 * f->n_cu;       // two workgroups per CU is what the registers allow; any grid drains the queues
+        int grid = 2 * f->n_cu;             // two workgroups per CU is what the registers allow; any grid drains the queues
+        static const int env_grid = getenv("GATOR_MDR_PERSIST_GRID") ? atoi(getenv("GATOR_MDR_PERSIST_GRID")) : 0;      // tests: a grid that leaves XCDs empty
+        if (env_grid > 0) grid = env_grid;
         if (f->mdr_x3 == 2) k_mdr_persist<2><<<grid, 256, 0, st>>>(pa);
         else if (f->mdr_x3 == 1) k_mdr_persist<1><<<grid, 256, 0, st>>>(pa);
         else k_mdr_persist<0><<<grid, 256, 0, st>>>(pa);
@@ -1192,6 +1218,8 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     ha.hf = f->hf; ha.bn_w = w.bn_w; ha.bn_b = w.bn_b; ha.bn_mean = w.bn_mean; ha.bn_var = w.bn_var;
     ha.bconv_w = w.bconv_w; ha.bconv_b = w.bconv_b; ha.vc = f->vc; ha.vcp = f->vcp;
     ha.persist_err = persist ? f->mdr_ctr + kCtrError : nullptr;
+    ha.done3 = persist ? f->mdr_ctr + kCtrDone + (size_t)3 * B : nullptr;
+    ha.status = c->status_dev;
     ha.vcp2 = f->x3 && f->up_x2 ? (_Float16*)f->vcp3 : nullptr;
     ha.vcp3 = f->x3 && !f->up_x2 ? (__bf16*)f->vcp3 : nullptr; ha.vcp3_plane = upsample_x3_vcp_elems(f->cap) / 3;     // plane stride fixed by the workspace capacity
     ha.alpha = c->alpha;

@@ -76,8 +76,9 @@ __device__ __forceinline__ f32x16 x3_mma(const X3& A, const X3& B, f32x16 acc) {
 // x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits, three partial products (hi*hi, hi*lo, lo*hi) per k-step
 // instead of six.  Unlike the exact three-way bf16 split this ROUNDS the operands (2^-23 relative), which is only acceptable
 // where the result is an average over many terms: measured in the fp64 oracle (two real fp16 planes, all other arithmetic exact)
-// the vertices move by 8e-6 mm max / 1.4e-6 mm rms -- 1 % of the path's own fp32 noise -- whereas the same treatment of the
-// token-wise linears costs 4e-4 mm (as much as the whole budget), so those stay on the exact split.  Operands are pre-scaled
+// the vertices move by 8e-6 mm max / 1.4e-6 mm rms -- 1 % of the path's own fp32 noise -- whereas the same treatment of BOTH operands
+// of the token-wise linears costs 4e-4 mm (as much as the whole budget): those keep their WEIGHTS exact and round only the
+// activations (the "4-product" form further down, 1.3e-4 mm; GATOR_MDR_X3=1 / GATOR_GAT8_H4=0 keep the exact six).  Operands are pre-scaled
 // by powers of two (Q, K, V x 16; P x 64 through the softmax offset) so that the low planes stay out of fp16's subnormal range.
 // Tile = [plane 2][k-step 2][lane 64][8 halves] = 4 KiB (the size of the fp32 tile).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -26,13 +26,23 @@ class GATOR(HipModule):
     def _config(self):
         return {'num_joint': self.num_joint, 'alpha': self.pose2mesh.alpha}
 
-    def forward(self, pose2d):
-        """pose2d [B,J,2] -> (cam_mesh [B,6890,3] metres, pose3d [B,J,3] mm);  lib/models/GATOR.py:16-22."""
+    supports_out = True        # forward(x, out=(verts, pose3d)) writes into the caller's buffers (ShardedForward: its rank's slice of the gather buffer)
+
+    def forward(self, pose2d, out=None):
+        """pose2d [B,J,2] -> (cam_mesh [B,6890,3] metres, pose3d [B,J,3] mm);  lib/models/GATOR.py:16-22.
+        `out` = (verts, pose3d): contiguous fp32 tensors of those shapes on the input's device that the kernels write instead of
+        fresh allocations."""
         x = self._prep(pose2d, 'GATOR.forward')
         B = x.shape[0]
         ctx = self._context(x.device)
-        verts = torch.empty((B, 6890, 3), device=x.device, dtype=torch.float32)
-        pose3d = torch.empty((B, self.num_joint, 3), device=x.device, dtype=torch.float32)
+        if out is not None:
+            verts, pose3d = out
+            for t, shp in ((verts, (B, 6890, 3)), (pose3d, (B, self.num_joint, 3))):
+                if tuple(t.shape) != shp or t.dtype != torch.float32 or t.device != x.device or not t.is_contiguous():
+                    raise RuntimeError('GATOR.forward: out tensors must be contiguous fp32 %s on %s' % (shp, x.device))
+        else:
+            verts = torch.empty((B, 6890, 3), device=x.device, dtype=torch.float32)
+            pose3d = torch.empty((B, self.num_joint, 3), device=x.device, dtype=torch.float32)
         fn = _lib.load().gator_forward_bf16 if self.precision == 'bf16' else _lib.load().gator_forward_f32
         _lib.check(fn(ctx, x.data_ptr(), B, verts.data_ptr(), pose3d.data_ptr(), self._stream(x.device)), 'gator_forward_' + self.precision)
         return verts, pose3d

@@ -51,6 +51,7 @@ class ShardedForward:
         self.metrics_fn = metrics_fn            # eval mode: (verts, pose3d, target, sample slice) -> 1-D tensor of partial sums
         self._bufs = {}
         self._stage = {}
+        self._stage_free = {}                   # staging slot -> event after which it may be written again
         self._comm_stream = None
         self._flip = 0
         self._target = None
@@ -105,12 +106,14 @@ class ShardedForward:
                                torch.empty((self.world * B, J, 3), device=device, dtype=torch.float32))
         return self._bufs[key]
 
-    def _staging(self, n, J, device):
-        key = (n, J, str(device))
+    def _staging(self, n, J, device, slot=0):
+        """[world, n, ...] landing tiles of a micro-batch's collective; two slots in turn, so that the forward of chunk k + 1 can
+        write its slot while the gather of chunk k still runs on the side stream."""
+        key = (n, J, str(device), slot & 1)
         if key not in self._stage:
             self._stage[key] = (torch.empty((self.world, n, 6890, 3), device=device, dtype=torch.float32),
                                 torch.empty((self.world, n, J, 3), device=device, dtype=torch.float32))
-        return self._stage[key]
+        return key, self._stage[key]
 
     def _side(self, device):
         """Context in which collectives are issued: the side stream on a HIP device, nothing on the host."""
@@ -122,21 +125,33 @@ class ShardedForward:
         self._comm_stream.wait_stream(cur)      # after the producing kernels AND after every queued read of the buffer we reuse
         return torch.cuda.stream(self._comm_stream), self._comm_stream
 
-    def _gather_chunk(self, verts, pose3d, s, e, B, gv, gp):
+    def _landing(self, s, e, B, J, gv, gp, slot):
+        """Where this rank's rows [s,e) must lie for the collective to run IN PLACE (send buffer = this rank's slot of the receive
+        buffer, RCCL's in-place all-gather): its slice of the output when the chunk is the whole local batch, its slot of a
+        [world, n, ...] staging tile for a micro-batch.  The forward writes there directly: no fresh output allocation and no
+        21 - 85 MB copy of the local shard into the gather buffer.  -> (receive verts, receive pose3d, my verts, my pose3d, key)"""
+        if s == 0 and e == B:
+            return gv, gp, gv[self.rank * B:(self.rank + 1) * B], gp[self.rank * B:(self.rank + 1) * B], None
+        key, (sv, sp) = self._staging(e - s, J, gv.device, slot)
+        return sv.view(-1, 6890, 3), sp.view(-1, J, 3), sv[self.rank], sp[self.rank], key
+
+    def _gather_chunk(self, verts, pose3d, s, e, B, gv, gp, slot=0):
         """All ranks' rows [s,e) of their local batches -> rows r*B+s .. r*B+e of the replicated outputs."""
         dev, J = verts.device, pose3d.shape[1]
         ctx, side = self._side(dev)
+        rv, rp, mv, mp, key = self._landing(s, e, B, J, gv, gp, slot)
         with ctx:
-            if s == 0 and e == B:               # whole local batch: rank-major concatenation IS the output layout
-                self.dist.all_gather_into_tensor(gv, verts)
-                self.dist.all_gather_into_tensor(gp, pose3d)
-            else:                               # micro-batch: one gather into a [world, n, ...] staging tile, one strided copy
-                sv, sp = self._staging(e - s, J, dev)
-                self.dist.all_gather_into_tensor(sv.view(-1, 6890, 3), verts)
-                self.dist.all_gather_into_tensor(sp.view(-1, J, 3), pose3d)
-                gv.view(self.world, B, 6890, 3)[:, s:e].copy_(sv)
-                gp.view(self.world, B, J, 3)[:, s:e].copy_(sp)
-        if side is not None:
+            # whole local batch: rank-major concatenation IS the output layout; micro-batch: one gather into the staging tile, then
+            # one strided copy.  `verts` is normally `mv` itself (the forward wrote its rank's slot); a model without `out=` hands
+            # back its own tensor and the collective copies it in.
+            self.dist.all_gather_into_tensor(rv, verts)
+            self.dist.all_gather_into_tensor(rp, pose3d)
+            if key is not None:
+                gv.view(self.world, B, 6890, 3)[:, s:e].copy_(rv.view(self.world, e - s, 6890, 3))
+                gp.view(self.world, B, J, 3)[:, s:e].copy_(rp.view(self.world, e - s, J, 3))
+                if side is not None:
+                    self._stage_free[key] = side.record_event()      # the next writer of this staging slot waits for this
+        if side is not None and verts.data_ptr() != mv.data_ptr():
             verts.record_stream(side)
             pose3d.record_stream(side)
         return side
@@ -161,11 +176,19 @@ class ShardedForward:
         self._throttle(pose2d_shard.device)
         gv, gp = self._buffers(B, J, pose2d_shard.device)
         side, chunks = None, []
-        for s, e in self._plan(B):
-            verts, pose3d = self.model(pose2d_shard[s:e])
-            verts, pose3d = verts.contiguous(), pose3d.contiguous()
-            side = self._gather_chunk(verts, pose3d, s, e, B, gv, gp)
-            chunks.append((verts, pose3d, s, e))
+        in_place = bool(getattr(self.model, 'supports_out', False))
+        for i, (s, e) in enumerate(self._plan(B)):
+            if in_place:                        # the forward writes this rank's slot of the collective's receive buffer
+                _, _, mv, mp, key = self._landing(s, e, B, J, gv, gp, i)
+                free = self._stage_free.pop(key, None)
+                if free is not None:            # a staging slot is re-used: its last collective + copy-out must be done first
+                    torch.cuda.current_stream(pose2d_shard.device).wait_event(free)
+                verts, pose3d = self.model(pose2d_shard[s:e], out=(mv, mp))
+            else:
+                verts, pose3d = self.model(pose2d_shard[s:e])
+                verts, pose3d = verts.contiguous(), pose3d.contiguous()
+            side = self._gather_chunk(verts, pose3d, s, e, B, gv, gp, i)
+            chunks.append((verts, pose3d, s, e, i))
         self._last = ('gather', (chunks, B, gv, gp))
         # the compute stream does NOT wait: the next step overlaps this gather
         self.last_event = side.record_event() if side is not None else None
@@ -240,8 +263,12 @@ class ShardedForward:
         kind, t = self._last
         if kind == 'gather':
             chunks, B, gv, gp = t
-            for verts, pose3d, s, e in chunks:
-                side = self._gather_chunk(verts, pose3d, s, e, B, gv, gp)
+            for verts, pose3d, s, e, i in chunks:
+                if not (s == 0 and e == B) and verts.data_ptr() == self._landing(s, e, B, pose3d.shape[1], gv, gp, i)[2].data_ptr():
+                    # in-place micro-batch: a later chunk has re-used the staging slot; put this rank's rows back first
+                    verts.copy_(gv.view(self.world, B, 6890, 3)[self.rank, s:e])
+                    pose3d.copy_(gp.view(self.world, B, -1, 3)[self.rank, s:e])
+                side = self._gather_chunk(verts, pose3d, s, e, B, gv, gp, i)
         else:
             ctx, side = self._side(t[0].device)
             with ctx:

@@ -27,7 +27,9 @@ extern "C" {
 typedef struct gator_ctx gator_ctx;
 
 typedef enum { GATOR_OK = 0, GATOR_EINVAL = -1, GATOR_EMISSING = -2, GATOR_ESHAPE = -3, GATOR_EHIP = -4,
-               GATOR_ENOMEM = -5, GATOR_EUNSUPPORTED = -6 } gator_status;
+               GATOR_ENOMEM = -5, GATOR_EUNSUPPORTED = -6,
+               GATOR_EDEVICE = -7     /* a kernel of an EARLIER call flagged its result as invalid (gator_device_status) */
+} gator_status;
 
 typedef enum { GATOR_F32 = 0, GATOR_I64 = 1, GATOR_I32 = 2 } gator_dtype;
 
@@ -49,9 +51,16 @@ typedef struct {
     int32_t reserved;
 } gator_tensor;
 
-/* GATOR_IMPL_FUSED computes its large products on the bf16 MFMA from an exact three-way bf16 split of every fp32 operand
- * (fp32-accurate; csrc/x3_common.h).  The environment variables GATOR_GAT_X3, GATOR_MDR_X3, GATOR_UPSAMPLE_X3 (= 0), read by
- * gator_create, select the fp32-input-MFMA form of a stage instead (same accuracy class, slower; A/B runs and tests). */
+/* GATOR_IMPL_FUSED computes every large product on the 16-bit MFMA from SPLIT fp32 operands (csrc/x3_common.h): weights always
+ * exactly (three fp16 or bf16 planes), and by default activations, attention operands and the vertex regressor's operands as TWO
+ * fp16 planes of 16 x value (22 significant bits; four resp. three partial products per fp32 product instead of six).
+ * Operand range of that default: every value that feeds a token-wise linear and every coarse vertex must stay below 4 094 in
+ * magnitude (16 x value must fit an fp16 plane); beyond it the plane overflows, the vertices of that forward come out NaN and the
+ * NEXT call on the ctx (or gator_device_status) returns GATOR_EDEVICE -- loud, never silently wrong.  Trained checkpoints are
+ * orders of magnitude inside (LayerNorm outputs, GELU hiddens, metres).  Environment variables read by gator_create select the forms
+ * without a rounded operand and without that limit (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 GATOR_GAT_TILED_H4=0: exact
+ * three-way bf16 split, six products) or the fp32-input MFMA form of a stage (GATOR_GAT_X3 / GATOR_MDR_X3 / GATOR_UPSAMPLE_X3 = 0);
+ * all forms are the same accuracy class and under test (tests/test_gpu_x3.py; statistics: profiles/r04_error_budget.md). */
 typedef enum { GATOR_IMPL_FUSED = 0,   /* MFMA / register-resident fused kernels (default) */
                GATOR_IMPL_BASIC = 1    /* bring-up kernels: one simple HIP kernel per reference op; used as an
                                           on-device cross-check of the fused path */
@@ -75,6 +84,13 @@ typedef struct {
  * (hop/path attention bias modules.py:98-107, MGCN adjacency :247-249, hop masks :163-170, BatchNorm affine). */
 int gator_create(const gator_tensor* tensors, int32_t n_tensors, const gator_config* cfg, gator_ctx** out);
 int gator_destroy(gator_ctx* ctx);
+
+/* Device-side validity of the forwards issued so far.  Kernels never synchronise the host, so a failure that only the device can
+ * see -- non-finite / out-of-range coarse vertices (operand range above), or a persistent MDR launch that did not finish every
+ * sample -- is recorded in a sticky, host-visible status word and reported by the NEXT entry point called on the ctx, once, as
+ * GATOR_EDEVICE (the affected vertices are NaN).  gator_device_status reports it on demand; sync != 0 waits for the device first
+ * (the reference raises at the point of use, lib/core/base.py:210-237; this is the asynchronous equivalent). */
+int gator_device_status(gator_ctx* ctx, int32_t sync);
 
 /* Replaces: GATOR.forward (lib/models/GATOR.py:16-22).
  *   pose2d [B,J,2] f32 device, contiguous  ->  verts [B,6890,3] f32 (metres), pose3d [B,J,3] f32 (mm).

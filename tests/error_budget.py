@@ -1,0 +1,203 @@
+"""Error budget of the shipped arithmetic, measured on the device against the fp64 oracle (test infrastructure).
+
+    python -m tests.error_budget --samples 16384 --out gpurun_out/r04_error_budget.json      (tools/error_budget.py starts it)
+
+For every cell (golden variant x weight seed) the same N synthetic poses run through
+  * the device forward in each arithmetic configuration (the shipped one under both encoder pins, one rounded operand class switched
+    back to its exact form at a time, everything exact, everything on the fp32-input MFMA), and
+  * the oracle in fp64 (the anchor) and in fp32 (the reference's own arithmetic: `ref32`),
+and the vertex error |x - fp64| in mm is reduced over ALL N x 6890 x 3 coordinates: max, rms, 99.999-th percentile (from a 1e-6 mm
+histogram), the share of samples whose worst coordinate is above 0.85e-3 / 1e-3 mm.  The oracle slices are computed by worker
+processes on the host cores while the device outputs wait in HBM; nothing here is timed.
+
+The switches are the library's own (read at gator_create): GATOR_GAT8_H4 / GATOR_GAT_TILED_H4 (encoder: activations on two fp16
+planes), GATOR_MDR_X3 (2: four-product linears + two-plane attention, 1: exact three-plane split), GATOR_UPSAMPLE_X3 (2 / 1 likewise),
+GATOR_*_X3=0 (fp32-input MFMA)."""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# name -> (environment at gator_create, encoder pin)
+CONFIGS = {
+    'shipped/sample': ({}, 'sample'),
+    'shipped/tiled': ({}, 'tiled'),
+    'enc_exact/sample': ({'GATOR_GAT8_H4': '0'}, 'sample'),
+    'enc_exact/tiled': ({'GATOR_GAT_TILED_H4': '0'}, 'tiled'),
+    'mdr_exact/sample': ({'GATOR_MDR_X3': '1'}, 'sample'),
+    'up_exact/sample': ({'GATOR_UPSAMPLE_X3': '1'}, 'sample'),
+    'all_exact/sample': ({'GATOR_GAT8_H4': '0', 'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1'}, 'sample'),
+    'all_exact/tiled': ({'GATOR_GAT_TILED_H4': '0', 'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1'}, 'tiled'),
+    'fp32_mfma/sample': ({'GATOR_GAT_X3': '0', 'GATOR_MDR_X3': '0', 'GATOR_UPSAMPLE_X3': '0'}, 'auto'),
+}
+SWITCHES = ('GATOR_GAT8_H4', 'GATOR_GAT_TILED_H4', 'GATOR_MDR_X3', 'GATOR_UPSAMPLE_X3', 'GATOR_GAT_X3', 'GATOR_GAT8', 'GATOR_GAT_TILED')
+HIST_BINS, HIST_MAX = 4000, 4e-3         # mm; 1e-6 mm bins
+
+
+def _oracle_worker(job):
+    """(variant, weight seed, pose seed, lo, hi, threads) -> (lo, fp64 vertices, fp32 vertices) of samples lo..hi."""
+    name, wseed, pseed, N, lo, hi, threads = job
+    import torch
+    torch.set_num_threads(threads)
+    from gator_amd import synthetic
+    from oracle import gator_oracle as go
+    from tests.helpers import oracle_setup
+    global _ORC
+    key = (name, wseed)
+    if '_ORC' not in globals() or _ORC[0] != key:
+        z, c, sd = oracle_setup(name, seed=wseed)
+        _ORC = (key, c, sd)
+    _, c, sd = _ORC
+    x = torch.from_numpy(synthetic.synthetic_pose2d(N, c.J, seed=pseed)[lo:hi])
+    r64, _ = go.gator_forward(sd, c, x, torch.float64)
+    r32, _ = go.gator_forward(sd, c, x, torch.float32)
+    return lo, r64.numpy(), r32.numpy()
+
+
+class Stat:
+    def __init__(self, n, device):
+        import torch
+        self.max = 0.0
+        self.sumsq = 0.0
+        self.count = 0
+        self.hist = torch.zeros(HIST_BINS, dtype=torch.float64, device=device)
+        self.per_sample = torch.zeros(n, dtype=torch.float64, device=device)
+
+    def add(self, lo, err_mm):
+        import torch
+        b = err_mm.shape[0]
+        self.max = max(self.max, float(err_mm.max()))
+        self.sumsq += float((err_mm * err_mm).sum())
+        self.count += err_mm.numel()
+        self.hist += torch.histc(err_mm.clamp(max=HIST_MAX * (1 - 1e-9)).float(), HIST_BINS, 0.0, HIST_MAX).double()
+        self.per_sample[lo:lo + b] = err_mm.reshape(b, -1).max(1).values
+
+    def summary(self):
+        import torch
+        cdf = torch.cumsum(self.hist, 0) / self.hist.sum()
+        def pct(q):
+            i = int(torch.searchsorted(cdf, torch.tensor(q, dtype=cdf.dtype, device=cdf.device)))
+            return (min(i, HIST_BINS - 1) + 1) * HIST_MAX / HIST_BINS          # upper edge of the bin
+        ps = self.per_sample
+        return {'max_mm': self.max, 'rms_mm': (self.sumsq / max(self.count, 1)) ** 0.5, 'p99_999_mm': pct(0.99999), 'p99_99_mm': pct(0.9999),
+                'samples_over_0.85e-3': int((ps > 0.85e-3).sum()), 'samples_over_1e-3': int((ps > 1e-3).sum()),
+                'median_sample_max_mm': float(ps.median()), 'coords': self.count}
+
+
+def device_outputs(name, wseed, pose, cfg, chunk):
+    """All N samples through one arithmetic configuration -> [N, 6890, 3] fp32 on the device."""
+    import torch
+    from tests.helpers import build_model
+    env, pin = CONFIGS[cfg]
+    saved = {k: os.environ.pop(k, None) for k in SWITCHES}
+    os.environ.update(env)
+    try:
+        z, m = build_model(name, 'fused', seed=wseed)
+        if pin != 'auto':
+            m.set_encoder(pin)
+        out = torch.empty(pose.shape[0], 6890, 3, device='cuda')
+        for lo in range(0, pose.shape[0], chunk):
+            v, _ = m(pose[lo:lo + chunk].contiguous())
+            out[lo:lo + chunk] = v
+        torch.cuda.synchronize()
+        m.invalidate()
+        del m
+    finally:
+        for k in SWITCHES:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+    return out
+
+
+def run_cell(name, wseed, N, configs, pool, nworkers, threads, slice_n, chunk, log):
+    import torch
+    from gator_amd import synthetic
+    from tests.helpers import load_golden
+    J = int(load_golden(name)['num_joint'])
+    pseed = 1000 + 17 * wseed
+    pose = torch.from_numpy(synthetic.synthetic_pose2d(N, J, seed=pseed)).cuda()
+    t0 = time.time()
+    jobs = [(name, wseed, pseed, N, lo, min(lo + slice_n, N), threads) for lo in range(0, N, slice_n)]
+    pending = pool.imap_unordered(_oracle_worker, jobs)        # the host cores start on the oracle while the device runs
+    outs = {}
+    for cfg in configs:
+        outs[cfg] = device_outputs(name, wseed, pose, cfg, chunk)
+        log('  [%s seed %d] device %-18s done (%.0f s)' % (name, wseed, cfg, time.time() - t0))
+    stats = {cfg: Stat(N, 'cuda') for cfg in list(configs) + ['ref32']}
+    done = 0
+    for lo, r64, r32 in pending:
+        ref = torch.from_numpy(r64).cuda()
+        b = ref.shape[0]
+        for cfg in configs:
+            stats[cfg].add(lo, (outs[cfg][lo:lo + b].double() - ref).abs() * 1e3)
+        stats['ref32'].add(lo, (torch.from_numpy(r32).cuda().double() - ref).abs() * 1e3)
+        done += b
+        if done % (8 * slice_n) == 0 or done == N:
+            log('  [%s seed %d] oracle %d / %d samples (%.0f s)' % (name, wseed, done, N, time.time() - t0))
+    res = {cfg: s.summary() for cfg, s in stats.items()}
+    # which samples are the worst under the shipped arithmetic, and what the reference's own arithmetic does on them
+    first = configs[0]
+    worst = torch.topk(stats[first].per_sample, min(5, N)).indices.tolist()
+    res['_worst_samples'] = [{'sample': int(i), first: float(stats[first].per_sample[i]), 'ref32': float(stats['ref32'].per_sample[i])} for i in worst]
+    return res
+
+
+def table(results):
+    lines = ['| variant / weight seed | configuration | max mm | p99.999 mm | rms mm | samples > 0.85e-3 | > 1e-3 | max / ref32 max |', '|---|---|---|---|---|---|---|---|']
+    for cell, res in results.items():
+        ref = res['ref32']['max_mm']
+        for cfg, s in res.items():
+            if cfg.startswith('_'):
+                continue
+            lines.append('| %s | %s | %.2e | %.2e | %.2e | %d | %d | %.2f |' % (cell, cfg, s['max_mm'], s['p99_999_mm'], s['rms_mm'], s['samples_over_0.85e-3'],
+                                                                              s['samples_over_1e-3'], s['max_mm'] / ref))
+    return '\n'.join(lines)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--samples', type=int, default=16384)
+    ap.add_argument('--variants', default='h36m17_bn,coco19_alpha')
+    ap.add_argument('--seeds', default='golden,1,2', help="weight seeds; 'golden' = the seed of the committed fixture")
+    ap.add_argument('--configs', default=','.join(CONFIGS))
+    ap.add_argument('--slice', type=int, default=128)
+    ap.add_argument('--chunk', type=int, default=2048)
+    ap.add_argument('--workers', type=int, default=0)
+    ap.add_argument('--threads', type=int, default=8)
+    ap.add_argument('--out', default='')
+    a = ap.parse_args()
+    ncpu = os.cpu_count() or 8
+    nworkers = a.workers or max(1, min(24, ncpu // a.threads))
+    configs = [c for c in a.configs.split(',') if c]
+    log = lambda s: print(s, file=sys.stderr, flush=True)
+    log('error budget: %d samples per cell, %d oracle workers x %d threads (%d host threads)' % (a.samples, nworkers, a.threads, ncpu))
+    from tests.helpers import load_golden
+    results = {}
+    with mp.get_context('spawn').Pool(nworkers) as pool:
+        for name in a.variants.split(','):
+            for sd in a.seeds.split(','):
+                wseed = int(load_golden(name)['seed']) if sd == 'golden' else int(sd)
+                results['%s / %d' % (name, wseed)] = run_cell(name, wseed, a.samples, configs, pool, nworkers, a.threads, a.slice, a.chunk, log)
+                log(table({k: v for k, v in results.items() if k.endswith('/ %d' % wseed) and k.startswith(name)}))
+    doc = {'samples_per_cell': a.samples, 'coords_per_cell': a.samples * 6890 * 3, 'configs': {k: {'env': CONFIGS[k][0], 'encoder': CONFIGS[k][1]} for k in configs},
+           'results': results, 'table': table(results)}
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, 'w') as f:
+            json.dump(doc, f, indent=1)
+        with open(os.path.splitext(a.out)[0] + '.md', 'w') as f:
+            f.write(doc['table'] + '\n')
+    print(doc['table'])
+
+
+if __name__ == '__main__':
+    main()

@@ -20,30 +20,32 @@ def golden_shapes(z):
             for k, s in zip(z['state_dict_keys'], z['state_dict_shapes'])}
 
 
-def variant_setup(name, upsample_gain=0.2):
-    """-> (z, J, alpha, base, numpy seeded weights {key: ndarray})  (same stream order as tools/gen_golden.py)."""
+def variant_setup(name, upsample_gain=0.2, seed=None):
+    """-> (z, J, alpha, base, numpy seeded weights {key: ndarray})  (same stream order as tools/gen_golden.py).
+    `seed` overrides the golden's weight / base-data seed (other weight draws of the same recipe: tools/error_budget.py)."""
     z = load_golden(name)
-    J, alpha, seed = int(z['num_joint']), bool(z['alpha']), int(z['seed'])
+    J, alpha = int(z['num_joint']), bool(z['alpha'])
+    seed = int(z['seed']) if seed is None else int(seed)
     base = synthetic.make_base_data(seed)
     weights = synthetic.seeded_state_dict(golden_shapes(z), base['rs'], upsample_gain=upsample_gain)
     return z, J, alpha, base, weights
 
 
-def oracle_setup(name, upsample_gain=0.2):
+def oracle_setup(name, upsample_gain=0.2, seed=None):
     from oracle import gator_oracle as go
-    z, J, alpha, base, weights = variant_setup(name, upsample_gain)
+    z, J, alpha, base, weights = variant_setup(name, upsample_gain, seed)
     c = go.Consts(J, synthetic.model_j_regressor(J), base, alpha)
     sd = {k: torch.from_numpy(v) for k, v in weights.items()}
     sd['pose_lifter.graph_adj'] = torch.from_numpy(c.graph_adj)
     return z, c, sd
 
 
-def build_model(name, impl='fused', device='cuda', upsample_gain=0.2):
+def build_model(name, impl='fused', device='cuda', upsample_gain=0.2, seed=None):
     """gator_amd GATOR module of a golden variant with the seeded weights loaded, on `device`."""
     import scipy.sparse as sps
     from gator_amd import models
     from gator_amd.models.GAT import _dense_adj  # noqa: F401
-    z, J, alpha, base, weights = variant_setup(name, upsample_gain)
+    z, J, alpha, base, weights = variant_setup(name, upsample_gain, seed)
     sk, fl = _joint_setting(J)
     adj = np.zeros((J, J))
     for a, b in tuple(sk) + tuple(fl):

@@ -128,3 +128,36 @@ def test_bf16_config3_full_size():
     ref, _ = go.gator_forward(sd, c, x[500:524].cpu(), torch.float64)
     e = np.abs(vb[500:524].cpu().numpy().astype(np.float64) - ref.numpy()) * 1e3
     assert e.max() < 8.0 and np.sqrt((e ** 2).mean()) < 1.0
+
+
+@pytest.mark.parametrize('key,gain', [('pose2mesh.encoder_1.mlp.fc1.weight', 3e4), ('pose_lifter.blocks.2.mlp.fc1.weight', 3e4),
+                                       ('pose2mesh.bias_conv1d.weight', 1e6)])
+def test_operand_range_violation_is_loud(key, gain):
+    """The default arithmetic carries activations as fp16 planes of 16 x value: |value| must stay below 4 094 (include/gator_hip.h).
+    Weights scaled so that an MLP hidden (MDR or GAT encoder) resp. the coarse vertices leave that range: the forward must not
+    return silently wrong numbers -- its vertices are NaN and the NEXT call on the ctx (or device_status) raises GATOR_EDEVICE;
+    after the report the ctx keeps working."""
+    z, m = build_model('h36m17_bn', 'fused', device=None)
+    sd = m.state_dict()
+    good = sd[key].clone()
+    sd[key] = good * gain
+    m.load_state_dict(sd)
+    m = m.cuda()
+    x = torch.from_numpy(synthetic.synthetic_pose2d(16, 17, seed=5)).cuda()
+    v, p = m(x)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(v).all()                     # loud in the data ...
+    with pytest.raises(RuntimeError, match='non-finite|out-of-range'):
+        m.device_status()                                   # ... and in the API
+    m.device_status()                                       # reported once, then clear
+    v2, _ = m(x)                                            # the ctx still accepts work
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError):
+        m(x)                                                # the forward after a bad one reports it without an explicit query
+
+
+def test_device_status_is_clean_after_normal_forwards():
+    z, m = build_model('coco19_alpha', 'fused')
+    for B in (1, 33, 300):
+        m(torch.from_numpy(synthetic.synthetic_pose2d(B, 19, seed=B)).cuda())
+    m.device_status()

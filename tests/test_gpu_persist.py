@@ -82,3 +82,39 @@ def test_persistent_launch_survives_random_batch_sizes(monkeypatch):
             assert torch.isfinite(v).all() and torch.equal(v, v0) and torch.equal(p, p0), (it, B)
     torch.cuda.synchronize()
     assert torch.isfinite(v).all()
+
+
+_ADOPT_CHILD = r"""
+import sys, torch
+sys.path.insert(0, '.')
+from gator_amd import synthetic
+from tests.helpers import build_model
+z, m = build_model('h36m17_bn', 'fused')
+for B in (3, 40, 97):
+    x = torch.from_numpy(synthetic.synthetic_pose2d(B, 17, seed=B)).cuda()
+    v, p = m(x)
+    torch.cuda.synchronize()
+    m.device_status()
+    torch.save((v.cpu(), p.cpu()), sys.argv[1] + '.%d' % B)
+print('ok')
+"""
+
+
+@pytest.mark.timeout(600)
+def test_queues_of_xcds_without_a_workgroup_are_adopted(tmp_path):
+    """A persistent launch whose grid leaves XCDs EMPTY (1, 3, 5 or 13 workgroups for 8 queues: what a CU mask or reserved CUs would do):
+    every queue is still drained -- by the one XCD that claims it -- and the result is bitwise the four launches'.  Before the
+    ownership protocol the samples of an empty XCD were silently never computed."""
+    import os, subprocess, sys
+    outs = {}
+    for tag, env in (('ref', {'GATOR_MDR_PERSIST': '0'}), ('g1', {'GATOR_MDR_PERSIST': '1', 'GATOR_MDR_PERSIST_GRID': '1'}),
+                     ('g3', {'GATOR_MDR_PERSIST': '1', 'GATOR_MDR_PERSIST_GRID': '3'}), ('g5', {'GATOR_MDR_PERSIST': '1', 'GATOR_MDR_PERSIST_GRID': '5'}),
+                     ('g13', {'GATOR_MDR_PERSIST': '1', 'GATOR_MDR_PERSIST_GRID': '13'})):
+        path = str(tmp_path / tag)
+        r = subprocess.run([sys.executable, '-c', _ADOPT_CHILD, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=500)
+        assert r.returncode == 0 and 'ok' in r.stdout, (tag, r.stdout[-500:], r.stderr[-2000:])
+        outs[tag] = {B: torch.load(path + '.%d' % B) for B in (3, 40, 97)}
+    for tag in ('g1', 'g3', 'g5', 'g13'):
+        for B in (3, 40, 97):
+            assert torch.isfinite(outs[tag][B][0]).all(), (tag, B)
+            assert torch.equal(outs[tag][B][0], outs['ref'][B][0]) and torch.equal(outs[tag][B][1], outs['ref'][B][1]), (tag, B)

@@ -18,12 +18,21 @@ def _fake_forward(x):                       # per-sample, batch-independent: lik
     return verts, x.repeat(1, 1, 2)[:, :, :3].contiguous()
 
 
-class _FakeModel:                           # the module surface ShardedForward touches: __call__ and set_encoder
-    def __init__(self):
+class _FakeModel:                           # the module surface ShardedForward touches: __call__(x, out=) and set_encoder
+    def __init__(self, supports_out=True):
         self.encoder_calls = []
+        self.supports_out = supports_out     # like gator_amd.models.GATOR: the forward writes into the caller's buffers
+        self.out_ptrs = []
 
-    def __call__(self, x):
-        return _fake_forward(x)
+    def __call__(self, x, out=None):
+        v, p = _fake_forward(x)
+        if out is None:
+            return v, p
+        assert out[0].is_contiguous() and out[1].is_contiguous() and out[0].shape == v.shape and out[1].shape == p.shape
+        out[0].copy_(v)
+        out[1].copy_(p)
+        self.out_ptrs.append(out[0].data_ptr())
+        return out
 
     def set_encoder(self, mode):
         self.encoder_calls.append(mode)
@@ -43,14 +52,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, micro, mode, q):
+def _worker(rank, world, port, micro, mode, q, in_place=True):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from gator_amd.parallel import ShardedForward
     n = 6
     ok = True
     if mode == 'gather':
-        model = _FakeModel()
+        model = _FakeModel(in_place)
         run = ShardedForward(model, world, rank, dist, micro_batch=micro)
         kept = []
         for step in range(5):                # five steps: the two output buffers rotate; step k's result survives step k+1
@@ -59,6 +68,11 @@ def _worker(rank, world, port, micro, mode, q):
             gv, gp = run.step(full[rank * n:(rank + 1) * n])
             rv, rp = _fake_forward(full)
             ok = ok and bool(torch.equal(gv, rv)) and bool(torch.equal(gp, rp))
+            if in_place and micro is None:   # the forward wrote this rank's slice of the gather buffer itself: no second copy of the shard
+                ok = ok and model.out_ptrs[-1] == gv[rank * n:].data_ptr()
+            elif in_place:                   # micro-batches land in this rank's slot of a [world, n, ...] staging tile
+                ok = ok and len(model.out_ptrs) == 2 * (step + 1) and all(
+                    any(t[0][rank].data_ptr() == ptr for t in run._stage.values()) for ptr in model.out_ptrs[-2:])
             if kept:
                 ok = ok and bool(torch.equal(kept[-1][0], kept[-1][1]))       # previous step's buffer not overwritten yet
                 ok = ok and kept[-1][0].data_ptr() != gv.data_ptr()
@@ -82,11 +96,11 @@ def _worker(rank, world, port, micro, mode, q):
     dist.destroy_process_group()
 
 
-def _run(micro, mode='gather'):
+def _run(micro, mode='gather', in_place=True):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, micro, mode, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, micro, mode, q, in_place)) for r in range(2)]
     for p in ps:
         p.start()
     res = [q.get(timeout=120) for _ in ps]
@@ -102,6 +116,11 @@ def test_allgather_full_batch():
 
 def test_allgather_microbatched_ragged():
     _run(4)                                  # 6 samples per rank in chunks of 4 + 2
+
+
+def test_allgather_model_without_out_argument():
+    _run(None, in_place=False)               # a model that returns its own tensors: the collective copies the shard in
+    _run(4, in_place=False)
 
 
 def test_eval_mode_allreduce_only():
