@@ -48,7 +48,8 @@ def build(force=False, verbose=True, diag=False):
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             is_hip = s.endswith('.hip')
-            cmd = [hipcc] + FLAGS + (['-DGATOR_DIAG=1'] if diag else []) + (NO_PK if s in NO_PK_SOURCES else []) + \
+            extra = os.environ.get('GATOR_HIPCC_FLAGS_' + s.rsplit('.', 1)[0], '').split()      # A/B builds of one source (e.g. -fno-slp-vectorize)
+            cmd = [hipcc] + FLAGS + extra + (['-DGATOR_DIAG=1'] if diag else []) + (NO_PK if s in NO_PK_SOURCES else []) + \
                 (['-x', 'hip', '-Rpass-analysis=kernel-resource-usage'] if is_hip else []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)

@@ -280,9 +280,12 @@ extern "C" int gator_create(const gator_tensor* tensors, int32_t n, const gator_
 // What a kernel left in the ctx's sticky status word (an EARLIER call's failure: nothing here synchronises).  Reported once, then cleared.
 static int take_device_status(gator_ctx* c, const char* fn) {
     const unsigned st = c->status_host ? __atomic_exchange_n(c->status_host, 0u, __ATOMIC_RELAXED) : 0u;
-    if (st == DEV_PERSIST_INCOMPLETE)
+    if (st == DEV_PERSIST_INCOMPLETE) {
+        fused_disable_persist(c);        // e.g. an XCD without workgroups (CU mask): its queue is never served.  The four-launch form has no such dependency.
         return fail(GATOR_EDEVICE, "%s: an earlier forward on this ctx did not complete its persistent MDR launch (a sample's stage tiles were never "
-                                   "finished: hang guard or an unserved queue); its vertices were set to NaN.  GATOR_MDR_PERSIST=0 selects the four-launch form", fn);
+                                   "finished: an XCD without workgroups, or the hang guard); the vertices of that forward are NaN.  This ctx now uses the "
+                                   "four-launch form of the MDR stages (same results); GATOR_MDR_PERSIST=0 selects it from the start", fn);
+    }
     if (st == DEV_NONFINITE)
         return fail(GATOR_EDEVICE, "%s: an earlier forward on this ctx produced non-finite or out-of-range coarse vertices (|vert431| must stay below 4094 m, "
                                    "and every activation that feeds a token-wise linear below 4094: they travel as fp16 planes of 16 x value).  "

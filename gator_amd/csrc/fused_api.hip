@@ -35,7 +35,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
                  o_q = take(9 * tiles / 2), o_k = take(9 * tiles / 2), o_v = take(9 * tiles / 2) /* THREE tile sets each (k_mdr_persist writes every set once per forward); q/k/v sized for X3 tiles (1.5x) */, o_jkv = take((size_t)cap * 12 * kTile),
                  o_hf = take((size_t)cap * kV * 32), o_lbf = take((size_t)cap * kV * kE), o_feat = take((size_t)cap * J * kC),
                  o_xout = take((size_t)cap * J * 3), o_pc = take((size_t)cap * J * 133),
-                 o_vcp3 = take(std::max(upsample_x3_vcp_elems(cap), upsample_x2_vcp_elems(cap)) / 2), o_lpart = take(gat_tail_part_floats(cap, J)), o_ctr = take(32 + (size_t)4 * cap);
+                 o_vcp3 = take(std::max(upsample_x3_vcp_elems(cap), upsample_x2_vcp_elems(cap)) / 2), o_lpart = take(gat_tail_part_floats(cap, J)), o_ctr = take(kMdrCtrHeader + (size_t)4 * cap);
     GATOR_HIP_CHECK(hipMalloc(&f->ws, n * sizeof(float)));
     GATOR_HIP_CHECK(hipMemset(f->ws, 0, n * sizeof(float)));
     GATOR_HIP_CHECK(hipDeviceSynchronize());      // the memset runs on the null stream; a non-blocking stream would not wait for it
@@ -133,7 +133,8 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
             if (f->gat_tiled_h4) {
                 float left = 0.f;
                 GATOR_HIP_CHECK(hipMalloc(&f->gxbuf_h3, (size_t)ntiles * kTileX3 * sizeof(float)));
-                rc = fused_repack_h3(f->gblk[0].qkv, f->gxbuf_h3, ntiles, &f->gat_tiled_wshift, &left, stream);
+                // the scale comes from the nine weight grids of each block (264 tiles), not from the mc / mdT / aoffT / f1b tables behind them
+                rc = fused_repack_h3(f->gblk[0].qkv, f->gxbuf_h3, ntiles, &f->gat_tiled_wshift, &left, stream, (int64_t)blk_tiles, 264);
                 if (rc == GATOR_OK && left > 1e-7f) rc = fail(GATOR_EUNSUPPORTED, "GAT weights span more than fp16 x 3 planes hold exactly: use GATOR_GAT_TILED_H4=0");
                 if (rc) return rc;
             }
@@ -224,6 +225,8 @@ int fused_create(gator_ctx* c, void* stream) {
     if (f->mdr_x3 < 0 || f->mdr_x3 > 2) return fail(GATOR_EINVAL, "GATOR_MDR_X3 must be 0, 1 or 2");
     const char* mper = getenv("GATOR_MDR_PERSIST");
     f->mdr_persist = mper ? (atoi(mper) != 0 ? 1 : 0) : -1;
+    const char* mpg = getenv("GATOR_MDR_PERSIST_GRID");
+    f->mdr_persist_grid = mpg ? atoi(mpg) : 0;
     const size_t n_up = f->x3 ? 0 : (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)64 * kTile;
     const size_t total = n_up + 3 * n_layer + 24 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
     GATOR_HIP_CHECK(hipMalloc(&f->wbuf, total * sizeof(float)));
@@ -587,6 +590,10 @@ int fused_set_joint_regressor(gator_ctx* c, const int32_t* row, const int32_t* c
     GATOR_HIP_CHECK(hipMemcpy(f->jr_rowptr, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice));
     f->jr_nnz = nnz; f->jr_nj = nj;
     return GATOR_OK;
+}
+
+void fused_disable_persist(gator_ctx* c) {
+    if (c->fused) c->fused->mdr_persist = 0;
 }
 
 int fused_set_encoder(gator_ctx* c, int mode) {

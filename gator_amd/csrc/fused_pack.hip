@@ -53,21 +53,31 @@ __global__ void k_repack_h3(const float* __restrict__ src, _Float16* __restrict_
     const float left = fabsf(r2 - (float)l);
     if (left > 0.f) atomicMax(res, __float_as_uint(left));
 }
-__global__ void k_absmax_tiles(const float* __restrict__ w, int64_t n, unsigned* __restrict__ out) {
+// max |w| over the tiles with (tile % period) < live (period 0: all of them)
+__global__ void k_absmax_tiles(const float* __restrict__ w, int64_t n, unsigned* __restrict__ out, int64_t period, int64_t live) {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (period == 0 || (i / kTile) % period < live) m = fmaxf(m, fabsf(w[i]));
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 }  // namespace
 
-int fused_repack_h3(const float* src_tiles, float* dst_tiles, int64_t ntiles, int* shift, float* residual, void* stream) {
+namespace {
+struct DevFree {        // temporaries of the pack routines: freed on every return path
+    void* p = nullptr;
+    ~DevFree() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+int fused_repack_h3(const float* src_tiles, float* dst_tiles, int64_t ntiles, int* shift, float* residual, void* stream, int64_t period, int64_t live) {
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = ntiles * kTile;
-    unsigned* d = nullptr;
-    GATOR_HIP_CHECK(hipMalloc(&d, 2 * sizeof(unsigned)));
+    DevFree tmp;
+    GATOR_HIP_CHECK(hipMalloc(&tmp.p, 2 * sizeof(unsigned)));
+    unsigned* d = (unsigned*)tmp.p;
     GATOR_HIP_CHECK(hipMemsetAsync(d, 0, 2 * sizeof(unsigned), st));
-    k_absmax_tiles<<<512, 256, 0, st>>>(src_tiles, total, d);
+    k_absmax_tiles<<<512, 256, 0, st>>>(src_tiles, total, d, period, live);
     unsigned bits[2] = {0, 0};
     GATOR_HIP_CHECK(hipMemcpyAsync(bits, d, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     GATOR_HIP_CHECK(hipStreamSynchronize(st));
@@ -85,7 +95,6 @@ int fused_repack_h3(const float* src_tiles, float* dst_tiles, int64_t ntiles, in
     GATOR_HIP_CHECK(hipGetLastError());
     GATOR_HIP_CHECK(hipMemcpyAsync(bits, d, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     GATOR_HIP_CHECK(hipStreamSynchronize(st));
-    (void)hipFree(d);
     float left;
     memcpy(&left, &bits[1], sizeof(left));
     *shift = sh;

@@ -8,6 +8,7 @@ constexpr int kVT = 14;                 // 32-token tiles per sample (431 -> 448
 constexpr int kOB = 216;                // 32-vertex output blocks of the upsample GEMM (6890 -> 6912)
 constexpr int kCB = 14;                 // 32-wide k blocks over the 431 coarse vertices
 constexpr int kTile = 32 * 32;          // floats in one packed 32x32 tile ([4 g][64 lanes][4])
+constexpr int kMdrCtrHeader = 32;       // words in front of k_mdr_persist's per-sample counts: [0..7] tickets per XCD, [8] error flag (mdr_fused.hip)
 
 struct MdrLayerP {                      // packed weights of one LBF layer (device pointers into FusedState::wbuf)
     const float *wq, *wk, *wv, *proj, *fc1, *fc2, *sa[4];
@@ -36,7 +37,7 @@ struct FusedWs {
     float *feat = nullptr, *xout = nullptr, *pc = nullptr;
     float *lpart = nullptr;             // [MT][J][2][kTile] lifter partial tiles (gat_tail.hip)
     bool mdr_ctr_clean = false;         // the joint-token kernel queued before launch_mdr has zeroed mdr_ctr for it
-    unsigned* mdr_ctr = nullptr;        // k_mdr_persist: [8] tickets per queue, [8] flags, [8] queue owners, [8] spare, [4][cap] tiles done per (stage, sample)
+    unsigned* mdr_ctr = nullptr;        // k_mdr_persist: kMdrCtrHeader words (tickets, flags), then [4][cap] tiles done per (stage, sample)
     void* vcp16 = nullptr;              // bf16 packed vert431 for the bf16 vertex GEMM (cap-sized)
     int vcp16_cap = 0;
 };
@@ -65,6 +66,7 @@ struct FusedState : FusedWs {
     int gat8_wshift = 0;                // its weight stream holds three fp16 planes of 2^gat8_wshift * w
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
     int mdr_persist = -1;               // the four MDR stages as ONE persistent launch (k_mdr_persist): -1 by batch size (launch_mdr), GATOR_MDR_PERSIST=0 never, =1 always
+    int mdr_persist_grid = 0;           // GATOR_MDR_PERSIST_GRID: workgroups of the persistent launch (0: two per CU)
     int mdr_wshift = 0;                 // GATOR_MDR_X3=2: wxbuf holds three fp16 planes of 2^mdr_wshift * w
     int mdr_x3 = 2;                     // GATOR_MDR_X3: 0 fp32-input MFMA; 1 exact bf16 x 3 split everywhere; 2 (default) that + the 431x431 attention on two fp16 planes
     bool x3 = true;                     // split-precision vertex regressor (GATOR_UPSAMPLE_X3=0: fp32-input MFMA kernel)

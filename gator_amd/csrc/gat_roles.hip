@@ -228,7 +228,7 @@ __device__ __forceinline__ void glds4(const float* gsrc, const float* lds_dst) {
 // the twelve MFMAs (k_gat's form) the six 1 KiB loads hold the in-order wave at the memory pipeline's issue rate while the matrix
 // pipe idles: measured here as 3.2k cycles per 4-tile unit against 1.5k of MFMA time.  sched_barrier pins the order.
 template <bool CL>
-__device__ __forceinline__ void tile_mma_refill(X3& w, const X3& b, f32x16& acc, const float* __restrict__ wp, int lane) {
+__device__ __forceinline__ void tile_mma_refill(X3& w, const X3& b, f32x16& acc, f32x16& /* six-product form: one accumulator */, const float* __restrict__ wp, int lane) {
     const bf16x8* q = reinterpret_cast<const bf16x8*>(wp) + lane;
 #define GAT8_MM(wpl, bpl, s) acc = CL ? GATOR_MFMA_BF16(b.p[bpl][s], w.p[wpl][s], acc) : GATOR_MFMA_BF16(w.p[wpl][s], b.p[bpl][s], acc)
 #pragma unroll
@@ -252,23 +252,26 @@ __device__ __forceinline__ void tile_mma_refill(X3& w, const X3& b, f32x16& acc,
 #undef GAT8_MM
 }
 // The four-product form (x3_common.h: weights exact on three fp16 planes, activations on two): w_hi a_lo | w_lo a_hi, w_mid a_hi,
-// w_hi a_hi -- 8 MFMAs per tile; the refill of a plane still follows the last MFMA that reads it.
+// w_hi a_hi -- 8 MFMAs per tile; the refill of a plane still follows the last MFMA that reads it.  The three cross products go to
+// their OWN accumulator `acs` (2^-11 of the result: its roundings do not matter), so the main one is rounded twice per tile instead of
+// eight times -- every MFMA rounds its accumulator at the accumulator's magnitude, and in-product accumulation is where the path's
+// fp32 noise comes from (x3_common.h, x2_mma).  unit4 adds the two once, in the product wave's idle vector slots.
 template <bool CL>
-__device__ __forceinline__ void tile_mma_refill(H3& w, const X2& b, f32x16& acc, const float* __restrict__ wp, int lane) {
+__device__ __forceinline__ void tile_mma_refill(H3& w, const X2& b, f32x16& acc, f32x16& acs, const float* __restrict__ wp, int lane) {
     const f16x8* q = reinterpret_cast<const f16x8*>(wp) + lane;
-#define GAT8_MM(wpl, bpl, s) acc = CL ? GATOR_MFMA_F16(b.p[bpl][s], w.p[wpl][s], acc) : GATOR_MFMA_F16(w.p[wpl][s], b.p[bpl][s], acc)
+#define GAT8_MM(wpl, bpl, s, AC) AC = CL ? GATOR_MFMA_F16(b.p[bpl][s], w.p[wpl][s], AC) : GATOR_MFMA_F16(w.p[wpl][s], b.p[bpl][s], AC)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        GAT8_MM(0, 1, s);                                  // w hi  * a lo
-        GAT8_MM(2, 0, s);                                  // w lo  * a hi
+        GAT8_MM(0, 1, s, acs);                             // w hi  * a lo
+        GAT8_MM(2, 0, s, acs);                             // w lo  * a hi
         __builtin_amdgcn_sched_barrier(0);
         w.p[2][s] = q[(2 * 2 + s) * 64];
         __builtin_amdgcn_sched_barrier(0);
-        GAT8_MM(1, 0, s);                                  // w mid * a hi
+        GAT8_MM(1, 0, s, acs);                             // w mid * a hi
         __builtin_amdgcn_sched_barrier(0);
         w.p[1][s] = q[(1 * 2 + s) * 64];
         __builtin_amdgcn_sched_barrier(0);
-        GAT8_MM(0, 0, s);                                  // w hi  * a hi
+        GAT8_MM(0, 0, s, acc);                             // w hi  * a hi
         __builtin_amdgcn_sched_barrier(0);
         w.p[0][s] = q[(0 * 2 + s) * 64];
         __builtin_amdgcn_sched_barrier(0);
@@ -296,25 +299,27 @@ template <int S0, bool CL, class WT, class OT>
 __device__ __forceinline__ void unit4(WT (&W)[kNT], const float* __restrict__& wp, OT b, const float* o1, const float* o2, const float* o3,
                                       float* raw, int lane) {
     const float* ops[4] = {o1, o1, o2, o3};
-    f32x16 acc = zero16();
+    f32x16 acc = zero16(), acs = zero16();
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         OT bn = b;
         if (kb < 3) ld_tile(bn, ops[kb + 1], lane);
-        tile_mma_refill<CL>(W[(S0 + kb) % kNT], b, acc, wp, lane);
+        tile_mma_refill<CL>(W[(S0 + kb) % kNT], b, acc, acs, wp, lane);
         wp += kTileX3;
         b = bn;
     }
+    if constexpr (std::is_same<WT, H3>::value) acc = acc + acs;
     store_block(raw, lane, acc);
 }
 // one tile: partial hop-2 linear (linears[1], 128 -> 16) over k block `w` of SB; C-layout
 template <int S0, class OT, class WT>
 __device__ __forceinline__ void unit1(WT (&W)[kNT], const float* __restrict__& wp, const float* o0, float* raw, int lane) {
-    f32x16 acc = zero16();
+    f32x16 acc = zero16(), acs = zero16();
     OT b;
     ld_tile(b, o0, lane);
-    tile_mma_refill<true>(W[S0 % kNT], b, acc, wp, lane);
+    tile_mma_refill<true>(W[S0 % kNT], b, acc, acs, wp, lane);
     wp += kTileX3;
+    if constexpr (std::is_same<WT, H3>::value) acc = acc + acs;
     store_block(raw, lane, acc);
 }
 
@@ -839,25 +844,24 @@ int gat8_build_stream(FusedState* f, void* stream) {
         }
         if (o - idx.data() != (ptrdiff_t)(w + 1) * kWaveTiles) return fail(GATOR_EINVAL, "gat8_build_stream: tile count");
     }
-    int* d_idx = nullptr;
-    GATOR_HIP_CHECK(hipMalloc(&d_idx, idx.size() * sizeof(int)));
+    struct DevFree { void* p = nullptr; ~DevFree() { if (p) (void)hipFree(p); } } t_idx, t_h3;      // temporaries: freed on every return path
+    GATOR_HIP_CHECK(hipMalloc(&t_idx.p, idx.size() * sizeof(int)));
+    int* d_idx = (int*)t_idx.p;
     GATOR_HIP_CHECK(hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
     GATOR_HIP_CHECK(hipMalloc(&f->g8stream, (size_t)kStreamFloats * sizeof(float)));
-    float* h3 = nullptr;
     if (f->gat8_h4) {      // the four-product form streams three fp16 planes of 2^shift * w: the fp32 tiles are put in stream order
         float left = 0.f;  // first, so that the shift comes from exactly the weights the kernel multiplies (not the tables in between)
-        GATOR_HIP_CHECK(hipMalloc(&h3, idx.size() * kTile * sizeof(float)));
+        GATOR_HIP_CHECK(hipMalloc(&t_h3.p, idx.size() * kTile * sizeof(float)));
+        float* h3 = (float*)t_h3.p;
         k_gather_tiles<kTile><<<(unsigned)idx.size(), 128, 0, (hipStream_t)stream>>>(f->gblk[0].qkv, d_idx, h3);
         int rc = fused_repack_h3(h3, f->g8stream, (int64_t)idx.size(), &f->gat8_wshift, &left, stream);
         if (rc == GATOR_OK && left > 1e-7f) rc = fail(GATOR_EUNSUPPORTED, "GAT weights span more than fp16 x 3 planes hold exactly: use GATOR_GAT8_H4=0");
-        if (rc) { (void)hipFree(h3); (void)hipFree(d_idx); return rc; }
+        if (rc) return rc;
     } else {
         k_gather_tiles<kTileX3><<<(unsigned)idx.size(), 128, 0, (hipStream_t)stream>>>(f->gxbuf, d_idx, f->g8stream);
     }
     GATOR_HIP_CHECK(hipGetLastError());
     GATOR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    GATOR_HIP_CHECK(hipFree(d_idx));
-    if (h3) GATOR_HIP_CHECK(hipFree(h3));
     return GATOR_OK;
 }
 

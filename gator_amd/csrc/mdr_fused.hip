@@ -116,8 +116,13 @@ __device__ __forceinline__ void linear64_T(const float* __restrict__ Wp, const f
 // a wave of back-to-back MFMAs makes NO progress at equal priority, full speed at priority 1 - and the MFMAs still issue every 32
 // cycles).  So a wave raises its priority while it runs VALU sections (softmax, splits, LayerNorm, GELU) and drops it for its
 // MFMA bursts: whoever has vector work gets the issue slots, the matrix pipe is fed from the gaps.
+#ifdef GATOR_AB_NO_PRIO
+#define MDR_PRIO_VALU()
+#define MDR_PRIO_MFMA()
+#else
 #define MDR_PRIO_VALU() __builtin_amdgcn_s_setprio(1)
 #define MDR_PRIO_MFMA() __builtin_amdgcn_s_setprio(0)
+#endif
 #define MDR_PIN()                            \
     do {                                     \
         asm volatile("" ::: "memory");       \
@@ -259,7 +264,12 @@ __device__ __forceinline__ f32x16 self_attention_head_x3(const float* __restrict
 // scaled by 16 and the probabilities carry an extra 2^6 (so that their low plane stays a normal fp16 number); both cancel in
 // O / (16 l).
 constexpr float kX2QK = 16.0f, kX2V = 16.0f;
-#define ATTN_TILE_X2(KT, KB, VB, OACC)                                                                      \
+#ifdef GATOR_AB_OLD_PV
+#define ATTN_PV(VB, PX) { if (pv_flip_) O2 = x2_mma(VB, PX, O2); else O = x2_mma(VB, PX, O); pv_flip_ = !pv_flip_; }
+#else
+#define ATTN_PV(VB, PX) { O2 = x2_mma_small(VB, PX, O2); O = x2_mma_main(VB, PX, O); }
+#endif
+#define ATTN_TILE_X2(KT, KB, VB)                                                                            \
     {                                                                                                       \
         MDR_PRIO_MFMA();                                                                                    \
         f32x16 S = x2_mma(KB, qx, zero16());  /* 256 x S^T[key][query] */                                   \
@@ -290,7 +300,9 @@ constexpr float kX2QK = 16.0f, kX2V = 16.0f;
         l += ps;                                                                                            \
         const X2 px_ = x2_split(S);                                                                         \
         MDR_PRIO_MFMA();                                                                                    \
-        OACC = x2_mma(VB, px_, OACC);   /* O^T[d][query] += V^T[d][key] P^T[key][query] */                  \
+        /* O^T[d][query] += V^T[d][key] P^T[key][query]: the hi*hi products of every key tile into O, the cross products (2^-11 of    \
+           it) into O2 -- O is rounded 28 times at full magnitude over the 14 tiles instead of 42 times for each of two equal halves */ \
+        ATTN_PV(VB, px_)                                                                                    \
     }
 __device__ __forceinline__ f32x16 self_attention_head_x2(const float* __restrict__ qt, const float* __restrict__ kbase,
                                                          const float* __restrict__ vbase, int lane) {
@@ -298,21 +310,23 @@ __device__ __forceinline__ f32x16 self_attention_head_x2(const float* __restrict
     const X2 qx = x2_load(qt, lane);
     f32x16 O = zero16(), O2 = zero16();
     float m = -1e30f, l = 0.f;
+    bool pv_flip_ = false;
+    (void)pv_flip_;
     X2 kb = x2_load(kbase, lane), vb = x2_load(vbase, lane);
-    // tiles kt (-> O) and kt + 1 (-> O2), the next tile's K/V in flight.  The last pair is peeled so that the mask of the 17 keys that
+    // tiles kt and kt + 1 per trip, the next tile's K/V in flight.  The last pair is peeled so that the mask of the 17 keys that
     // do not exist (431 = 13 x 32 + 15) is compile-time there and absent from the loop (it cost 5 selects per tile as a runtime test).
 #pragma unroll 1
     for (int kt = 0; kt < kVT - 2; kt += 2) {
         X2 kn = x2_load(kbase + (size_t)(kt + 1) * 2 * kTile, lane), vn = x2_load(vbase + (size_t)(kt + 1) * 2 * kTile, lane);
-        ATTN_TILE_X2(0, kb, vb, O)
+        ATTN_TILE_X2(0, kb, vb)
         kb = x2_load(kbase + (size_t)(kt + 2) * 2 * kTile, lane);
         vb = x2_load(vbase + (size_t)(kt + 2) * 2 * kTile, lane);
-        ATTN_TILE_X2(0, kn, vn, O2)
+        ATTN_TILE_X2(0, kn, vn)
     }
     {
         X2 kn = x2_load(kbase + (size_t)(kVT - 1) * 2 * kTile, lane), vn = x2_load(vbase + (size_t)(kVT - 1) * 2 * kTile, lane);
-        ATTN_TILE_X2(kVT - 2, kb, vb, O)
-        ATTN_TILE_X2(kVT - 1, kn, vn, O2)
+        ATTN_TILE_X2(kVT - 2, kb, vb)
+        ATTN_TILE_X2(kVT - 1, kn, vn)
     }
     l += xhalf(l);
     return (O + O2) * ((1.0f / kX2V) / l);
@@ -424,8 +438,18 @@ __device__ __forceinline__ W2H ldw2h(const float* __restrict__ Wx, int i0, int i
     w.t[1] = h3_load(Wx + (size_t)i1 * kTileX3, lane);
     return w;
 }
+// a 64-deep product: the twelve cross products of both tiles first (accumulator still at bias magnitude), the four hi*hi products last
+#ifdef GATOR_AB_OLD_LIN
 __device__ __forceinline__ f32x16 lin2_T(const W2H& w, const X2 (&x)[2], f32x16 init) { return h3_mma_wa(w.t[1], x[1], h3_mma_wa(w.t[0], x[0], init)); }
 __device__ __forceinline__ f32x16 lin2_C(const W2H& w, const X2 (&x)[2]) { return h3_mma_aw(x[1], w.t[1], h3_mma_aw(x[0], w.t[0], zero16())); }
+#else
+__device__ __forceinline__ f32x16 lin2_T(const W2H& w, const X2 (&x)[2], f32x16 init) {
+    return h3_mma_wa_main(w.t[1], x[1], h3_mma_wa_main(w.t[0], x[0], h3_mma_wa_small(w.t[1], x[1], h3_mma_wa_small(w.t[0], x[0], init))));
+}
+__device__ __forceinline__ f32x16 lin2_C(const W2H& w, const X2 (&x)[2]) {
+    return h3_mma_aw_main(x[1], w.t[1], h3_mma_aw_main(x[0], w.t[0], h3_mma_aw_small(x[1], w.t[1], h3_mma_aw_small(x[0], w.t[0], zero16()))));
+}
+#endif
 
 template <int XA> struct TokOp;
 template <> struct TokOp<0> { typedef W2 W; typedef f32x16 A; };
@@ -777,14 +801,15 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
 //   * tickets are handed out in dependency order and a workgroup holds a ticket only while it runs, so every wait is for a unit
 //     that some running workgroup already owns: no deadlock whatever the residency.  A poll budget (~6 s) turns a would-be hang (a bug)
 //     into a flag in ctr[kCtrError] and garbage output instead of a dead GPU.
-// Which XCD serves a queue is decided at run time: a workgroup CLAIMS a queue (compare-and-swap on ctr[kCtrOwner + q]) before it
-// takes tickets from it, its own XCD's queue first.  Normally every queue is claimed by its own XCD within the first microsecond.  If
-// an XCD received no workgroup at all (a CU mask, reserved CUs, a partitioned device), its queue is still unowned when the others
-// have drained theirs, and the first XCD to get there adopts it -- ALL of it, so that a sample's tiles are still produced and
-// consumed through ONE L2 (the hand-off below has no cache maintenance and relies on exactly that).  Workgroups of any other XCD
-// leave an owned queue alone.  No sample is left uncomputed whatever the placement; only locality depends on it.
-constexpr int kCtrError = 8, kCtrOwner = 16, kCtrDone = 32;   // ctr: [0..7] tickets per queue, [8] error flag, [16..23] owner (1 + XCD) per queue,
-                                                              //      [32 + stage * B + b] tiles done, stage 0..3
+// What if an XCD gets no workgroup (a CU mask, reserved CUs, a partitioned device)?  Its queue is never served and nobody waits for it.
+// That must not be silent: EVERY stage counts its finished tiles per sample (the last one too), k_mdr_head refuses a sample whose 14
+// head-feature tiles were not all written -- NaN vertices plus the ctx's sticky status word -- and the host side answers the report
+// (GATOR_EDEVICE at the next call, api.hip) by switching that ctx to the four-launch form for good.  (Serving foreign queues instead
+// was built and measured in round 4: a workgroup claimed a queue by compare-and-swap, its own first, then any unowned one, so that an
+// orphan queue was adopted as a whole by ONE other XCD.  Correct in every placement tried -- grids of 1, 3, 5, 13 workgroups -- but with
+// the queue loop around the three ticket loops hipcc lays the tile bodies out differently and the launch takes 423 us instead of 385
+// even when the loop runs once; a second, cold copy of the body spills 2 KB per lane.  Not worth 10 % of the dominant kernel.)
+constexpr int kCtrError = 8, kCtrDone = kMdrCtrHeader;       // ctr: [0..7] tickets per XCD, [8] error flag, [kCtrDone + stage * B + b] tiles done, stage 0..3
 struct MdrPersistArgs {
     MdrArgs st[4];
     unsigned* ctr;
@@ -796,88 +821,76 @@ __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) 
     __shared__ int s_unit;
     const int B = p.st[0].B, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned xcc;                                                // the XCD this workgroup REALLY runs on
+    unsigned xcc;                                                // the XCD this workgroup REALLY runs on picks its queue
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const int xcd = (int)(xcc & 7u);
+    const int nb = xcd < B ? (B - xcd + 7) >> 3 : 0;            // samples of this XCD: xcd, xcd + 8, ...
+    const int ntile = nb * kVT, units = (ntile + 3) >> 2;       // per stage
+    if (units == 0) return;
+    auto ticket = [&]() {
+        __syncthreads();                                        // everyone is done with s_unit (and, at a stage change, with VT)
+        if (threadIdx.x == 0) s_unit = (int)atomicAdd(p.ctr + xcd, 1u);
+        __syncthreads();
+        return __builtin_amdgcn_readfirstlane(s_unit);          // a scalar: stage, tile and sample ids stay out of the VGPRs
+    };
     int staged = -1;                                            // the stage whose channel vectors are in VT
-#pragma unroll 1
-    for (int qi = 0; qi < 8; ++qi) {
-        const int q = (xcd + qi) & 7;                           // queue q: samples q, q + 8, ...; own XCD's first
-        const int nb = q < B ? (B - q + 7) >> 3 : 0;
-        const int ntile = nb * kVT, units = (ntile + 3) >> 2;   // per stage
-        if (units == 0) continue;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned me = 1u + (unsigned)xcd, prev = atomicCAS(p.ctr + kCtrOwner + q, 0u, me);
-            s_unit = (prev == 0u || prev == me) ? 1 : 0;
-        }
-        __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(s_unit) == 0) continue;      // another XCD serves this queue
-        auto ticket = [&]() {
-            __syncthreads();                                    // everyone is done with s_unit (and, at a stage change, with VT)
-            if (threadIdx.x == 0) s_unit = (int)atomicAdd(p.ctr + q, 1u);
+    // one ticket: (stage the channel vectors,) wait for the sample's previous stage, run the tile, publish it
+    auto run = [&](auto mode, int stage, int unit) {
+        constexpr int MODE = decltype(mode)::value;
+        // the stage's arguments (p.st[stage]) through a pointer into the kernel-argument segment that the optimiser cannot see
+        // through: otherwise every argument load of the body is loop-invariant, hoisted in front of the ticket loop and held in
+        // SGPRs across it (106 SGPRs, spills into VGPRs, scratch)
+        typedef const __attribute__((address_space(4))) MdrArgs* KArgPtr;
+        typedef const __attribute__((address_space(4))) char* KBytePtr;
+        unsigned aoff = (unsigned)offsetof(MdrPersistArgs, st) + (unsigned)__builtin_amdgcn_readfirstlane(stage) * (unsigned)sizeof(MdrArgs);
+        asm volatile("" : "+s"(aoff));
+        KArgPtr ap = (KArgPtr)((KBytePtr)__builtin_amdgcn_kernarg_segment_ptr() + aoff);
+        const MdrArgs& a = *(const MdrArgs*)ap;
+        const int lt = 4 * (unit - stage * units) + wave;
+        const bool live = lt < ntile;                           // (wave-uniform) a ticket's last waves may have nothing left
+        const int smp = xcd + 8 * (lt / kVT), id = smp * kVT + lt % kVT;
+        // the completion count of the sample's previous stage is requested FIRST: its L2 round trip (1 - 2 us under load, once per
+        // tile) hides behind the staging below instead of standing in front of the tile
+        const unsigned* d = p.ctr + kCtrDone + (size_t)(MODE > 0 ? stage - 1 : 0) * B + smp;
+        unsigned seen = kVT;
+        if (MODE > 0 && live && lane == 0) seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (staged != stage) {                                  // tickets come in stage order: at most four times per workgroup
+            mdr_stage_vectors<MODE, XA>(a, VT);
+            staged = stage;
             __syncthreads();
-            return __builtin_amdgcn_readfirstlane(s_unit);      // a scalar: stage, tile and sample ids stay out of the VGPRs
-        };
-        // one ticket: (stage the channel vectors,) wait for the sample's previous stage, run the tile, publish it
-        auto run = [&](auto mode, int stage, int unit) {
-            constexpr int MODE = decltype(mode)::value;
-            // the stage's arguments (p.st[stage]) through a pointer into the kernel-argument segment that the optimiser cannot see
-            // through: otherwise every argument load of the body is loop-invariant, hoisted in front of the ticket loop and held in
-            // SGPRs across it (106 SGPRs, spills into VGPRs, scratch)
-            typedef const __attribute__((address_space(4))) MdrArgs* KArgPtr;
-            typedef const __attribute__((address_space(4))) char* KBytePtr;
-            unsigned aoff = (unsigned)offsetof(MdrPersistArgs, st) + (unsigned)__builtin_amdgcn_readfirstlane(stage) * (unsigned)sizeof(MdrArgs);
-            asm volatile("" : "+s"(aoff));
-            KArgPtr ap = (KArgPtr)((KBytePtr)__builtin_amdgcn_kernarg_segment_ptr() + aoff);
-            const MdrArgs& a = *(const MdrArgs*)ap;
-            const int lt = 4 * (unit - stage * units) + wave;
-            const bool live = lt < ntile;                       // (wave-uniform) a ticket's last waves may have nothing left
-            const int smp = q + 8 * (lt / kVT), id = smp * kVT + lt % kVT;
-            // the completion count of the sample's previous stage is requested FIRST: its L2 round trip (1 - 2 us under load, once per
-            // tile) hides behind the staging below instead of standing in front of the tile
-            const unsigned* d = p.ctr + kCtrDone + (size_t)(MODE > 0 ? stage - 1 : 0) * B + smp;
-            unsigned seen = kVT;
-            if (MODE > 0 && live && lane == 0) seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (staged != stage) {                              // tickets come in stage order: at most four times per queue
-                mdr_stage_vectors<MODE, XA>(a, VT);
-                staged = stage;
-                __syncthreads();
-            }
-            if (!live) return;
-            if (MODE > 0) {
-                if (lane == 0) {
-                    int budget = 1 << 24;                       // ~6 s of polling
-                    while (seen < (unsigned)kVT && --budget > 0) {
-                        __builtin_amdgcn_s_sleep(8);
-                        seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (budget <= 0) atomicExch(p.ctr + kCtrError, 1u + stage);
-                }
-                // Acquire among CUs that share an L2, with NO cache invalidate: every tile of the three tile sets is written exactly once
-                // per launch (launch_mdr) and read only behind its completion count, and the L1 starts a launch empty, so neither
-                // the L1 nor the L2 can hold an older copy of what is read from here on.  (The agent-scope fence pair instead --
-                // `buffer_wbl2 sc1` / `buffer_inv sc1` at each of ~10k tile starts -- measured +240 us per forward; `buffer_inv sc1`
-                // alone +30 us.)  The compiler barrier keeps the tile's loads behind the poll.
-                asm volatile("" ::: "memory");
-            }
-            mdr_tile<MODE, XA>(a, id, VT, park);
-            // Release to the same L2: the L1 is write-through, so once the stores are acknowledged (vmcnt 0) every CU of the XCD
-            // sees them; then the count goes up (an atomic executed in that L2).  The last stage counts too: k_mdr_head refuses a
-            // sample whose 14 head-feature tiles were not all written (launch_mdr).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(p.ctr + kCtrDone + (size_t)stage * B + smp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        // Tickets come in stage order, so within a queue a workgroup's stages only ever go up: three plain loops, one tile body each
-        // (one loop with a switch keeps all three bodies' state alive at once: 256 VGPRs + 760 B of scratch).
-        int unit = ticket();
-        for (; unit < units; unit = ticket()) run(std::integral_constant<int, 0>(), 0, unit);
-        for (; unit < 3 * units; unit = ticket()) {
-            const int stage = unit >= 2 * units ? 2 : 1;
-            run(std::integral_constant<int, 1>(), stage, unit);
         }
-        for (; unit < 4 * units; unit = ticket()) run(std::integral_constant<int, 2>(), 3, unit);
+        if (!live) return;
+        if (MODE > 0) {
+            if (lane == 0) {
+                int budget = 1 << 24;                           // ~6 s of polling
+                while (seen < (unsigned)kVT && --budget > 0) {
+                    __builtin_amdgcn_s_sleep(8);
+                    seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (budget <= 0) atomicExch(p.ctr + kCtrError, 1u + stage);
+            }
+            // Acquire among CUs that share an L2, with NO cache invalidate: every tile of the three tile sets is written exactly once
+            // per launch (launch_mdr) and read only behind its completion count, and the L1 starts a launch empty, so neither
+            // the L1 nor the L2 can hold an older copy of what is read from here on.  (The agent-scope fence pair instead --
+            // `buffer_wbl2 sc1` / `buffer_inv sc1` at each of ~10k tile starts -- measured +240 us per forward; `buffer_inv sc1`
+            // alone +30 us.)  The compiler barrier keeps the tile's loads behind the poll.
+            asm volatile("" ::: "memory");
+        }
+        mdr_tile<MODE, XA>(a, id, VT, park);
+        // Release to the same L2: the L1 is write-through, so once the stores are acknowledged (vmcnt 0) every CU of the XCD
+        // sees them; then the count goes up (an atomic executed in that L2).  The last stage counts too (for k_mdr_head, see above).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(p.ctr + kCtrDone + (size_t)stage * B + smp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // Tickets come in stage order, so a workgroup's stages only ever go up: three plain loops, one tile body each (one loop with a
+    // switch keeps all three bodies' state alive at once: 256 VGPRs + 760 B of scratch).
+    int unit = ticket();
+    for (; unit < units; unit = ticket()) run(std::integral_constant<int, 0>(), 0, unit);
+    for (; unit < 3 * units; unit = ticket()) {
+        const int stage = unit >= 2 * units ? 2 : 1;
+        run(std::integral_constant<int, 1>(), stage, unit);
     }
+    for (; unit < 4 * units; unit = ticket()) run(std::integral_constant<int, 2>(), 3, unit);
 }
 
 // Joint tokens: jf = Linear(133->64)(pose_combine) + pos_j (MDR.py:130-134); per layer k = wk(LN1(jf)), v = wv(LN1(jf))
@@ -899,8 +912,8 @@ __global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     if (a.mdr_ctr) {
-        if (t < 4) a.mdr_ctr[32 + (size_t)t * gridDim.x + b] = 0u;      // kCtrDone
-        if (b == 0 && t >= 64 && t < 96) a.mdr_ctr[t - 64] = 0u;         // tickets, error flag, queue owners
+        if (t < 4) a.mdr_ctr[kCtrDone + (size_t)t * gridDim.x + b] = 0u;
+        if (b == 0 && t >= 64 && t < 80) a.mdr_ctr[t - 64] = 0u;        // tickets, error flag
     }
     for (int e = t; e < 5 * kTile; e += 128) {
         const int j4 = e & 3, ln = (e >> 2) & 63, g = (e >> 8) & 3, kb = e >> 10;
@@ -1152,7 +1165,10 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     const double R = (double)nwg / f->n_cu;
     const bool auto_persist = R >= 3.0 && (std::ceil(R) - R) / R >= 0.04;
     bool persist = f->mdr_persist < 0 ? auto_persist : f->mdr_persist > 0;
-    // (any device shape drains all eight queues: a queue whose own XCD has no workgroup is adopted by another one, k_mdr_persist)
+    // the queues are per XCD and a workgroup serves the queue of the XCD it runs on: that drains every queue only when the device is
+    // the whole 8-XCD part (a partitioned device shows fewer CUs; its workgroups would all sit on one XCD).  A placement that leaves
+    // an XCD empty anyway is caught by k_mdr_head (completion counts) and answered by api.hip (four launches from then on).
+    if (f->n_cu != 256 && f->mdr_persist < 0) persist = false;
 #ifdef GATOR_DIAG
     if (want_stamps) persist = false;       // the stamps describe the per-stage launches
 #endif
@@ -1191,8 +1207,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         if (!ctr_clean) GATOR_HIP_CHECK(hipMemsetAsync(f->mdr_ctr, 0, (kCtrDone + (size_t)4 * B) * sizeof(unsigned), st));
         StageTimer tm(c, "mdr_layers", stream);
         int grid = 2 * f->n_cu;             // two workgroups per CU is what the registers allow; any grid drains the queues
-        static const int env_grid = getenv("GATOR_MDR_PERSIST_GRID") ? atoi(getenv("GATOR_MDR_PERSIST_GRID")) : 0;      // tests: a grid that leaves XCDs empty
-        if (env_grid > 0) grid = env_grid;
+        if (f->mdr_persist_grid > 0) grid = f->mdr_persist_grid;      // GATOR_MDR_PERSIST_GRID (tests: a grid that leaves XCDs without a workgroup)
         if (f->mdr_x3 == 2) k_mdr_persist<2><<<grid, 256, 0, st>>>(pa);
         else if (f->mdr_x3 == 1) k_mdr_persist<1><<<grid, 256, 0, st>>>(pa);
         else k_mdr_persist<0><<<grid, 256, 0, st>>>(pa);

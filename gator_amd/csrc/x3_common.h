@@ -114,6 +114,25 @@ __device__ __forceinline__ void x2_store(float* __restrict__ tile, int lane, con
 #pragma unroll
         for (int s = 0; s < 2; ++s) q[(pl * 2 + s) * 64] = v.p[pl][s];
 }
+// Order of the partial products (round 4).  Every MFMA rounds the fp32 accumulator once AT THE ACCUMULATOR'S MAGNITUDE, whatever the
+// size of what it adds; in-product accumulation is where this path's fp32 noise comes from (profiles/r04_error_budget.md: rounding
+// only the tensors an op writes gives a quarter of it).  So the cross products (2^-11 of the result) of ALL k-steps go first, while the
+// accumulator is still small, and the hi*hi products last: a fresh 32-deep product then rounds twice at full magnitude instead of six
+// times.  Same instructions, same count.
+__device__ __forceinline__ f32x16 x2_mma_small(const X2& A, const X2& B, f32x16 acc) {      // the four cross products only
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        acc = GATOR_MFMA_F16(A.p[1][s], B.p[0][s], acc);      // lo*hi
+        acc = GATOR_MFMA_F16(A.p[0][s], B.p[1][s], acc);      // hi*lo
+    }
+    return acc;
+}
+__device__ __forceinline__ f32x16 x2_mma_main(const X2& A, const X2& B, f32x16 acc) {       // the two hi*hi products only
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc = GATOR_MFMA_F16(A.p[0][s], B.p[0][s], acc);
+    return acc;
+}
+#ifdef GATOR_AB_OLD_ORDER
 __device__ __forceinline__ f32x16 x2_mma(const X2& A, const X2& B, f32x16 acc) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -123,6 +142,9 @@ __device__ __forceinline__ f32x16 x2_mma(const X2& A, const X2& B, f32x16 acc) {
     }
     return acc;
 }
+#else
+__device__ __forceinline__ f32x16 x2_mma(const X2& A, const X2& B, f32x16 acc) { return x2_mma_main(A, B, x2_mma_small(A, B, acc)); }
+#endif
 
 // ---- "4-product" token-wise linears (round 3, MDR with GATOR_MDR_X3=2): activations on TWO fp16 planes, weights on THREE ---------
 // The weight side dominates the error of a rounded linear because its rounding is the same for every token and sample (emulated in
@@ -145,33 +167,47 @@ __device__ __forceinline__ H3 h3_load(const float* __restrict__ tile, int lane) 
 }
 // two planes of scale * v (scale: a power of two that also carries whatever factor the producer left in v)
 __device__ __forceinline__ X2 x2_split_scaled(const f32x16& v, float scale) { return x2_split(v * scale); }
-// acc += W . a (rows of the result = the weight's lane index); small terms first
-__device__ __forceinline__ f32x16 h3_mma_wa(const H3& W, const X2& a, f32x16 acc) {
+// acc += W . a (rows of the result = the weight's lane index), in two parts so that a caller chaining several tiles into one
+// accumulator can run the cross products of ALL its tiles first and the hi*hi products last (see x2_mma)
+__device__ __forceinline__ f32x16 h3_mma_wa_small(const H3& W, const X2& a, f32x16 acc) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        acc = GATOR_MFMA_F16(W.p[0][s], a.p[1][s], acc);      // w hi  * a lo
         acc = GATOR_MFMA_F16(W.p[2][s], a.p[0][s], acc);      // w lo  * a hi
+        acc = GATOR_MFMA_F16(W.p[0][s], a.p[1][s], acc);      // w hi  * a lo
         acc = GATOR_MFMA_F16(W.p[1][s], a.p[0][s], acc);      // w mid * a hi
-        acc = GATOR_MFMA_F16(W.p[0][s], a.p[0][s], acc);      // w hi  * a hi
     }
     return acc;
 }
+__device__ __forceinline__ f32x16 h3_mma_wa_main(const H3& W, const X2& a, f32x16 acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc = GATOR_MFMA_F16(W.p[0][s], a.p[0][s], acc);      // w hi  * a hi
+    return acc;
+}
+__device__ __forceinline__ f32x16 h3_mma_wa(const H3& W, const X2& a, f32x16 acc) { return h3_mma_wa_main(W, a, h3_mma_wa_small(W, a, acc)); }
 // acc += a . W (rows of the result = the activation's lane index)
-__device__ __forceinline__ f32x16 h3_mma_aw(const X2& a, const H3& W, f32x16 acc) {
+__device__ __forceinline__ f32x16 h3_mma_aw_small(const X2& a, const H3& W, f32x16 acc) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        acc = GATOR_MFMA_F16(a.p[1][s], W.p[0][s], acc);
         acc = GATOR_MFMA_F16(a.p[0][s], W.p[2][s], acc);
+        acc = GATOR_MFMA_F16(a.p[1][s], W.p[0][s], acc);
         acc = GATOR_MFMA_F16(a.p[0][s], W.p[1][s], acc);
-        acc = GATOR_MFMA_F16(a.p[0][s], W.p[0][s], acc);
     }
     return acc;
 }
+__device__ __forceinline__ f32x16 h3_mma_aw_main(const X2& a, const H3& W, f32x16 acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc = GATOR_MFMA_F16(a.p[0][s], W.p[0][s], acc);
+    return acc;
+}
+__device__ __forceinline__ f32x16 h3_mma_aw(const X2& a, const H3& W, f32x16 acc) { return h3_mma_aw_main(a, W, h3_mma_aw_small(a, W, acc)); }
 
 // fused_pack.hip: fp32 packed tiles [g][lane][4] -> X3 tiles, same tile indices
 int fused_repack_x3(const float* src_tiles, float* dst_tiles, int64_t ntiles, void* stream);
-// ... -> H3 tiles (three fp16 planes of 2^shift * w); *shift is chosen from max|w| over all the tiles, *residual is the largest
-// |2^shift w - (hi + mid + lo)| relative to max|2^shift w| (0 unless a weight is more than 2^20 below the largest)
-int fused_repack_h3(const float* src_tiles, float* dst_tiles, int64_t ntiles, int* shift, float* residual, void* stream);
+// ... -> H3 tiles (three fp16 planes of 2^shift * w); *shift is chosen from max|w| over the tiles with (tile % period) < live (the
+// weight grids; period 0 = every tile), so that 2^13 <= max|2^shift w| < 2^14.  The three planes hold 2^shift w down to 2^-24
+// absolute, i.e. every weight to 2^-38 of the largest one ("exact" in this code base means that); *residual is the largest
+// |2^shift w - (hi + mid + lo)| relative to max|2^shift w| -- at most 2^-39 by construction, reported as a sanity value.
+int fused_repack_h3(const float* src_tiles, float* dst_tiles, int64_t ntiles, int* shift, float* residual, void* stream,
+                    int64_t period = 0, int64_t live = 0);
 
 }  // namespace gator

@@ -87,8 +87,8 @@ int gator_destroy(gator_ctx* ctx);
 
 /* Device-side validity of the forwards issued so far.  Kernels never synchronise the host, so a failure that only the device can
  * see -- non-finite / out-of-range coarse vertices (operand range above), or a persistent MDR launch that did not finish every
- * sample -- is recorded in a sticky, host-visible status word and reported by the NEXT entry point called on the ctx, once, as
- * GATOR_EDEVICE (the affected vertices are NaN).  gator_device_status reports it on demand; sync != 0 waits for the device first
+ * sample (an XCD without workgroups under a CU mask; the ctx then switches to the four-launch form for good) -- is recorded in a sticky,
+ * host-visible status word and reported by the NEXT entry point called on the ctx, once, as GATOR_EDEVICE (the affected vertices are NaN).  gator_device_status reports it on demand; sync != 0 waits for the device first
  * (the reference raises at the point of use, lib/core/base.py:210-237; this is the asynchronous equivalent). */
 int gator_device_status(gator_ctx* ctx, int32_t sync);
 

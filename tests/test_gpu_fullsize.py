@@ -36,6 +36,38 @@ def test_b256_accuracy_vs_fp64_oracle(setup):
     assert np.abs(p.cpu().numpy() - rp.numpy()).max() <= 1e-3
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('name,J', [('h36m17_bn', 17), ('coco19_alpha', 19)])
+def test_b4096_shipped_policy_every_coordinate_of_512_samples(name, J):
+    """B = 4 096 under the SHIPPED policy (no switch, no pin: two full rounds of the sample-tiled encoder + the remainder on the
+    one-sample-per-workgroup one), both variants: every coordinate of 512 oracle-checked samples -- 256 from the tiled rounds, 256
+    from the remainder -- within 1e-3 mm of the fp64 oracle, and not noisier than the reference's own fp32 arithmetic on the same
+    samples (the oracle in fp32: same ops, same order).  The statistics over 16k samples x 3 weight draws: profiles/r04_error_budget.md."""
+    from oracle import gator_oracle as go
+    z, m = build_model(name, 'fused')
+    x = torch.from_numpy(synthetic.synthetic_pose2d(4096, J, seed=4096 + J)).cuda()
+    v, p = m(x)
+    torch.cuda.synchronize()
+    m.device_status()
+    assert torch.isfinite(v).all()
+    idx = list(range(0, 256)) + list(range(4096 - 256, 4096))
+    zz, c, sd = oracle_setup(name)
+    xs = x[idx].cpu()
+    errs, refs = [], []
+    for lo in range(0, 512, 128):
+        r64, rp = go.gator_forward(sd, c, xs[lo:lo + 128], torch.float64)
+        r32, _ = go.gator_forward(sd, c, xs[lo:lo + 128], torch.float32)
+        errs.append(np.abs(v[idx[lo:lo + 128]].cpu().numpy().astype(np.float64) - r64.numpy()) * 1e3)
+        refs.append(np.abs(r32.numpy().astype(np.float64) - r64.numpy()) * 1e3)
+        assert np.abs(p[idx[lo:lo + 128]].cpu().numpy() - rp.numpy()).max() <= 1e-3
+    e, r = np.concatenate(errs), np.concatenate(refs)
+    rms = lambda a: float(np.sqrt((a ** 2).mean()))
+    print('\n[%s B=4096, 512 samples, %d coordinates] ours: max %.3e rms %.3e mm (tiled rounds %.3e, remainder %.3e) ; reference fp32 arithmetic: max %.3e rms %.3e mm'
+          % (name, e.size, e.max(), rms(e), e[:256].max(), e[256:].max(), r.max(), rms(r)))
+    assert e.max() <= 1e-3
+    assert rms(e) <= rms(r) and e.max() <= 1.25 * r.max()
+
+
 def test_deterministic_and_batch_independent(setup):
     m, x, v, p = setup
     v2, p2 = m(x)
