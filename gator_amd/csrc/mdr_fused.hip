@@ -72,21 +72,34 @@ __device__ __forceinline__ void layernorm64(const f32x16 (&x)[2], const float* _
     y[1] = d1 * rstd * load_chanvec_S(w, 32, h) + load_chanvec_S(b, 32, h);
 }
 
+// sum of squares of the 64 channel deviations of a token: four FMA chains per block instead of 32 products + 32 adds (and each term
+// rounded once instead of twice)
+__device__ __forceinline__ float row_sumsq64(const f32x16& a, const f32x16& b) {
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r & 3] = __builtin_fmaf(a[r], a[r], p[r & 3]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r & 3] = __builtin_fmaf(b[r], b[r], p[r & 3]);
+    const float s = (p[0] + p[1]) + (p[2] + p[3]);
+    return s + xhalf(s);
+}
+// nn.LayerNorm(64) with the affine part as one FMA per value: (d * rstd) * w + b.  w and b come from the workgroup's LDS table; when
+// the result only feeds 4-product linears the table holds 16 w and 16 b (mdr_stage_vectors), so the result IS the operand scale.
 __device__ __forceinline__ void layernorm64_L(const f32x16 (&x)[2], const float* w, const float* b, int h, f32x16 (&y)[2]) {
     const float mean = row_sum64(x[0], x[1]) * (1.0f / 64.0f);
     f32x16 d0 = x[0] - mean, d1 = x[1] - mean;
-    const float var = row_sum64(d0 * d0, d1 * d1) * (1.0f / 64.0f);
+    const float var = row_sumsq64(d0, d1) * (1.0f / 64.0f);
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    y[0] = d0 * rstd * chanvec_lds(w, 0, h) + chanvec_lds(b, 0, h);
-    y[1] = d1 * rstd * chanvec_lds(w, 32, h) + chanvec_lds(b, 32, h);
+    y[0] = __builtin_elementwise_fma(d0 * rstd, chanvec_lds(w, 0, h), chanvec_lds(b, 0, h));
+    y[1] = __builtin_elementwise_fma(d1 * rstd, chanvec_lds(w, 32, h), chanvec_lds(b, 32, h));
 }
 __device__ __forceinline__ void custom_ln64_L(f32x16 (&x)[2], const float* a2, const float* b2, int h) {
     const float mean = row_sum64(x[0], x[1]) * (1.0f / 64.0f);
     f32x16 d0 = x[0] - mean, d1 = x[1] - mean;
-    const float std = sqrtf(row_sum64(d0 * d0, d1 * d1) * (1.0f / 63.0f));
+    const float std = sqrtf(row_sumsq64(d0, d1) * (1.0f / 63.0f));
     const float inv = 1.0f / (std + 1e-6f);
-    x[0] = chanvec_lds(a2, 0, h) * d0 * inv + chanvec_lds(b2, 0, h);
-    x[1] = chanvec_lds(a2, 32, h) * d1 * inv + chanvec_lds(b2, 32, h);
+    x[0] = __builtin_elementwise_fma(chanvec_lds(a2, 0, h) * d0, f32x16(inv), chanvec_lds(b2, 0, h));
+    x[1] = __builtin_elementwise_fma(chanvec_lds(a2, 32, h) * d1, f32x16(inv), chanvec_lds(b2, 32, h));
 }
 
 // Annotated-Transformer LayerNorm: a_2 * (x - mean) / (std_unbiased + 1e-6) + b_2
@@ -304,6 +317,7 @@ constexpr float kX2QK = 16.0f, kX2V = 16.0f;
            it) into O2 -- O is rounded 28 times at full magnitude over the 14 tiles instead of 42 times for each of two equal halves */ \
         ATTN_PV(VB, px_)                                                                                    \
     }
+template <bool kActScale16>
 __device__ __forceinline__ f32x16 self_attention_head_x2(const float* __restrict__ qt, const float* __restrict__ kbase,
                                                          const float* __restrict__ vbase, int lane) {
     const int h = lane >> 5;
@@ -329,7 +343,7 @@ __device__ __forceinline__ f32x16 self_attention_head_x2(const float* __restrict
         ATTN_TILE_X2(kVT - 1, kn, vn)
     }
     l += xhalf(l);
-    return (O + O2) * ((1.0f / kX2V) / l);
+    return (O + O2) * (((kActScale16 ? 16.0f : 1.0f) / kX2V) / l);      // kActScale16: 16 x the head's output, the operand scale of the out-projection
 }
 
 // ---- cross-attention over the J joint tokens (keys/values precomputed per sample by k_mdr_joint) -------------------------
@@ -387,7 +401,7 @@ __device__ __forceinline__ f32x16 cross_attention_head_x2(const float* __restric
     }
     sum += xhalf(sum);
     const float inv = 64.0f / sum;                                         // probabilities x 64: low plane stays fp16-normal
-    return x2_mma(vx, x2_split(S * inv), zero16()) * (1.0f / 1024.0f);
+    return x2_mma(vx, x2_split(S * inv), zero16()) * (1.0f / 64.0f);      // 16 x the head's output: the operand scale of the projection that follows
 }
 
 // ---- weight stream of the tokenwise part: two buffers of one tile pair each (2 x 32 VGPRs).  The pair for the NEXT
@@ -490,6 +504,8 @@ __device__ __forceinline__ void mdr_stage_vectors(const MdrArgs& a, float* VT) {
             // 4-product linears return lin_s x their value: the biases that start or join their accumulators carry the factor too
             if (XA == 2 && (off < VO_N1W || (off >= VO_PROJB && off < VO_N2W) || (off >= VO_FC2B && off < VO_A2) || (off >= VO_SA0B && off < VO_TOKW3)))
                 v = v * a.lin_s;
+            // norm1 / norm2 only feed 4-product linears: their affine part carries the operand scale, so LayerNorm's FMA delivers 16 x value
+            if (XA == 2 && ((off >= VO_N1W && off < VO_PROJB) || (off >= VO_N2W && off < VO_FC2B))) v = v * kActScale;
             reinterpret_cast<f32x4*>(VT)[e] = v;
         }
     }
@@ -569,9 +585,9 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
     } else {
         f32x16 att[2];
         if constexpr (XA == 2) {
-            att[0] = self_attention_head_x2(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
+            att[0] = self_attention_head_x2<true>(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
                                     a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
-            att[1] = self_attention_head_x2(a.q_in + (tile + 1) * TQ, a.k_in + ((size_t)b * kVT * 2 + 1) * TQ,
+            att[1] = self_attention_head_x2<true>(a.q_in + (tile + 1) * TQ, a.k_in + ((size_t)b * kVT * 2 + 1) * TQ,
                                     a.v_in + ((size_t)b * kVT * 2 + 1) * TQ, lane);
         } else if constexpr (XA == 1) {
             att[0] = self_attention_head_x3(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
@@ -591,7 +607,9 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         MDR_PIN();
         MDR_STAMP(0)
         // linears[-1] + residual (vanilla_transformer_encoder.py:94, MDR.py:143)
-        const Act attx[2] = {mk<XA>(att[0]), mk<XA>(att[1])};
+        Act attx[2];
+        if constexpr (XA == 2) { attx[0] = x2_split(att[0]); attx[1] = x2_split(att[1]); }      // the heads come out at 16 x value already
+        else { attx[0] = mk<XA>(att[0]); attx[1] = mk<XA>(att[1]); }
         const f32x16 y0 = lin2_T(A, attx, chanvec_lds(VT, VO_SA3B, h));
         if (MODE == 1) A = ldw<XA>(w.wq, 0, 1, lane); else A = ldw<XA>(a.head_w, 0, 1, lane);
         MDR_PIN();
@@ -635,8 +653,8 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         {
             f32x16 fzf[2];
             layernorm64_L(vf, VT + VO_N1W, VT + VO_N1B, h, fzf);
-            fz[0] = mk<XA>(fzf[0]);
-            fz[1] = mk<XA>(fzf[1]);
+            if constexpr (XA == 2) { fz[0] = x2_split(fzf[0]); fz[1] = x2_split(fzf[1]); }      // already 16 x value (staged 16 w, 16 b)
+            else { fz[0] = mk<XA>(fzf[0]); fz[1] = mk<XA>(fzf[1]); }
         }
         const float* jb = a.jkv + (((size_t)b * 3 + a.layer) * 4) * kTile;       // [k/v][head] tiles
         q[0] = lin2_T(A, fz, zero16());
@@ -650,7 +668,9 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
             if constexpr (XA == 2) o[hd] = cross_attention_head_x2(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], 16.0f * inv, a.J, lane);
             else o[hd] = cross_attention_head(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], a.J, lane);
         }
-        const Act ox[2] = {mk<XA>(o[0]), mk<XA>(o[1])};
+        Act ox[2];
+        if constexpr (XA == 2) { ox[0] = x2_split(o[0]); ox[1] = x2_split(o[1]); }      // cross_attention_head_x2 returns 16 x value
+        else { ox[0] = mk<XA>(o[0]); ox[1] = mk<XA>(o[1]); }
         const f32x16 y0 = lin2_T(A, ox, chanvec_lds(VT, VO_PROJB, h));
         A = ldw<XA>(w.fc1, 0, 1, lane);                                            // MLP chunk 0: fc1 rows 0..31
         MDR_PIN();
@@ -667,8 +687,8 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         {
             f32x16 y2f[2];
             layernorm64_L(vf, VT + VO_N2W, VT + VO_N2B, h, y2f);
-            y2[0] = mk<XA>(y2f[0]);
-            y2[1] = mk<XA>(y2f[1]);
+            if constexpr (XA == 2) { y2[0] = x2_split(y2f[0]); y2[1] = x2_split(y2f[1]); }
+            else { y2[0] = mk<XA>(y2f[0]); y2[1] = mk<XA>(y2f[1]); }
         }
         if constexpr (X) {      // the residual stream waits in LDS while the MLP needs the registers
             park_vf(vf);
