@@ -455,6 +455,13 @@ extern "C" int gator_enable_block_taps(gator_ctx* c, int32_t on) {
     return GATOR_OK;
 }
 
+extern "C" int gator_encoder_for_batch(gator_ctx* c, int32_t B) {
+    if (!c || B <= 0) return fail(GATOR_EINVAL, "gator_encoder_for_batch: null ctx or batch <= 0");
+    if (c->impl == GATOR_IMPL_BASIC || !c->fused) return GATOR_ENCODER_SAMPLE;
+    const int n = fused_tiled_samples(c, B);
+    return n == 0 ? GATOR_ENCODER_SAMPLE : GATOR_ENCODER_TILED;      // a batch the policy splits between both counts as tiled (its full rounds are)
+}
+
 extern "C" int gator_set_encoder(gator_ctx* c, int32_t mode) {
     if (!c) return fail(GATOR_EINVAL, "gator_set_encoder: null ctx");
     if (c->impl != GATOR_IMPL_FUSED || !c->fused) return fail(GATOR_EUNSUPPORTED, "gator_set_encoder: fused ctx only");

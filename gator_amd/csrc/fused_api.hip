@@ -492,6 +492,24 @@ int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float*
     return rc;
 }
 
+// How many samples of a batch of B the sample-tiled encoder takes under the ctx's current policy (the rest goes to the
+// one-sample-per-workgroup kernel); also behind gator_encoder_for_batch, so that a caller pinning the encoder asks the library
+// instead of repeating the rule.
+int fused_tiled_samples(const gator_ctx* c, int B) {
+    const FusedState* f = c->fused;
+    int n_tiled = 0;
+    if (f && f->gat_x3 && f->gat_tiled != 0) {
+        if (f->gat_tiled == 1) n_tiled = B;
+        else if (B >= f->gat_tiled_min_batch) {
+            const int round = f->n_cu * gat_tiled_samples_per_wg(c->J);
+            n_tiled = (B / round) * round;
+            // the remainder: k_gat8 takes ~0.18 ms per n_cu samples (four partial products), a partial round of the tiled kernel ~0.85 ms
+            if (B - n_tiled > 4 * f->n_cu) n_tiled = B;
+        }
+    }
+    return n_tiled;
+}
+
 static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream, bool bf16, float* joints) {
     int rc = fused_ensure_ws(c, B);
     if (rc) return rc;
@@ -503,16 +521,7 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
     // Within one kernel results are bit-identical whatever the batch; between the two they agree to fp32 rounding noise
     // (tests/test_gpu_tiled.py), so above the threshold a sample's last bits depend on the batch size and its position in it.
     // GATOR_GAT_TILED=0 keeps every batch on k_gat (bitwise batch invariance at any size), =1 forces the tiled kernel.
-    int n_tiled = 0;
-    if (f->gat_x3 && f->gat_tiled != 0) {
-        if (f->gat_tiled == 1) n_tiled = B;
-        else if (B >= f->gat_tiled_min_batch) {
-            const int round = f->n_cu * gat_tiled_samples_per_wg(c->J);
-            n_tiled = (B / round) * round;
-            // the remainder: k_gat8 takes ~0.18 ms per n_cu samples (four partial products), a partial round of the tiled kernel ~0.85 ms
-            if (B - n_tiled > 4 * f->n_cu) n_tiled = B;
-        }
-    }
+    const int n_tiled = fused_tiled_samples(c, B);
     const bool tiled = n_tiled > 0;
     {   // x_out [B,3J] IS pose3d [B,J,3]: the tail writes the caller's buffer and produces the MDR joint K/V
         StageTimer tm(c, "gat", stream);

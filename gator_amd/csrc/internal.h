@@ -121,7 +121,8 @@ int fused_upsample_bf16(gator_ctx* c, const float* vert431, int B, float* verts,
 int fused_set_joint_regressor(gator_ctx* c, const int32_t* row, const int32_t* col, const float* val, int nnz, int nj);
 int fused_forward_joints(gator_ctx* c, const float* pose2d, int B, float* joints, float* pose3d, float* verts, void* stream);
 int fused_set_encoder(gator_ctx* c, int mode);
-void fused_disable_persist(gator_ctx* c);      // from now on the four MDR stages run as four launches on this ctx
+void fused_disable_persist(gator_ctx* c);
+int fused_tiled_samples(const gator_ctx* c, int B);     // samples of a batch of B that the sample-tiled encoder would take      // from now on the four MDR stages run as four launches on this ctx
 }  // namespace gator
 
 namespace gator {

@@ -129,13 +129,8 @@ __device__ __forceinline__ void linear64_T(const float* __restrict__ Wp, const f
 // a wave of back-to-back MFMAs makes NO progress at equal priority, full speed at priority 1 - and the MFMAs still issue every 32
 // cycles).  So a wave raises its priority while it runs VALU sections (softmax, splits, LayerNorm, GELU) and drops it for its
 // MFMA bursts: whoever has vector work gets the issue slots, the matrix pipe is fed from the gaps.
-#ifdef GATOR_AB_NO_PRIO
-#define MDR_PRIO_VALU()
-#define MDR_PRIO_MFMA()
-#else
 #define MDR_PRIO_VALU() __builtin_amdgcn_s_setprio(1)
 #define MDR_PRIO_MFMA() __builtin_amdgcn_s_setprio(0)
-#endif
 #define MDR_PIN()                            \
     do {                                     \
         asm volatile("" ::: "memory");       \
@@ -277,11 +272,7 @@ __device__ __forceinline__ f32x16 self_attention_head_x3(const float* __restrict
 // scaled by 16 and the probabilities carry an extra 2^6 (so that their low plane stays a normal fp16 number); both cancel in
 // O / (16 l).
 constexpr float kX2QK = 16.0f, kX2V = 16.0f;
-#ifdef GATOR_AB_OLD_PV
-#define ATTN_PV(VB, PX) { if (pv_flip_) O2 = x2_mma(VB, PX, O2); else O = x2_mma(VB, PX, O); pv_flip_ = !pv_flip_; }
-#else
 #define ATTN_PV(VB, PX) { O2 = x2_mma_small(VB, PX, O2); O = x2_mma_main(VB, PX, O); }
-#endif
 #define ATTN_TILE_X2(KT, KB, VB)                                                                            \
     {                                                                                                       \
         MDR_PRIO_MFMA();                                                                                    \
@@ -314,7 +305,9 @@ constexpr float kX2QK = 16.0f, kX2V = 16.0f;
         const X2 px_ = x2_split(S);                                                                         \
         MDR_PRIO_MFMA();                                                                                    \
         /* O^T[d][query] += V^T[d][key] P^T[key][query]: the hi*hi products of every key tile into O, the cross products (2^-11 of    \
-           it) into O2 -- O is rounded 28 times at full magnitude over the 14 tiles instead of 42 times for each of two equal halves */ \
+           it) into O2 -- O is rounded 28 times at full magnitude over the 14 tiles instead of 42 times for each of two equal halves.   \
+           (Measured and not taken: a third accumulator for the odd tiles' hi*hi products spills; the same split for the MLP's fc2      \
+           accumulators fits in exactly 256 registers, makes the launch 8 % slower and moves the error by nothing.) */                   \
         ATTN_PV(VB, px_)                                                                                    \
     }
 template <bool kActScale16>
@@ -324,8 +317,6 @@ __device__ __forceinline__ f32x16 self_attention_head_x2(const float* __restrict
     const X2 qx = x2_load(qt, lane);
     f32x16 O = zero16(), O2 = zero16();
     float m = -1e30f, l = 0.f;
-    bool pv_flip_ = false;
-    (void)pv_flip_;
     X2 kb = x2_load(kbase, lane), vb = x2_load(vbase, lane);
     // tiles kt and kt + 1 per trip, the next tile's K/V in flight.  The last pair is peeled so that the mask of the 17 keys that
     // do not exist (431 = 13 x 32 + 15) is compile-time there and absent from the loop (it cost 5 selects per tile as a runtime test).
@@ -453,17 +444,12 @@ __device__ __forceinline__ W2H ldw2h(const float* __restrict__ Wx, int i0, int i
     return w;
 }
 // a 64-deep product: the twelve cross products of both tiles first (accumulator still at bias magnitude), the four hi*hi products last
-#ifdef GATOR_AB_OLD_LIN
-__device__ __forceinline__ f32x16 lin2_T(const W2H& w, const X2 (&x)[2], f32x16 init) { return h3_mma_wa(w.t[1], x[1], h3_mma_wa(w.t[0], x[0], init)); }
-__device__ __forceinline__ f32x16 lin2_C(const W2H& w, const X2 (&x)[2]) { return h3_mma_aw(x[1], w.t[1], h3_mma_aw(x[0], w.t[0], zero16())); }
-#else
 __device__ __forceinline__ f32x16 lin2_T(const W2H& w, const X2 (&x)[2], f32x16 init) {
     return h3_mma_wa_main(w.t[1], x[1], h3_mma_wa_main(w.t[0], x[0], h3_mma_wa_small(w.t[1], x[1], h3_mma_wa_small(w.t[0], x[0], init))));
 }
 __device__ __forceinline__ f32x16 lin2_C(const W2H& w, const X2 (&x)[2]) {
     return h3_mma_aw_main(x[1], w.t[1], h3_mma_aw_main(x[0], w.t[0], h3_mma_aw_small(x[1], w.t[1], h3_mma_aw_small(x[0], w.t[0], zero16()))));
 }
-#endif
 
 template <int XA> struct TokOp;
 template <> struct TokOp<0> { typedef W2 W; typedef f32x16 A; };

@@ -132,19 +132,7 @@ __device__ __forceinline__ f32x16 x2_mma_main(const X2& A, const X2& B, f32x16 a
     for (int s = 0; s < 2; ++s) acc = GATOR_MFMA_F16(A.p[0][s], B.p[0][s], acc);
     return acc;
 }
-#ifdef GATOR_AB_OLD_ORDER
-__device__ __forceinline__ f32x16 x2_mma(const X2& A, const X2& B, f32x16 acc) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        acc = GATOR_MFMA_F16(A.p[1][s], B.p[0][s], acc);      // lo*hi
-        acc = GATOR_MFMA_F16(A.p[0][s], B.p[1][s], acc);      // hi*lo
-        acc = GATOR_MFMA_F16(A.p[0][s], B.p[0][s], acc);      // hi*hi
-    }
-    return acc;
-}
-#else
 __device__ __forceinline__ f32x16 x2_mma(const X2& A, const X2& B, f32x16 acc) { return x2_mma_main(A, B, x2_mma_small(A, B, acc)); }
-#endif
 
 // ---- "4-product" token-wise linears (round 3, MDR with GATOR_MDR_X3=2): activations on TWO fp16 planes, weights on THREE ---------
 // The weight side dominates the error of a rounded linear because its rounding is the same for every token and sample (emulated in

@@ -67,9 +67,9 @@ class ShardedForward:
         self.encoder = encoder
         self._pinned = None
 
-    TILED_MIN_BATCH = 1025                      # the library's own rule (fused_api.hip): up to 4 x 256 samples the one-sample-per-workgroup encoder is faster
+    TILED_MIN_BATCH = 1025                      # fallback only (a model without encoder_for_batch / no context yet): the library's default rule
 
-    def _pin_encoder(self, calls_batch):
+    def _pin_encoder(self, calls_batch, device=None):
         """world > 1: one encoder kernel for every call of this run (see the module docstring)."""
         if self._pinned is not None or not hasattr(self.model, 'set_encoder'):
             return
@@ -78,7 +78,12 @@ class ShardedForward:
             if self.world <= 1 and not self.always_gather:
                 self._pinned = 'auto'
                 return
-            want = 'tiled' if calls_batch >= self.TILED_MIN_BATCH else 'sample'
+            ask = getattr(self.model, 'encoder_for_batch', None)      # the library's own decision (its switches, the device's CU count)
+            if ask is not None and device is not None and device.type == 'cuda' and hasattr(self.model, '_context'):
+                self.model._context(device)                           # the decision needs the packed context (created on first use anyway)
+            want = ask(calls_batch) if ask is not None else None
+            if want is None:
+                want = 'tiled' if calls_batch >= self.TILED_MIN_BATCH else 'sample'
         self.model.set_encoder(want)
         self._pinned = want
 
@@ -172,7 +177,7 @@ class ShardedForward:
         if self.dist is None or (self.world == 1 and not self.always_gather):
             return self.model(pose2d_shard)
         B, J = pose2d_shard.shape[0], pose2d_shard.shape[1]
-        self._pin_encoder(min(B, self.micro or B))
+        self._pin_encoder(min(B, self.micro or B), pose2d_shard.device)
         self._throttle(pose2d_shard.device)
         gv, gp = self._buffers(B, J, pose2d_shard.device)
         side, chunks = None, []
@@ -233,7 +238,7 @@ class ShardedForward:
         if fused and getattr(self.model, '_jreg', None) is None:
             self.model.set_joint_regressor(self._regressor_dense)
         B = pose2d_shard.shape[0]
-        self._pin_encoder(min(B, self.micro or B))
+        self._pin_encoder(min(B, self.micro or B), pose2d_shard.device)
         self._throttle(pose2d_shard.device)
         acc = None
         for s, e in self._plan(B):

@@ -133,6 +133,10 @@ int gator_enable_block_taps(gator_ctx* ctx, int32_t on);
 #define GATOR_ENCODER_SAMPLE 0
 #define GATOR_ENCODER_TILED 1
 int gator_set_encoder(gator_ctx* ctx, int32_t mode);
+/* Which kernel GATOR_ENCODER_AUTO would use for a call of `batch` samples on this ctx (its environment switches, the device's CU
+ * count): GATOR_ENCODER_SAMPLE or GATOR_ENCODER_TILED (a batch the policy splits between both counts as TILED); negative on error.
+ * What a sharded run pins for every call so that the rule lives in one place (gator_amd/parallel.py). */
+int gator_encoder_for_batch(gator_ctx* ctx, int32_t batch);
 
 /* Measurement hook (bench.py `roofline`): gator_profile_enable(ctx, n) with n >= 1 brackets every stage launch of every
  * n-th forward by a hipEvent pair recorded on the launch stream (n = 0 switches it off).  gator_profile_read synchronises those events and returns, per stage name
