@@ -458,7 +458,7 @@ extern "C" int gator_enable_block_taps(gator_ctx* c, int32_t on) {
 extern "C" int gator_encoder_for_batch(gator_ctx* c, int32_t B) {
     if (!c || B <= 0) return fail(GATOR_EINVAL, "gator_encoder_for_batch: null ctx or batch <= 0");
     if (c->impl == GATOR_IMPL_BASIC || !c->fused) return GATOR_ENCODER_SAMPLE;
-    const int n = fused_tiled_samples(c, B);
+    const int n = fused_tiled_samples(c, B, /* unpinned: what AUTO would do, whatever gator_set_encoder has pinned */ true);
     return n == 0 ? GATOR_ENCODER_SAMPLE : GATOR_ENCODER_TILED;      // a batch the policy splits between both counts as tiled (its full rounds are)
 }
 

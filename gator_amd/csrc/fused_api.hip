@@ -35,7 +35,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
                  o_q = take(9 * tiles / 2), o_k = take(9 * tiles / 2), o_v = take(9 * tiles / 2) /* THREE tile sets each (k_mdr_persist writes every set once per forward); q/k/v sized for X3 tiles (1.5x) */, o_jkv = take((size_t)cap * 12 * kTile),
                  o_hf = take((size_t)cap * kV * 32), o_lbf = take((size_t)cap * kV * kE), o_feat = take((size_t)cap * J * kC),
                  o_xout = take((size_t)cap * J * 3), o_pc = take((size_t)cap * J * 133),
-                 o_vcp3 = take(std::max(upsample_x3_vcp_elems(cap), upsample_x2_vcp_elems(cap)) / 2), o_lpart = take(gat_tail_part_floats(cap, J)), o_ctr = take(kMdrCtrHeader + (size_t)4 * cap);
+                 o_vcp3 = take(std::max(upsample_x3_vcp_elems(cap), upsample_x2_vcp_elems(cap)) / 2), o_lpart = take(gat_tail_part_floats(cap, J)), o_ctr = take(mdr_ctr_words(cap));
     GATOR_HIP_CHECK(hipMalloc(&f->ws, n * sizeof(float)));
     GATOR_HIP_CHECK(hipMemset(f->ws, 0, n * sizeof(float)));
     GATOR_HIP_CHECK(hipDeviceSynchronize());      // the memset runs on the null stream; a non-blocking stream would not wait for it
@@ -192,6 +192,7 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
         if (rc) return rc;
         const char* tl = getenv("GATOR_GAT_TILED");
         f->gat_tiled = tl ? atoi(tl) : -1;
+        f->gat_tiled_env = f->gat_tiled;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) f->n_cu = prop.multiProcessorCount;
         const char* tm = getenv("GATOR_GAT_TILED_MIN_BATCH");
@@ -227,6 +228,8 @@ int fused_create(gator_ctx* c, void* stream) {
     f->mdr_persist = mper ? (atoi(mper) != 0 ? 1 : 0) : -1;
     const char* mpg = getenv("GATOR_MDR_PERSIST_GRID");
     f->mdr_persist_grid = mpg ? atoi(mpg) : 0;
+    const char* mpc = getenv("GATOR_MDR_PERSIST_CHUNK");
+    f->mdr_persist_chunk = mpc ? atoi(mpc) : 0;
     const size_t n_up = f->x3 ? 0 : (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)64 * kTile;
     const size_t total = n_up + 3 * n_layer + 24 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
     GATOR_HIP_CHECK(hipMalloc(&f->wbuf, total * sizeof(float)));
@@ -495,11 +498,12 @@ int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float*
 // How many samples of a batch of B the sample-tiled encoder takes under the ctx's current policy (the rest goes to the
 // one-sample-per-workgroup kernel); also behind gator_encoder_for_batch, so that a caller pinning the encoder asks the library
 // instead of repeating the rule.
-int fused_tiled_samples(const gator_ctx* c, int B) {
+int fused_tiled_samples(const gator_ctx* c, int B, bool unpinned) {
     const FusedState* f = c->fused;
     int n_tiled = 0;
-    if (f && f->gat_x3 && f->gat_tiled != 0) {
-        if (f->gat_tiled == 1) n_tiled = B;
+    const int policy = f ? (unpinned ? f->gat_tiled_env : f->gat_tiled) : 0;
+    if (f && f->gat_x3 && policy != 0) {
+        if (policy == 1) n_tiled = B;
         else if (B >= f->gat_tiled_min_batch) {
             const int round = f->n_cu * gat_tiled_samples_per_wg(c->J);
             n_tiled = (B / round) * round;
@@ -607,7 +611,7 @@ void fused_disable_persist(gator_ctx* c) {
 
 int fused_set_encoder(gator_ctx* c, int mode) {
     if (mode == 1 && !c->fused->gat_x3) return fail(GATOR_EUNSUPPORTED, "gator_set_encoder: the sample-tiled encoder needs the split-precision path (GATOR_GAT_X3)");
-    c->fused->gat_tiled = mode;
+    c->fused->gat_tiled = mode == GATOR_ENCODER_AUTO ? c->fused->gat_tiled_env : mode;      // AUTO = the ctx's own policy, incl. a GATOR_GAT_TILED pin of the environment
     return GATOR_OK;
 }
 

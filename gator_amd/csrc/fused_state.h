@@ -8,7 +8,9 @@ constexpr int kVT = 14;                 // 32-token tiles per sample (431 -> 448
 constexpr int kOB = 216;                // 32-vertex output blocks of the upsample GEMM (6890 -> 6912)
 constexpr int kCB = 14;                 // 32-wide k blocks over the 431 coarse vertices
 constexpr int kTile = 32 * 32;          // floats in one packed 32x32 tile ([4 g][64 lanes][4])
-constexpr int kMdrCtrHeader = 32;       // words in front of k_mdr_persist's per-sample counts: [0..7] tickets per XCD, [8] error flag (mdr_fused.hip)
+constexpr int kMdrCtrChunks = 64;       // persistent MDR launches one forward may be cut into (launch_mdr: chunks of 320 .. 640 samples)
+// words of k_mdr_persist's counters for a forward of B samples: per launch a 32-word header (tickets, error flag) + 4 counts per sample
+__host__ __device__ inline size_t mdr_ctr_words(int B) { return (size_t)32 * kMdrCtrChunks + (size_t)4 * B; }
 
 struct MdrLayerP {                      // packed weights of one LBF layer (device pointers into FusedState::wbuf)
     const float *wq, *wk, *wv, *proj, *fc1, *fc2, *sa[4];
@@ -37,7 +39,7 @@ struct FusedWs {
     float *feat = nullptr, *xout = nullptr, *pc = nullptr;
     float *lpart = nullptr;             // [MT][J][2][kTile] lifter partial tiles (gat_tail.hip)
     bool mdr_ctr_clean = false;         // the joint-token kernel queued before launch_mdr has zeroed mdr_ctr for it
-    unsigned* mdr_ctr = nullptr;        // k_mdr_persist: kMdrCtrHeader words (tickets, flags), then [4][cap] tiles done per (stage, sample)
+    unsigned* mdr_ctr = nullptr;        // k_mdr_persist: the counter blocks of a forward's launches, mdr_ctr_words(cap) words (mdr_fused.hip: MdrChunkPlan)
     void* vcp16 = nullptr;              // bf16 packed vert431 for the bf16 vertex GEMM (cap-sized)
     int vcp16_cap = 0;
 };
@@ -51,7 +53,8 @@ struct FusedState : FusedWs {
     // upsample: Wp[tap][ob][cb][4][64][4]
     const float* up_w = nullptr;
     void* up_w3 = nullptr;              // bf16 [plane 3][tap][ob][28][64][8]  hi/mid/lo split of upsample_conv.weight
-    int gat_tiled = -1;                 // GATOR_GAT_TILED: 0 never, 1 always, -1 (default): by batch size, see fused_forward_one
+    int gat_tiled = -1;                 // encoder policy in force: 0 never tiled, 1 always, -1: by batch size (fused_tiled_samples); gator_set_encoder changes it
+    int gat_tiled_env = -1;             // ... as gator_create found it (GATOR_GAT_TILED, default -1): what GATOR_ENCODER_AUTO means for this ctx
     int gat_tiled_min_batch = 1024;
     int n_cu = 256;                     // compute units of the ctx's device
     bool gat_split_tail = true;         // full forward: lifter + joint tokens as batched launches (GATOR_GAT_TAIL=0: inside k_gat)
@@ -66,6 +69,7 @@ struct FusedState : FusedWs {
     int gat8_wshift = 0;                // its weight stream holds three fp16 planes of 2^gat8_wshift * w
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
     int mdr_persist = -1;               // the four MDR stages as ONE persistent launch (k_mdr_persist): -1 by batch size (launch_mdr), GATOR_MDR_PERSIST=0 never, =1 always
+    int mdr_persist_chunk = 0;          // GATOR_MDR_PERSIST_CHUNK: most samples per persistent launch (0: 384)
     int mdr_persist_grid = 0;           // GATOR_MDR_PERSIST_GRID: workgroups of the persistent launch (0: two per CU)
     int mdr_wshift = 0;                 // GATOR_MDR_X3=2: wxbuf holds three fp16 planes of 2^mdr_wshift * w
     int mdr_x3 = 2;                     // GATOR_MDR_X3: 0 fp32-input MFMA; 1 exact bf16 x 3 split everywhere; 2 (default) that + the 431x431 attention on two fp16 planes

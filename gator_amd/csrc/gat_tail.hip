@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void k_gat_joint(const JointTailArgs a) {
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J, tok = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     if (a.mdr_ctr) {
-        if (t < 4) a.mdr_ctr[kMdrCtrHeader + (size_t)t * a.B + b] = 0u;      // per-sample completion counts of the four stages
-        if (b == 0 && t >= 64 && t < 80) a.mdr_ctr[t - 64] = 0u;             // tickets, error flag
+        // every persistent launch's counter block (tickets, error flag, completion counts): the whole region, dealt over the workgroups
+        for (size_t i = (size_t)b * 256 + t; i < mdr_ctr_words(a.B); i += (size_t)a.B * 256) a.mdr_ctr[i] = 0u;
     }
     // operands of the joint-token part are requested first: their latency hides behind the partial sums below
     const int tkj = tok < J ? tok : 0;

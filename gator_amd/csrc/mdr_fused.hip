@@ -815,10 +815,29 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
 // orphan queue was adopted as a whole by ONE other XCD.  Correct in every placement tried -- grids of 1, 3, 5, 13 workgroups -- but with
 // the queue loop around the three ticket loops hipcc lays the tile bodies out differently and the launch takes 423 us instead of 385
 // even when the loop runs once; a second, cold copy of the body spills 2 KB per lane.  Not worth 10 % of the dominant kernel.)
-constexpr int kCtrError = 8, kCtrDone = kMdrCtrHeader;       // ctr: [0..7] tickets per XCD, [8] error flag, [kCtrDone + stage * B + b] tiles done, stage 0..3
+// Counter block of ONE persistent launch: [0..7] tickets per XCD, [8] error flag, [kCtrDone + stage * B + b] finished tiles of (stage,
+// sample), stage 0..3, with B and b the launch's own batch (a large forward runs as several launches over chunks of its samples,
+// launch_mdr: their blocks follow each other in FusedWs::mdr_ctr, see mdr_ctr_block).  The kernel's argument block stays exactly
+// {stage arguments, ctr}: the tile body needs every scalar register there is, and each further scalar that must survive it
+// (measured with a base pointer, an offset and a stride more) is spilled into VGPR lanes and reloaded in its loops: +30 - 40 us.
+constexpr int kCtrError = 8, kCtrDone = 32;
 struct MdrPersistArgs {
-    MdrArgs st[4];
-    unsigned* ctr;
+    MdrArgs st[4];            // their B and every per-sample pointer are this launch's CHUNK of the batch
+    unsigned* ctr;            // this launch's counter block
+};
+// chunk plan of a forward of B samples in nch launches: the first B % nch chunks have one sample more.  -> (chunk, first sample, size)
+// of sample b, and the word offset of a chunk's counter block
+struct MdrChunkPlan {
+    int nch, base, rem;
+    __host__ __device__ void locate(int b, int& ch, int& b0, int& n) const {
+        const int split = rem * (base + 1);
+        if (b < split) { ch = b / (base + 1); n = base + 1; b0 = ch * n; }
+        else { ch = rem + (b - split) / base; n = base; b0 = split + (ch - rem) * base; }
+    }
+    __host__ __device__ size_t block(int ch) const {
+        const int big = ch < rem ? ch : rem;
+        return (size_t)ch * kCtrDone + 4 * ((size_t)big * (base + 1) + (size_t)(ch - big) * base);
+    }
 };
 template <int XA>
 __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) {
@@ -918,8 +937,8 @@ __global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     if (a.mdr_ctr) {
-        if (t < 4) a.mdr_ctr[kCtrDone + (size_t)t * gridDim.x + b] = 0u;
-        if (b == 0 && t >= 64 && t < 80) a.mdr_ctr[t - 64] = 0u;        // tickets, error flag
+        // every launch's counter block (tickets, error flag, completion counts): the whole region, dealt over the workgroups
+        for (size_t i = (size_t)b * 128 + t; i < mdr_ctr_words((int)gridDim.x); i += (size_t)gridDim.x * 128) a.mdr_ctr[i] = 0u;
     }
     for (int e = t; e < 5 * kTile; e += 128) {
         const int j4 = e & 3, ln = (e >> 2) & 63, g = (e >> 8) & 3, kb = e >> 10;
@@ -970,8 +989,8 @@ struct HeadArgs {
     __bf16* vcp3;           // non-null: write the hi/mid/lo bf16 planes of the split-precision vertex GEMM instead of vcp
     size_t vcp3_plane;
     _Float16* vcp2;         // non-null: write the scaled hi/lo fp16 planes of the two-plane vertex GEMM (upsample_x2.hip) instead
-    const unsigned* persist_err;   // non-null: k_mdr_persist's hang-guard flag; if it is set the outputs are poisoned with NaN (loud, not silent)
-    const unsigned* done3;         // non-null: k_mdr_persist's per-sample count of finished last-stage tiles; a sample short of 14 was not computed -> NaN
+    const unsigned* persist_ctr;   // non-null: the counter blocks of the forward's persistent launches.  The sample's launch must not have tripped its
+    MdrChunkPlan plan;             // hang guard and must have counted all 14 last-stage tiles of the sample; else its vertices are NaN (loud, not silent)
     unsigned* status;              // the ctx's sticky device status word (host-mapped; internal.h: DeviceStatus), read by the next API call
     int alpha;
 };
@@ -1063,7 +1082,13 @@ __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a
     }
     __syncthreads();
     const int mt = b >> 5, sl = b & 31;
-    const bool poisoned = (a.persist_err && *a.persist_err != 0u) || (a.done3 && a.done3[b] != (unsigned)kVT);
+    bool poisoned = false;
+    if (a.persist_ctr) {
+        int ch, b0, n;
+        a.plan.locate(b, ch, b0, n);
+        const unsigned* blk = a.persist_ctr + a.plan.block(ch);
+        poisoned = blk[kCtrError] != 0u || blk[kCtrDone + (size_t)3 * n + (b - b0)] != (unsigned)kVT;
+    }
     // |vert431| must stay below 4 094 m for the two-plane vertex regressor (16 x value in an fp16 plane); any non-finite value -- e.g.
     // an activation beyond +-4 094 that overflowed an fp16 operand plane somewhere upstream -- ends up here as NaN too
     const float limit = a.vcp2 ? 4094.0f : 3.0e38f;
@@ -1162,14 +1187,15 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     constexpr size_t solo = 0;
 #endif
     MdrPersistArgs pa{};
-    // One persistent launch or four?  Same tile body, bitwise the same results; the persistent form wins where the four launches
-    // waste a fractional generation (R = workgroups per CU: 3.5 at B = 256 is billed as 4, 5.25 at B = 384 as 6).  Below R = 3 its
-    // per-sample dependency chain costs more than the fraction it saves, and with nothing to save (B = 512, 1024, 2048: R whole)
-    // the four launches are 0 - 2 % faster (sweep in DESIGN.md 4d).
+    MdrChunkPlan plan{1, B, 0};
+    // Persistent launch(es) or four per-stage launches?  Same tile body, bitwise the same results.  The persistent form has no
+    // fractional generation per stage (R = workgroups per CU: 3.5 at B = 256 is billed as 4 by each of the four launches) and, cut
+    // into chunks, keeps a sample's tiles cache-resident between stages; below R = 3 (B < ~220) its per-sample dependency chain
+    // costs more than it saves.
     const bool ctr_clean = f->mdr_ctr_clean;      // zeroed for THIS call by the joint-token kernel queued just before (either entry point)
     f->mdr_ctr_clean = false;
     const double R = (double)nwg / f->n_cu;
-    const bool auto_persist = R >= 3.0 && (std::ceil(R) - R) / R >= 0.04;
+    const bool auto_persist = R >= 3.0;      // (round 3 also asked for a wasted fractional generation >= 4 %; with chunked launches the persistent form wins from R = 3 on: sweep in DESIGN.md)
     bool persist = f->mdr_persist < 0 ? auto_persist : f->mdr_persist > 0;
     // the queues are per XCD and a workgroup serves the queue of the XCD it runs on: that drains every queue only when the device is
     // the whole 8-XCD part (a partitioned device shows fewer CUs; its workgroups would all sit on one XCD).  A placement that leaves
@@ -1208,15 +1234,45 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
             else k_mdr_layer<2, 0><<<nwg, 256, 0, st>>>(a, nwg);
         }
     }
-    if (persist) {      // the four stages as one launch (k_mdr_persist): tickets and per-sample completion counts start from zero
-        pa.ctr = f->mdr_ctr;
-        if (!ctr_clean) GATOR_HIP_CHECK(hipMemsetAsync(f->mdr_ctr, 0, (kCtrDone + (size_t)4 * B) * sizeof(unsigned), st));
+    if (persist) {      // the four stages as persistent launches (k_mdr_persist): tickets and per-sample completion counts start from zero
+        if (!ctr_clean) GATOR_HIP_CHECK(hipMemsetAsync(f->mdr_ctr, 0, mdr_ctr_words(B) * sizeof(unsigned), st));
         StageTimer tm(c, "mdr_layers", stream);
         int grid = 2 * f->n_cu;             // two workgroups per CU is what the registers allow; any grid drains the queues
         if (f->mdr_persist_grid > 0) grid = f->mdr_persist_grid;      // GATOR_MDR_PERSIST_GRID (tests: a grid that leaves XCDs without a workgroup)
-        if (f->mdr_x3 == 2) k_mdr_persist<2><<<grid, 256, 0, st>>>(pa);
-        else if (f->mdr_x3 == 1) k_mdr_persist<1><<<grid, 256, 0, st>>>(pa);
-        else k_mdr_persist<0><<<grid, 256, 0, st>>>(pa);
+        // A large batch runs as several launches over chunks of 320 .. 640 samples.  The tickets are stage-major, so a sample's Q/K/V/residual
+        // tiles (448 KB) are read one stage after they were written: at B = 256 / 384 the 115 / 172 MB in between stay in the Infinity
+        // Cache, at B = 512 and above they do not and the launch costs 1.545 - 1.565 us per sample instead of 1.495 (measured, round 4).
+        // Chunks are independent (a tile depends on its own sample only) and each writes its own tiles exactly once, so the hand-off
+        // rules of the kernel hold per launch; results are bitwise those of one launch.
+        // Chunk size, measured (MDR stage, ms): B = 512: one launch 0.787, 2 x 256 0.835; B = 1024: one launch 1.560, 3 x 342 1.533, 4 x 256
+        // 1.649; B = 2048: one launch 3.246, 6 x 342 3.064, 8 x 256 3.270 -- launches of 320 .. 400 samples are the efficient ones
+        // (1.495 us per sample), 256-sample launches inside a larger forward are not (1.63).  So: floor(B / 320) launches.
+        int nch = f->mdr_persist_chunk > 0 ? (B + f->mdr_persist_chunk - 1) / f->mdr_persist_chunk : B / 320;
+        if (nch < 1) nch = 1;
+        if (nch > kMdrCtrChunks) nch = kMdrCtrChunks;
+        const size_t tq = f->mdr_x3 == 1 ? kTileX3 : kTile;
+        plan = MdrChunkPlan{nch, B / nch, B % nch};
+        for (int ch = 0, b0 = 0; ch < nch; ++ch) {
+            const int n = B / nch + (ch < B % nch ? 1 : 0);
+            MdrPersistArgs pc_ = pa;
+            for (int li = 0; li <= 3; ++li) {
+                MdrArgs& s = pc_.st[li];
+                const size_t ov = (size_t)b0 * kVT * 2 * kTile, oq = (size_t)b0 * kVT * 2 * tq;
+                s.B = n;
+                s.vf_in += ov; s.q_in += oq; s.k_in += oq; s.v_in += oq;
+                s.vf_out += ov; s.q_out += oq; s.k_out += oq; s.v_out += oq;
+                s.jkv += (size_t)b0 * 12 * kTile;
+                if (s.pc) s.pc += (size_t)b0 * c->J * 133;
+                if (s.xout) s.xout += (size_t)b0 * c->J * 3;
+                s.hf += (size_t)b0 * kV * 32;
+                s.lbf += (size_t)b0 * kV * kE;
+            }
+            pc_.ctr = f->mdr_ctr + plan.block(ch);
+            if (f->mdr_x3 == 2) k_mdr_persist<2><<<grid, 256, 0, st>>>(pc_);
+            else if (f->mdr_x3 == 1) k_mdr_persist<1><<<grid, 256, 0, st>>>(pc_);
+            else k_mdr_persist<0><<<grid, 256, 0, st>>>(pc_);
+            b0 += n;
+        }
     }
 #ifdef GATOR_DIAG
     if (d_st) {
@@ -1238,8 +1294,8 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     HeadArgs ha;
     ha.hf = f->hf; ha.bn_w = w.bn_w; ha.bn_b = w.bn_b; ha.bn_mean = w.bn_mean; ha.bn_var = w.bn_var;
     ha.bconv_w = w.bconv_w; ha.bconv_b = w.bconv_b; ha.vc = f->vc; ha.vcp = f->vcp;
-    ha.persist_err = persist ? f->mdr_ctr + kCtrError : nullptr;
-    ha.done3 = persist ? f->mdr_ctr + kCtrDone + (size_t)3 * B : nullptr;
+    ha.persist_ctr = persist ? f->mdr_ctr : nullptr;
+    ha.plan = plan;
     ha.status = c->status_dev;
     ha.vcp2 = f->x3 && f->up_x2 ? (_Float16*)f->vcp3 : nullptr;
     ha.vcp3 = f->x3 && !f->up_x2 ? (__bf16*)f->vcp3 : nullptr; ha.vcp3_plane = upsample_x3_vcp_elems(f->cap) / 3;     // plane stride fixed by the workspace capacity
