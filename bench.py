@@ -537,6 +537,24 @@ def main():
                             os.environ.pop(k, None)
                         else:
                             os.environ[k] = v
+            # the headline forward captured once into a hipGraph (torch.cuda.CUDAGraph around model(x)) and replayed: what a caller with a
+            # fixed batch shape gets by removing the host side of the six launches (results are bitwise the eager ones: tests/test_gpu_fullsize.py)
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    model(x)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    model(x)
+                for _ in range(a.warmup):
+                    graph.replay()
+                dv = sorted(block(lambda: graph.replay(), a.steps)[0] for _ in range(5))[2]
+                variants['headline replayed from a hipGraph (torch.cuda.CUDAGraph)'] = {'value': round(B * a.steps / dv, 1), 'ms_per_step': round(dv / a.steps * 1e3, 4)}
+                del graph
+            except Exception as e:       # a box whose runtime refuses the capture does not invalidate the line
+                variants['headline replayed from a hipGraph (torch.cuda.CUDAGraph)'] = {'error': str(e)[:200]}
             line['variants'] = variants
         if world == 1 and B >= 128 and a.subbatch_variant:
             # same workload with the library's sub-batch pipelining (two half-batches on two streams; bit-identical results).

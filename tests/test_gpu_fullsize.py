@@ -122,3 +122,29 @@ def test_subbatch_streams_bitwise(setup):
         assert torch.equal(vs, v[:n]) and torch.equal(ps, p[:n]), n
     vs, ps = m2(x[:64].contiguous())            # below the threshold: plain path, same context
     assert torch.equal(vs, v[:64]) and torch.equal(ps, p[:64])
+
+
+def test_forward_is_graph_capturable_and_replays_bitwise(setup):
+    """The steady-state forward issues no allocation, no host synchronisation and no host-side read of device memory (the status
+    word is host memory), so it can be captured into a hipGraph on a side stream and replayed: same bits as the eager call, also
+    after the input buffer was overwritten in place (the graph reads the buffer, not a copy)."""
+    m, x, v, p = setup
+    xs = x.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):                       # warm-up on the capture stream (workspace, contexts)
+            m(xs)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        vg, pg = m(xs)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(vg, v) and torch.equal(pg, p)
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(1)).cuda()
+    xs.copy_(x[perm])
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(vg, v[perm]) and torch.equal(pg, p[perm])
+    m.device_status()

@@ -3,7 +3,7 @@
 #   kernel-trace stats of the bench command, then separate PMC passes (never combined with a trace domain).
 # Output: gpurun_out/prof_<tag>/...; digest with tools/pmc_digest.py.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 REPO=$PWD
