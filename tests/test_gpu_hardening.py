@@ -161,3 +161,37 @@ def test_device_status_is_clean_after_normal_forwards():
     for B in (1, 33, 300):
         m(torch.from_numpy(synthetic.synthetic_pose2d(B, 19, seed=B)).cuda())
     m.device_status()
+
+
+@pytest.mark.parametrize('gain', [3.0, 8.0])
+def test_attention_rescale_paths_under_large_logits(gain):
+    """The 431-key self-attention forms its probabilities against a running reference and rescales lazily; with the shipped synthetic
+    weights the rescale branches (and, since round 4, the long way of a tile whose probabilities would leave the fp16 range) almost
+    never run.  Here the q / k projections of all three layers are scaled so that the logits grow 9 x / 64 x: every tile sequence
+    rescales, many tiles take the long way.  Criterion: the error against the fp64 oracle stays within twice the reference
+    arithmetic's own error (the oracle in fp32) on the same weights, results are deterministic and batch independent."""
+    from oracle import gator_oracle as go
+    z, m = build_model('h36m17_bn', 'fused', device=None)
+    zz, c, sd_o = oracle_setup('h36m17_bn')
+    sd = m.state_dict()
+    for sfx in ('', '_1', '_2'):
+        for n in (0, 1):
+            for leaf in ('weight', 'bias'):
+                k = 'pose2mesh.selfatt%s.linears.%d.%s' % (sfx, n, leaf)
+                sd[k] = sd[k] * gain
+                sd_o[k] = sd_o[k] * gain
+    m.load_state_dict(sd)
+    m = m.cuda()
+    x = torch.from_numpy(synthetic.synthetic_pose2d(24, 17, seed=9))
+    v, p = m(x.cuda())
+    torch.cuda.synchronize()
+    m.device_status()
+    r64, _ = go.gator_forward(sd_o, c, x, torch.float64)
+    r32, _ = go.gator_forward(sd_o, c, x, torch.float32)
+    ours = float(np.abs(v.cpu().numpy().astype(np.float64) - r64.numpy()).max() * 1e3)
+    ref = float(np.abs(r32.numpy().astype(np.float64) - r64.numpy()).max() * 1e3)
+    print('\n[logit gain %.0f^2] ours vs fp64 %.3e mm, reference arithmetic vs fp64 %.3e mm' % (gain, ours, ref))
+    assert ours <= max(1.5e-3, 2.0 * ref)
+    v2, _ = m(x.cuda())
+    vs, _ = m(x[5:9].cuda())
+    assert torch.equal(v, v2) and torch.equal(vs, v[5:9])
