@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
 
     // From here on the two roles run in DISJOINT branches and meet only at workgroup barriers: s_barrier counts arrivals, it does not
     // care which branch a wave arrives from, so this is well defined exactly as long as both branches execute the SAME NUMBER of
-    // barriers in the same order -- GAT8_BAR(0), then (1) .. (22) per block.  tests/test_host_cpu.py parses this file and fails if the
+    // barriers in the same order -- barrier 0, then 1 .. 22 per block, each written with the numbered macro.  tests/test_host_cpu.py parses this file and fails if the
     // two sequences differ (a barrier only one role executes hangs the GPU); keep that test in the CPU suite.
     if (wave < 4) {
         // =========================================== product waves ===========================================================
