@@ -15,6 +15,8 @@
 //              residual, LayerNorm, the J x J attention of heads 2w / 2w+1 (fp32-input MFMA, scores and probabilities in
 //              registers), the MGCN adjacency product, the hop-1 / hop-2 aggregations, GELU and the exact hi/mid/lo split into
 //              the next operand tile.
+// (Round 4, measured and not kept: s_setprio 1 / 2 / 3 on the helpers only inside their long steps -- scores + softmax, P.V, the four
+// GELU steps -- moves k_gat8 by less than 1 us; round 3 had the static form making the sum worse.)
 // One workgroup barrier per step, 22 steps per block; in 16 of them a product wave streams one 4-tile unit (a 32-channel output
 // block over K = 128) while the helper finishes the previous unit, six are helper-only (SB, the hop aggregations, residual +
 // LayerNorm twice).  Both roles live in disjoint branches of one kernel so that neither pays the other's registers; the barriers
@@ -23,10 +25,12 @@
 // LDS (149 KiB): A = 4 operand tiles (Y = LN1(x) | Y2 = LN2(x) | hidden blocks 4w+3), B = 12 operand tiles (AT | SB | FB, later
 // hidden blocks 4w+j, j < 3), R0 / R1 = 2 x 4 raw tiles (product wave w writes R[step & 1][w], helper w reads it in the next
 // step), X = 4 fp32 tiles: the embedding's output (first LayerNorm), then the four partial hop-2 linears; ST = per-wave LayerNorm
-// statistics.  k_gat8<false>: arithmetic and operand formats are k_gat's (x3_common.h: exact three-way bf16 split, six partial
+// statistics.  k_gat8<false, 16>: arithmetic and operand formats are k_gat's (x3_common.h: exact three-way bf16 split, six partial
 // products, fp32 accumulation); it agrees with k_gat to fp32 rounding (the MLP's four partial sums group the hidden blocks
-// differently, the LayerNorm variance is combined from per-wave statistics), not bit for bit.  k_gat8<true> (default): the token-wise
-// products on four partial products, the J x J attention and the hop aggregations on fp16 planes.
+// differently, the LayerNorm variance is combined from per-wave statistics), not bit for bit.  k_gat8<true, LR> (default): the
+// token-wise products on four partial products, the J x J attention and the hop aggregations on fp16 planes; LR = the
+// registers of a rows-over-tokens tile that hold tokens which exist (10 for J <= 18, 12 for J <= 20): the helpers skip the others, and
+// the MLP's hidden tiles go through a C-layout GELU (hid_store) -- bitwise the results of the all-rows form.
 #include "fused_common.h"
 #include "fused_state.h"
 #include "x3_common.h"
@@ -87,10 +91,17 @@ constexpr int kXo = kR + 8 * kTile;                     // 4 fp32 tiles
 constexpr int kDummy = kXo + 4 * kTile;                 // 4 x 1 KiB landing window of the L2 warm-up (never read)
 constexpr int kStat = kDummy + 1024;                     // [4 helper waves][32 tokens][mean, M2] of the wave's 32 channels (LayerNorm statistics)
 constexpr int kGat8LdsFloats = kStat + 256;             // 149 KiB
+#ifdef GATOR_DIAG
+constexpr int kDiagStamps = 2 * kDepth * 23 * 2 + kDepth * 8;      // u64 cycle stamps, kept in LDS while the kernel runs (a global
+constexpr int kDiagLdsFloats = 2 * kDiagStamps;                    // store waits ~0.5k cycles behind the product waves' stream and
+#else                                                               // would be measured as work of the step it sits in)
+constexpr int kDiagLdsFloats = 0;
+#endif
 
 #ifdef GATOR_DIAG
 // diagnostic library only (python -m gator_amd.build --diag; GATOR_GAT_STAMPS=1): per role, block and step the cycles spent working
-// (from leaving the previous barrier to arriving at this one) and waiting in the barrier, of workgroup 0's waves 0 and 4
+// (from leaving the previous barrier to arriving at this one) and waiting in the barrier, of workgroup 0's waves 0 and 4; written to
+// LDS, copied out by GAT8_STAMPS_OUT when the role is done
 #define GAT8_BAR(n)                                                                                      \
     do {                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                               \
@@ -101,6 +112,8 @@ constexpr int kGat8LdsFloats = kStat + 256;             // 149 KiB
         st_last = t_go_;                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                               \
     } while (0)
+#define GAT8_STAMPS_OUT(n0, n1)                                                                          \
+    do { if (st_out) for (int i_ = (n0); i_ < (n1); ++i_) a.stamps[i_] = st_lds[i_]; } while (0)
 #define GAT8_SUB(k)                                                                                     \
     do {                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                               \
@@ -110,6 +123,7 @@ constexpr int kGat8LdsFloats = kStat + 256;             // 149 KiB
 #else
 #define GAT8_BAR(n) __syncthreads()
 #define GAT8_SUB(k)
+#define GAT8_STAMPS_OUT(n0, n1)
 #endif
 
 // A helper wave is alone with its own dependency chains (its SIMD partner issues MFMAs, nobody fills its latency slots), so the
@@ -163,6 +177,96 @@ __device__ __forceinline__ void gelu_tile8(f32x16& v) {     // (operates on true
     }
 }
 
+// The MLP's hidden tiles in the four-product form.  fc1 leaves its accumulator in C layout (channel on the lane, token rows in the
+// registers), so the GELU and the split run over the LR registers that hold tokens instead of all 16 -- in T layout 15 of a tile's
+// 32 token lanes are padding at J = 17 and every instruction pays for them.  fc2 wants the hidden activations as an operand with k =
+// channel, i.e. the transpose of what a C-layout lane holds, and the operand goes through LDS anyway: lane (c, h) writes its value of
+// token t as ONE half into chunk (plane, s = c >> 4, lane' = t + 32 ((c >> 2) & 1)), element 4 ((c >> 3) & 1) + (c & 3).  The chunk
+// index is XOR-ed with s + 2 (lane' >> 5) so that the 64 lanes of one such store hit 32 different banks (unswizzled: 8); the fc2
+// units read the tile with the same XOR (x2_load_swz).  Token rows that do not exist are not written: their halves keep whatever
+// finite operand the tile held before, which only ever reaches the same padding token's outputs.
+__device__ __forceinline__ X2 x2_load_swz(const float* __restrict__ tile, int lane) {
+    const f16x8* q = reinterpret_cast<const f16x8*>(tile);
+    X2 o;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) o.p[pl][s] = q[(pl * 2 + s) * 64 + (lane ^ (s + 2 * (lane >> 5)))];
+    return o;
+}
+struct HidAddr { int base, off[4]; };                  // byte offsets of a C-layout lane into a hidden operand tile
+__device__ __forceinline__ HidAddr hid_addr(int lane) {
+    const int c = lane & 31, hh = lane >> 5, s = c >> 4, kh = (c >> 2) & 1, jj = 4 * ((c >> 3) & 1) + (c & 3), swz = s + 2 * kh;
+    HidAddr a;
+    a.base = s * 1024 + (4 * hh + 32 * kh) * 16 + jj * 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a.off[q] = (q ^ swz) * 16;
+    return a;
+}
+// two planes of 16 x v[r] for the token rows r < LR, scattered into the operand tile
+template <int LR>
+__device__ __forceinline__ void hid_store(float* tile, const HidAddr& ha, const f32x16& v) {
+    char* lb = reinterpret_cast<char*>(tile) + ha.base;
+#pragma unroll
+    for (int r = 0; r < LR; ++r) {
+        const float x = v[r] * 16.0f;
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        char* pr = lb + ha.off[r & 3] + (r >> 2) * 128;
+        *reinterpret_cast<_Float16*>(pr) = hi;
+        *reinterpret_cast<_Float16*>(pr + 2048) = lo;
+    }
+}
+// gelu_tile8 over the first NP register pairs only
+template <int NP>
+__device__ __forceinline__ void gelu_pairs(f32x16& v) {
+    f32x2 x[NP], t[NP], r[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        x[p][0] = v[2 * p]; x[p][1] = v[2 * p + 1];
+        const f32x2 a = x[p] * 0.70710678118654752440f;
+        t[p][0] = fminf(fabsf(a[0]), 4.3f);
+        t[p][1] = fminf(fabsf(a[1]), 4.3f);
+    }
+    const float c[8] = {4.369443071e-04f, -1.460381877e-03f, -8.251648338e-04f, 2.830188636e-02f, -1.485066472e-01f, -9.184098145e-01f,
+                        -1.627909326e+00f, -9.999999783e-01f};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) r[p] = pk_fma(f32x2(-4.435285315e-05f), t[p], f32x2(c[0]));
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) r[p] = pk_fma(r[p], t[p], f32x2(c[k]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        r[p][0] = __builtin_amdgcn_exp2f(r[p][0]);
+        r[p][1] = __builtin_amdgcn_exp2f(r[p][1]);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const f32x2 up = 1.0f - r[p];
+        f32x2 phi;
+        phi[0] = x[p][0] < 0.f ? r[p][0] : up[0];
+        phi[1] = x[p][1] < 0.f ? r[p][1] : up[1];
+        const f32x2 y = x[p] * phi;
+        v[2 * p] = y[0]; v[2 * p + 1] = y[1];
+    }
+}
+// the first ceil(LR / 4) register groups of a block
+template <int LR>
+__device__ __forceinline__ f32x16 load_block_rows(const float* __restrict__ p, int lane) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(p) + lane;
+    f32x16 v = zero16();
+#pragma unroll
+    for (int g = 0; g < (LR + 3) / 4; ++g) {
+        const f32x4 t = q[g * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * g + j] = t[j];
+    }
+    return v;
+}
+
 // nn.LayerNorm(128) of the residual stream X (4 fp32 tiles in LDS): statistics over all four tiles, result for this wave's own
 // channel block only (xw = its registers, the same values as X[w]); same operation order as k_gat's layernorm128
 __device__ __forceinline__ f32x16 ln_own(const float* X, const f32x16& xw, const f32x16& wv, const f32x16& bv, int lane) {
@@ -208,6 +312,52 @@ __device__ __forceinline__ f32x16 ln_stats(const float* ST, const f32x16& xw, co
     const float m2 = ((q[0] + q[1]) + (q[2] + q[3])) + 32.0f * dev;
     const float rstd = 1.0f / sqrtf(m2 * (1.0f / 128.0f) + 1e-5f);
     return (xw - mean) * rstd * wv + bv;
+}
+
+// ---- token rows that do not exist.  A tile whose REGISTERS run over tokens (C layout: v[r] <-> token kap(r) + 4h; S^T and P^T with
+// the key on the row) has live data only in registers r < LR: tokens 0 .. J-1 with J = 17 / 19 sit in r <= 8 / 10.  The rows behind
+// them hold products against zero operand rows or masked scores (probability exactly 0): every instruction spent on them is wasted,
+// and the helper waves are the long side of most steps.  LR (even: 10 for J <= 18, 12 for J <= 20, else 16) is a template
+// parameter of the kernel; skipping dead rows changes no bit of a live value (sums lose terms that are exactly +0).
+template <int LR>
+__device__ __forceinline__ X2 x2_split_rows(const f32x16& v) {     // x2_split with zero halves for the dead rows
+    X2 o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (8 * s + j < LR) {
+                const float x = v[8 * s + j];
+                const _Float16 hh = (_Float16)x;
+                o.p[0][s][j] = hh;
+                o.p[1][s][j] = (_Float16)(x - (float)hh);
+            } else {
+                o.p[0][s][j] = (_Float16)0.f;
+                o.p[1][s][j] = (_Float16)0.f;
+            }
+        }
+    return o;
+}
+// (a + b) + (c + d) over the live registers of group q, the association of the full tree (a dead term is an exact +0)
+template <int LR, class F>
+__device__ __forceinline__ float tree4(int q, F f) {
+    const int n = LR - 4 * q;          // live registers in this group
+    if (n <= 0) return 0.f;
+    if (n == 1) return f(4 * q);
+    if (n == 2) return f(4 * q) + f(4 * q + 1);
+    if (n == 3) return (f(4 * q) + f(4 * q + 1)) + f(4 * q + 2);
+    return (f(4 * q) + f(4 * q + 1)) + (f(4 * q + 2) + f(4 * q + 3));
+}
+// dot16 (fused_common.h) over the live k rows only: the same two chains (even / odd registers)
+template <int LR>
+__device__ __forceinline__ f32x16 dot16_rows(const f32x16& A, const f32x16& B, f32x16 init) {
+    f32x16 e = init, o = zero16();
+#pragma unroll
+    for (int r = 0; r < LR; r += 2) {
+        e = GATOR_MFMA(A[r], B[r], e);
+        o = GATOR_MFMA(A[r + 1], B[r + 1], o);
+    }
+    return e + o;
 }
 
 // ---- product wave: one unit = the K = 128 contraction of one 32-channel output block (4 weight tiles) --------------------------
@@ -288,6 +438,8 @@ __device__ __forceinline__ f32x16 x2_mma_step(const X2& A, const X2& B, int s, f
 __device__ __forceinline__ void ld_tile(X3& o, const float* p, int lane) { o = x3_load(p, lane); }
 __device__ __forceinline__ void ld_tile(X2& o, const float* p, int lane) { o = x2_load(p, lane); }
 __device__ __forceinline__ void ld_tile(H3& o, const float* p, int lane) { o = h3_load(p, lane); }
+template <bool SWZ> __device__ __forceinline__ void ld_opnd(X3& o, const float* p, int lane) { o = x3_load(p, lane); }
+template <bool SWZ> __device__ __forceinline__ void ld_opnd(X2& o, const float* p, int lane) { o = SWZ ? x2_load_swz(p, lane) : x2_load(p, lane); }
 
 // ---- product wave: one unit = the K = 128 contraction of one 32-channel output block (4 weight tiles) --------------------------
 // CL = false: weights as A operand -> T-layout accumulator (token on the lane); CL = true: activations as A -> C-layout.
@@ -295,7 +447,7 @@ __device__ __forceinline__ void ld_tile(H3& o, const float* p, int lane) { o = h
 // `b` = the unit's first operand tile, already requested: where that tile was complete two barriers ago (Y for k / v / h0 / h1, Y2
 // for the later fc1 units, the hidden blocks for fc2) the caller reads it BEFORE the barrier that opens the step, so the matrix
 // pipe does not idle through an LDS round trip after every barrier.
-template <int S0, bool CL, class WT, class OT>
+template <int S0, bool CL, bool SWZ = false, class WT, class OT>
 __device__ __forceinline__ void unit4(WT (&W)[kNT], const float* __restrict__& wp, OT b, const float* o1, const float* o2, const float* o3,
                                       float* raw, int lane) {
     const float* ops[4] = {o1, o1, o2, o3};
@@ -303,7 +455,7 @@ __device__ __forceinline__ void unit4(WT (&W)[kNT], const float* __restrict__& w
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         OT bn = b;
-        if (kb < 3) ld_tile(bn, ops[kb + 1], lane);
+        if (kb < 3) ld_opnd<SWZ>(bn, ops[kb + 1], lane);
         tile_mma_refill<CL>(W[(S0 + kb) % kNT], b, acc, acs, wp, lane);
         wp += kTileX3;
         b = bn;
@@ -334,7 +486,7 @@ __device__ __forceinline__ void skip_pad(WT (&W)[kNT], const float* __restrict__
 }
 
 // H4: the token-wise products on four partial products (weights H3, operands X2; raw tiles carry 1 / a.lin_inv) instead of six
-template <bool H4>
+template <bool H4, int LR>
 __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
     typedef typename std::conditional<H4, H3, X3>::type WT;
     typedef typename std::conditional<H4, X2, X3>::type OT;
@@ -410,7 +562,9 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         for (int s = 0; s < kNT; ++s) { ld_tile(W[s], wp, lane); wp += kTileX3; }
         asm volatile("" ::: "memory");
 #ifdef GATOR_DIAG
-        unsigned long long* st_out = (a.stamps && b == 0 && t == 0) ? a.stamps : nullptr;
+        unsigned long long* st_lds = reinterpret_cast<unsigned long long*>(lds + kGat8LdsFloats);
+        unsigned long long* st_out = (a.stamps && b == 0 && t == 0) ? st_lds : nullptr;
+        if (st_out) for (int i_ = 0; i_ < kDepth * 23 * 2; ++i_) st_lds[i_] = 0;
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
         int bi_ = 0;
 #endif
@@ -452,45 +606,49 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             GAT8_BAR(11);                                                   // helpers: residual
             GAT8_BAR(12);                                                   // helpers: Y2 = LN2(x)
             ld_tile(pre, Y0, lane);
-            unit4<(OFF_FC1 + 0) % kNT, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             // fc1, hidden block 4w
+            unit4<(OFF_FC1 + 0) % kNT, H4>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             // fc1, hidden block 4w
             ld_tile(pre, Y0, lane);
             GAT8_BAR(13);
-            unit4<(OFF_FC1 + 4) % kNT, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 1
+            unit4<(OFF_FC1 + 4) % kNT, H4>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 1
             ld_tile(pre, Y0, lane);
             GAT8_BAR(14);
-            unit4<(OFF_FC1 + 8) % kNT, false>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             //      4w + 2
+            unit4<(OFF_FC1 + 8) % kNT, H4>(W, wp, pre, Y1, Y2, Y3, R0w, lane);             //      4w + 2
             ld_tile(pre, Y0, lane);
             GAT8_BAR(15);
-            unit4<(OFF_FC1 + 12) % kNT, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 3
-            ld_tile(pre, Bq, lane);                                        // (hidden blocks 4w' were complete at barrier 14)
+            unit4<(OFF_FC1 + 12) % kNT, H4>(W, wp, pre, Y1, Y2, Y3, R1w, lane);             //      4w + 3
+            ld_opnd<H4>(pre, Bq, lane);                                    // (hidden blocks 4w' were complete at barrier 14)
             GAT8_BAR(16);
             // fc2: unit u contracts over hidden blocks {4w' + u}: tiles 3w' + u of B for u < 3, tile w' of A for u = 3
-            unit4<(OFF_FC2 + 0) % kNT, false>(W, wp, pre, Bq + 3 * kTileX3, Bq + 6 * kTileX3, Bq + 9 * kTileX3, R0w, lane);
-            ld_tile(pre, Bq + 1 * kTileX3, lane);
+            unit4<(OFF_FC2 + 0) % kNT, false, H4>(W, wp, pre, Bq + 3 * kTileX3, Bq + 6 * kTileX3, Bq + 9 * kTileX3, R0w, lane);
+            ld_opnd<H4>(pre, Bq + 1 * kTileX3, lane);
             GAT8_BAR(17);
-            unit4<(OFF_FC2 + 4) % kNT, false>(W, wp, pre, Bq + 4 * kTileX3, Bq + 7 * kTileX3, Bq + 10 * kTileX3, R1w, lane);
-            ld_tile(pre, Bq + 2 * kTileX3, lane);
+            unit4<(OFF_FC2 + 4) % kNT, false, H4>(W, wp, pre, Bq + 4 * kTileX3, Bq + 7 * kTileX3, Bq + 10 * kTileX3, R1w, lane);
+            ld_opnd<H4>(pre, Bq + 2 * kTileX3, lane);
             GAT8_BAR(18);
-            unit4<(OFF_FC2 + 8) % kNT, false>(W, wp, pre, Bq + 5 * kTileX3, Bq + 8 * kTileX3, Bq + 11 * kTileX3, R0w, lane);
-            ld_tile(pre, Y0, lane);                                        // (hidden blocks 4w' + 3, complete at barrier 17)
+            unit4<(OFF_FC2 + 8) % kNT, false, H4>(W, wp, pre, Bq + 5 * kTileX3, Bq + 8 * kTileX3, Bq + 11 * kTileX3, R0w, lane);
+            ld_opnd<H4>(pre, Y0, lane);                                    // (hidden blocks 4w' + 3, complete at barrier 17)
             GAT8_BAR(19);
-            unit4<(OFF_FC2 + 12) % kNT, false>(W, wp, pre, Y1, Y2, Y3, R1w, lane);
+            unit4<(OFF_FC2 + 12) % kNT, false, H4>(W, wp, pre, Y1, Y2, Y3, R1w, lane);
             skip_pad<(OFF_FC2 + 16) % kNT>(W, wp, lane);                          // the block's dummy tiles: refill their slots, no product
             GAT8_BAR(20);
             GAT8_BAR(21);                                                   // helpers: residual
             GAT8_BAR(22);                                                   // helpers: Y = LN1(x) of the next block | final norm
         }
+        GAT8_STAMPS_OUT(0, kDepth * 23 * 2);
         return;
     }
 
     // =============================================== helper waves ===============================================================
     const int tok = lane & 31;
+    const HidAddr hid = hid_addr(lane);
 #ifdef GATOR_DIAG
     if (a.dbg & 1) {
         for (int n = 0; n < 1 + 22 * kDepth; ++n) __syncthreads();
         return;
     }
-    unsigned long long* st_out = (a.stamps && b == 0 && t == 256) ? a.stamps + (size_t)kDepth * 23 * 2 : nullptr;
+    unsigned long long* st_lds = reinterpret_cast<unsigned long long*>(lds + kGat8LdsFloats);
+    unsigned long long* st_out = (a.stamps && b == 0 && t == 256) ? st_lds + (size_t)kDepth * 23 * 2 : nullptr;
+    if (st_out) for (int i_ = 0; i_ < kDepth * 23 * 2 + kDepth * 8; ++i_) st_out[i_] = 0;
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
     int bi_ = 0;
 #endif
@@ -529,6 +687,8 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         GAT8_BAR(1);
         // ---- step 2: q
         const f32x16 q = pick(R0w, lane, bq);
+        X2 qx;                                                 // H4: q on two planes already here (the helper has slack in this step)
+        if constexpr (H4) qx = x2_split(q * 16.0f);
         if (warm) warm_weights(0, (a.pf_loads + 1) / 2);
         GAT8_BAR(2);
         // ---- step 3: k; scores and softmax of heads 2w, 2w+1 (modules.py:121-133): S^T[key][query], query on the lane
@@ -537,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             const f32x16 k = pick(R1w, lane, bk);
             float sscale = 0.25f;
             if constexpr (H4) {      // q, k on two fp16 planes of 16 x value: a head's 16 channels are exactly one k-step (registers 0..7 | 8..15)
-                const X2 kx = x2_split(k * 16.0f), qx = x2_split(q * 16.0f);
+                const X2 kx = x2_split(k * 16.0f);
                 sa = GATOR_MFMA_F16(kx.p[1][0], qx.p[0][0], sa);
                 sb = GATOR_MFMA_F16(kx.p[1][1], qx.p[0][1], sb);
                 sa = GATOR_MFMA_F16(kx.p[0][0], qx.p[1][0], sa);
@@ -552,42 +712,43 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
                     sb = GATOR_MFMA(k[r + 8], q[r + 8], sb);                        // head 2w+1: channels 16..31
                 }
             }
+            // rows = keys: only registers r < LR can hold a key that exists (the others' probability is exactly 0)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool ok = kap(r) + 4 * h < J;
-                sa[r] = ok ? (sa[r] * sscale + ba[r]) * kLog2e8 : -1e30f;            // q k^T * head_dim**-0.5 + hop/path bias
-                sb[r] = ok ? (sb[r] * sscale + bb[r]) * kLog2e8 : -1e30f;
-            }
-            float ma, mb, la, lb;
-            {   // row maxima and sums as trees (four independent partials each)
-                float pa[4], pb[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    pa[q] = fmaxf(fmaxf(sa[4 * q], sa[4 * q + 1]), fmaxf(sa[4 * q + 2], sa[4 * q + 3]));
-                    pb[q] = fmaxf(fmaxf(sb[4 * q], sb[4 * q + 1]), fmaxf(sb[4 * q + 2], sb[4 * q + 3]));
+                if (r < LR) {
+                    const bool ok = kap(r) + 4 * h < J;
+                    sa[r] = ok ? (sa[r] * sscale + ba[r]) * kLog2e8 : -1e30f;        // q k^T * head_dim**-0.5 + hop/path bias
+                    sb[r] = ok ? (sb[r] * sscale + bb[r]) * kLog2e8 : -1e30f;
+                } else {
+                    sa[r] = 0.f;
+                    sb[r] = 0.f;
                 }
-                ma = fmaxf(fmaxf(pa[0], pa[1]), fmaxf(pa[2], pa[3]));
-                mb = fmaxf(fmaxf(pb[0], pb[1]), fmaxf(pb[2], pb[3]));
+            }
+            float ma = sa[0], mb = sb[0], la, lb;
+            {   // row maxima; sums as trees (four independent partials each)
+#pragma unroll
+                for (int r = 1; r < LR; ++r) { ma = fmaxf(ma, sa[r]); mb = fmaxf(mb, sb[r]); }
                 ma = fmaxf(ma, xhalf(ma));
                 mb = fmaxf(mb, xhalf(mb));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < LR; ++r) {
                     sa[r] = __builtin_amdgcn_exp2f(sa[r] - ma);
                     sb[r] = __builtin_amdgcn_exp2f(sb[r] - mb);
                 }
+                float pa[4], pb[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    pa[q] = (sa[4 * q] + sa[4 * q + 1]) + (sa[4 * q + 2] + sa[4 * q + 3]);
-                    pb[q] = (sb[4 * q] + sb[4 * q + 1]) + (sb[4 * q + 2] + sb[4 * q + 3]);
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    pa[q4] = tree4<LR>(q4, [&](int r) { return sa[r]; });
+                    pb[q4] = tree4<LR>(q4, [&](int r) { return sb[r]; });
                 }
-                la = (pa[0] + pa[1]) + (pa[2] + pa[3]);
-                lb = (pb[0] + pb[1]) + (pb[2] + pb[3]);
+                la = LR > 12 ? (pa[0] + pa[1]) + (pa[2] + pa[3]) : LR > 8 ? (pa[0] + pa[1]) + pa[2] : pa[0] + pa[1];
+                lb = LR > 12 ? (pb[0] + pb[1]) + (pb[2] + pb[3]) : LR > 8 ? (pb[0] + pb[1]) + pb[2] : pb[0] + pb[1];
             }
             la += xhalf(la);
             lb += xhalf(lb);
             const float ia = 1.0f / la, ib = 1.0f / lb;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sa[r] = sa[r] * ia; sb[r] = sb[r] * ib; }
+            for (int r = 0; r < LR; ++r) { sa[r] = sa[r] * ia; sb[r] = sb[r] * ib; }
         }
         GAT8_BAR(3);
         // ---- steps 4, 5: v; P.V (both heads, rows 0..15 <- head 2w, rows 16..31 <- head 2w+1); pick up h0 in between
@@ -598,14 +759,14 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             if constexpr (H4) v = v * inv;
             X2 va, vbx, pa, pb;      // H4: V of head 2w (channel lanes 0..15) / head 2w+1 (16..31) and the two probability tiles on two planes
             if constexpr (H4) {
-                const X2 vx = x2_split((v + vb) * 16.0f);
+                const X2 vx = x2_split_rows<LR>((v + vb) * 16.0f);      // rows = keys
                 const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) { va.p[pl][ks] = lo ? vx.p[pl][ks] : z; vbx.p[pl][ks] = lo ? z : vx.p[pl][ks]; }
-                pa = x2_split(sa * 64.0f);
-                pb = x2_split(sb * 64.0f);
+                pa = x2_split_rows<LR>(sa * 64.0f);
+                pb = x2_split_rows<LR>(sb * 64.0f);
                 O = x2_mma_step(va, pa, 0, O);
                 Ob = x2_mma_step(vbx, pb, 0, Ob);
             } else {
@@ -644,7 +805,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             f32x16 h1 = load_block(R0w, lane);
             if constexpr (H4) h1 = h1 * inv;
             h1 = h1 * mct;
-            g_out = dot16(h1, aoff, bg) + O;
+            g_out = dot16_rows<LR>(h1, aoff, bg) + O;          // k = token j: Aoff[t][j] is zero for the rows that do not exist
         }
         const f32x16 bp = load_chanvec_T(vec, V_PROJB + 32 * w, h);
         GAT8_BAR(6);
@@ -666,13 +827,17 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             if constexpr (H4) {
                 // the hop masks are 0 / 1: one exact fp16 plane; the aggregated tiles on two planes like every other operand of this
                 // form -> 2 x 4 fp16 MFMAs (256 cycles) instead of 32 fp32-input ones (2 048) in a step the product waves wait through
-                const X2 u0x = x2_split(u0 * 16.0f), u1x = x2_split(u1 * (16.0f * inv));
+                const X2 u0x = x2_split_rows<LR>(u0 * 16.0f), u1x = x2_split_rows<LR>(u1 * (16.0f * inv));      // rows = the aggregated token
                 f32x16 f0 = zero16(), f1a = zero16();
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     f16x8 m1h, m2h;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { m1h[j] = (_Float16)m1[8 * s + j]; m2h[j] = (_Float16)m2[8 * s + j]; }
+                    for (int j = 0; j < 8; ++j) {
+                        const bool live = 8 * s + j < LR;
+                        m1h[j] = live ? (_Float16)m1[8 * s + j] : (_Float16)0.f;
+                        m2h[j] = live ? (_Float16)m2[8 * s + j] : (_Float16)0.f;
+                    }
                     f0 = GATOR_MFMA_F16(u0x.p[1][s], m1h, f0);
                     f1a = GATOR_MFMA_F16(u1x.p[1][s], m2h, f1a);
                     f0 = GATOR_MFMA_F16(u0x.p[0][s], m1h, f0);
@@ -711,37 +876,52 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         // ---- step 12: Y2 = LN2(x)
         st_opnd(A + w * kTileX3, lane, ln_stats(lds + kStat, xw, n2w, n2b, lane));
         GAT8_BAR(12);
-        // ---- steps 13-17: MLP hidden blocks 4w + j: bias, GELU, split (modules.py:188-196)
-        f32x16 fb0 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 0), h), fb1 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 1), h);
+        // ---- steps 13-17: MLP hidden blocks 4w + j: bias, GELU, split (modules.py:188-196).  H4: the raw tile is in C layout (channel
+        // on the lane: ONE bias value per lane; token rows r < LR in the registers), see hid_store; else T layout, all 16 registers.
+        struct FcBias { float s; f32x16 v; };
+        auto fc1_bias = [&](int j) {
+            FcBias o;
+            if constexpr (H4) {
+                o.v = zero16();
+#ifdef GATOR_DIAG
+                if (a.dbg & 8) { o.s = 0.f; return o; }
+#endif
+                o.s = vec[V_FC1B + 32 * (4 * w + j) + (lane & 31)];
+            }
+            else { o.s = 0.f; o.v = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + j), h); }
+            return o;
+        };
+        auto hidden = [&](const float* raw, float* dst, const FcBias& fb) {
+            if constexpr (H4) {
+                f32x16 hd = fma16(load_block_rows<LR>(raw, lane), inv, f32x16(fb.s));
+                GAT8_SUB(0);
+#ifdef GATOR_DIAG
+                if (!(a.dbg & 2))
+#endif
+                gelu_pairs<LR / 2>(hd);
+                GAT8_SUB(1);
+#ifdef GATOR_DIAG
+                if (!(a.dbg & 4))
+#endif
+                hid_store<LR>(dst, hid, hd);
+                GAT8_SUB(3);
+            } else {
+                f32x16 hd = pick(raw, lane, fb.v);
+                gelu_tile8(hd);
+                st_opnd(dst, lane, hd);
+            }
+        };
+        FcBias fb0 = fc1_bias(0), fb1 = fc1_bias(1);
         GAT8_BAR(13);
-        {
-            f32x16 hd = pick(R0w, lane, fb0);
-            gelu_tile8(hd);
-            st_opnd(Bq + (3 * w + 0) * kTileX3, lane, hd);
-        }
-        fb0 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 2), h);
+        hidden(R0w, Bq + (3 * w + 0) * kTileX3, fb0);
+        fb0 = fc1_bias(2);
         GAT8_BAR(14);
-        {
-            f32x16 hd = pick(R1w, lane, fb1);
-            GAT8_SUB(0);
-            gelu_tile8(hd);
-            GAT8_SUB(1);
-            st_opnd(Bq + (3 * w + 1) * kTileX3, lane, hd);
-            GAT8_SUB(3);
-        }
-        fb1 = load_chanvec_T(vec, V_FC1B + 32 * (4 * w + 3), h);
+        hidden(R1w, Bq + (3 * w + 1) * kTileX3, fb1);
+        fb1 = fc1_bias(3);
         GAT8_BAR(15);
-        {
-            f32x16 hd = pick(R0w, lane, fb0);
-            gelu_tile8(hd);
-            st_opnd(Bq + (3 * w + 2) * kTileX3, lane, hd);
-        }
+        hidden(R0w, Bq + (3 * w + 2) * kTileX3, fb0);
         GAT8_BAR(16);
-        {
-            f32x16 hd = pick(R1w, lane, fb1);
-            gelu_tile8(hd);
-            st_opnd(A + w * kTileX3, lane, hd);                                    // (Y2 is dead: fc1 finished before barrier 16)
-        }
+        hidden(R1w, A + w * kTileX3, fb1);                                             // (Y2 is dead: fc1 finished before barrier 16)
         const f32x16 bfc2 = load_chanvec_T(vec, V_FC2B + 32 * w, h);
         GAT8_BAR(17);
         // ---- steps 18-21: the four partial sums of fc2, residual
@@ -799,6 +979,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         }
         GAT8_BAR(22);
     }
+    GAT8_STAMPS_OUT(kDepth * 23 * 2, 2 * kDepth * 23 * 2 + kDepth * 8);
 }
 
 // one workgroup per destination tile: dst tile i <- src tile idx[i]  (TILE floats: 6 KiB X3 tiles or 4 KiB fp32 tiles)
@@ -811,11 +992,13 @@ __global__ void k_gather_tiles(const float* __restrict__ src, const int* __restr
 
 }  // namespace
 
-constexpr size_t kGat8Lds = (size_t)kGat8LdsFloats * sizeof(float);
+constexpr size_t kGat8Lds = (size_t)(kGat8LdsFloats + kDiagLdsFloats) * sizeof(float);
 
 int gat8_prepare_device() {
-    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
-    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     return GATOR_OK;
 }
 
@@ -907,8 +1090,11 @@ int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* 
     }
 #endif
     a.lin_inv = std::ldexp(1.0f, -(4 + f->gat8_wshift));
-    if (f->gat8_h4) k_gat8<true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
-    else k_gat8<false><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    // token rows that exist sit in registers r < LR of a row-over-token tile: token t <-> r = (t & 3) + 4 (t >> 3), so J <= 18 / 20 -> 10 / 12
+    if (!f->gat8_h4) k_gat8<false, 16><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else if (c->J <= 18) k_gat8<true, 10><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else if (c->J <= 20) k_gat8<true, 12><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else k_gat8<true, 16><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     GATOR_HIP_CHECK(hipGetLastError());
 #ifdef GATOR_DIAG
     if (a.stamps) {     // diagnostic build: synchronous read-back; blocks 1..5 averaged (block 0 carries the cold start)
