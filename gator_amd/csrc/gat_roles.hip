@@ -16,7 +16,11 @@
 //              registers), the MGCN adjacency product, the hop-1 / hop-2 aggregations, GELU and the exact hi/mid/lo split into
 //              the next operand tile.
 // (Round 4, measured and not kept: s_setprio 1 / 2 / 3 on the helpers only inside their long steps -- scores + softmax, P.V, the four
-// GELU steps -- moves k_gat8 by less than 1 us; round 3 had the static form making the sum worse.)
+// GELU steps -- moves k_gat8 by less than 1 us; round 3 had the static form making the sum worse.  The GELU as plain instead of
+// packed FMAs, the file without packed fp32 or without SLP vectorisation: no change either.  With the diagnostic library:
+// GATOR_GAT8_DBG=16 (helpers keep only the barriers and the L2 warm-up) 128 us against 167 for the whole kernel on one box -- the
+// helpers cost 39 us, and their steps are latency (LDS round trips, barrier skew), not instruction count: 40 % fewer VALU
+// instructions in the GELU steps bought 2.5 us.)
 // One workgroup barrier per step, 22 steps per block; in 16 of them a product wave streams one 4-tile unit (a 32-channel output
 // block over K = 128) while the helper finishes the previous unit, six are helper-only (SB, the hop aggregations, residual +
 // LayerNorm twice).  Both roles live in disjoint branches of one kernel so that neither pays the other's registers; the barriers
@@ -504,7 +508,10 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
     float* X = lds + kXo;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, h = lane >> 5, J = a.J;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int w = wave & 3;                              // channel block of this wave (either role)
+    const bool is_prod = wave < 4;
+    const int w = wave & 3;                              // channel block of this wave (either role).  Waves i and i + 4 share a SIMD: every
+                                                         // SIMD hosts one product and one helper wave (both product waves of a pair on one
+                                                         // SIMD, helpers on the other two: 180 us instead of 162, measured in round 4)
     float* R0w = lds + kR + w * kTile;
     float* R1w = lds + kR + (4 + w) * kTile;
 
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             hbuf[e] = j < J ? a.gl0_W[c * 2] * p[j * 2] + a.gl0_W[c * 2 + 1] * p[j * 2 + 1] + a.gl0_b[c] : 0.f;
         }
         __syncthreads();
-        if (wave >= 4) {   // helper w -> GroupNorm group w (16 channels x J tokens), two-pass
+        if (!is_prod) {   // helper w -> GroupNorm group w (16 channels x J tokens), two-pass
             float s = 0.f;
             for (int e = lane; e < 16 * 32; e += 64) s += ((e & 31) < J) ? hbuf[w * 512 + e] : 0.f;
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             gt[e] = tok < J ? gelu_f((hbuf[c * 32 + tok] - stat[(c >> 4) * 2]) * stat[(c >> 4) * 2 + 1] * a.gn_w[c] + a.gn_b[c]) : 0.f;
         }
         __syncthreads();
-        if (wave >= 4) {   // GraphLinear(64->128) on the fp32-input MFMA: helper w -> channel block w; + folded position tiles
+        if (!is_prod) {   // GraphLinear(64->128) on the fp32-input MFMA: helper w -> channel block w; + folded position tiles
             f32x16 acc = load_chanvec_T(a.gl3_b, 32 * w, h) + load_block(a.posT + (size_t)w * kTile, lane), ac1 = zero16();
             mma2_T(load_wtile(a.gl3_p, w * 2 + 0, lane), load_block(gt, lane), acc, load_wtile(a.gl3_p, w * 2 + 1, lane),
                    load_block(gt + kTile, lane), ac1);
@@ -554,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
     // care which branch a wave arrives from, so this is well defined exactly as long as both branches execute the SAME NUMBER of
     // barriers in the same order -- barrier 0, then 1 .. 22 per block, each written with the numbered macro.  tests/test_host_cpu.py parses this file and fails if the
     // two sequences differ (a barrier only one role executes hangs the GPU); keep that test in the CPU suite.
-    if (wave < 4) {
+    if (is_prod) {
         // =========================================== product waves ===========================================================
         WT W[kNT];                                                          // the head of the weight stream (held back until here: five tiles
         const float* __restrict__ wp = a.wstream + (size_t)w * kWaveTiles * kTileX3;     // live across the embedding would spill)
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         asm volatile("" ::: "memory");
 #ifdef GATOR_DIAG
         unsigned long long* st_lds = reinterpret_cast<unsigned long long*>(lds + kGat8LdsFloats);
-        unsigned long long* st_out = (a.stamps && b == 0 && t == 0) ? st_lds : nullptr;
+        unsigned long long* st_out = (a.stamps && b == 0 && w == 0 && lane == 0) ? st_lds : nullptr;
         if (st_out) for (int i_ = 0; i_ < kDepth * 23 * 2; ++i_) st_lds[i_] = 0;
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
         int bi_ = 0;
@@ -646,8 +653,23 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         for (int n = 0; n < 1 + 22 * kDepth; ++n) __syncthreads();
         return;
     }
+    if (a.dbg & 16) {      // barriers + the L2 warm-up of the weight streams only: what the product waves cost with warm weights
+        __syncthreads();
+        for (int bi = 0; bi < kDepth; ++bi)
+            for (int n = 1; n <= 22; ++n) {
+                if ((n == 2 || n == 19) && bi + 1 < kDepth && a.pf_loads > 0) {
+                    const char* wsrc = reinterpret_cast<const char*>(a.wstream + ((size_t)w * kWaveTiles + (size_t)(bi + 1) * kBlkTiles) * kTileX3);
+                    const int share = a.pf_loads * 8192, first = ((b >> 3) % a.pf_n) * share, lim = kBlkTiles * kTileX3 * 4 - 128;
+                    const int i0 = n == 2 ? 0 : (a.pf_loads + 1) / 2, i1 = n == 2 ? (a.pf_loads + 1) / 2 : a.pf_loads;
+                    for (int i = i0; i < i1; ++i)
+                        glds4(reinterpret_cast<const float*>(wsrc + min(first + i * 8192 + lane * 128, lim)), lds + kDummy + w * 256);
+                }
+                __syncthreads();
+            }
+        return;
+    }
     unsigned long long* st_lds = reinterpret_cast<unsigned long long*>(lds + kGat8LdsFloats);
-    unsigned long long* st_out = (a.stamps && b == 0 && t == 256) ? st_lds + (size_t)kDepth * 23 * 2 : nullptr;
+    unsigned long long* st_out = (a.stamps && b == 0 && w == 0 && lane == 0) ? st_lds + (size_t)kDepth * 23 * 2 : nullptr;
     if (st_out) for (int i_ = 0; i_ < kDepth * 23 * 2 + kDepth * 8; ++i_) st_out[i_] = 0;
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
     int bi_ = 0;
