@@ -555,6 +555,21 @@ def main():
                 del graph
             except Exception as e:       # a box whose runtime refuses the capture does not invalidate the line
                 variants['headline replayed from a hipGraph (torch.cuda.CUDAGraph)'] = {'error': str(e)[:200]}
+            # the same through the library's own switch (gator_set_graph_replay: the forward is captured the second time it is seen with the
+            # same batch and tensors, then one hipGraphLaunch per call) -- what a caller of the C ABI gets without torch
+            try:
+                mg, _, _ = build_model(J, a.impl, dev)
+                mg.precision = a.precision
+                mg.set_graph_replay(True)
+                og = (torch.empty(B, 6890, 3, device=dev), torch.empty(B, J, 3, device=dev))
+                for _ in range(max(a.warmup, 3)):
+                    mg(x, out=og)
+                dv = sorted(block(lambda: mg(x, out=og), a.steps)[0] for _ in range(5))[2]
+                variants['headline with the library replaying the forward from a hipGraph (gator_set_graph_replay)'] = {
+                    'value': round(B * a.steps / dv, 1), 'ms_per_step': round(dv / a.steps * 1e3, 4), 'graph_launches': mg.graph_launches()}
+                del mg
+            except Exception as e:
+                variants['headline with the library replaying the forward from a hipGraph (gator_set_graph_replay)'] = {'error': str(e)[:200]}
             line['variants'] = variants
         if world == 1 and B >= 128 and a.subbatch_variant:
             # same workload with the library's sub-batch pipelining (two half-batches on two streams; bit-identical results).

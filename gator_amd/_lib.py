@@ -46,6 +46,7 @@ SIGNATURES = {
     'gator_enable_block_taps': (_I, [_P, _I]),
     'gator_set_encoder': (_I, [_P, _I]),
     'gator_encoder_for_batch': (_I, [_P, _I]),
+    'gator_set_graph_replay': (_I, [_P, _I]),
     'gator_profile_enable': (_I, [_P, _I]),
     'gator_profile_read': (_I, [_P, ctypes.c_char_p, _L, _P, _P, _I, _P]),
     'gator_regress_joints_f32': (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P]),

@@ -462,6 +462,12 @@ extern "C" int gator_encoder_for_batch(gator_ctx* c, int32_t B) {
     return n == 0 ? GATOR_ENCODER_SAMPLE : GATOR_ENCODER_TILED;      // a batch the policy splits between both counts as tiled (its full rounds are)
 }
 
+extern "C" int gator_set_graph_replay(gator_ctx* c, int32_t on) {
+    if (!c) return fail(GATOR_EINVAL, "gator_set_graph_replay: null ctx");
+    if (c->impl != GATOR_IMPL_FUSED || !c->fused) return fail(GATOR_EUNSUPPORTED, "gator_set_graph_replay: fused ctx only");
+    return fused_set_graph_replay(c, on);
+}
+
 extern "C" int gator_set_encoder(gator_ctx* c, int32_t mode) {
     if (!c) return fail(GATOR_EINVAL, "gator_set_encoder: null ctx");
     if (c->impl != GATOR_IMPL_FUSED || !c->fused) return fail(GATOR_EUNSUPPORTED, "gator_set_encoder: fused ctx only");

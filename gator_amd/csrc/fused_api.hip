@@ -11,6 +11,15 @@
 namespace gator {
 namespace {
 
+static void graph_slot_free(FusedState::GraphSlot& g) {
+    if (g.exec) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
+    if (g.graph) (void)hipGraphDestroy((hipGraph_t)g.graph);
+    g.exec = g.graph = nullptr;
+}
+static void graphs_clear(FusedState* f) {
+    for (auto& g : f->graphs) graph_slot_free(g);
+    f->graphs.clear();
+}
 // The launchers read the workspace through the FusedWs base of FusedState; a scope loads set `i` into it and stores it back
 // (possibly re-allocated) on exit.  Set 0 is the normal workspace, set 1 the second half-batch in sub-batch mode.
 struct WsScope {
@@ -24,6 +33,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
     if (f->ws && B <= f->cap) return GATOR_OK;
     if (f->ws) {
         GATOR_HIP_CHECK(hipDeviceSynchronize());
+        graphs_clear(f);                                 // captured forwards hold pointers into the old workspace
         GATOR_HIP_CHECK(hipFree(f->ws));
         f->ws = nullptr;
     }
@@ -224,6 +234,7 @@ int fused_create(gator_ctx* c, void* stream) {
     const char* mx3 = getenv("GATOR_MDR_X3");
     f->mdr_x3 = mx3 ? atoi(mx3) : 2;
     if (f->mdr_x3 < 0 || f->mdr_x3 > 2) return fail(GATOR_EINVAL, "GATOR_MDR_X3 must be 0, 1 or 2");
+    if (const char* e = getenv("GATOR_GRAPH")) f->graph_replay = atoi(e) != 0;      // hipGraph replay of repeated forwards (gator_set_graph_replay)
     const char* mper = getenv("GATOR_MDR_PERSIST");
     f->mdr_persist = mper ? (atoi(mper) != 0 ? 1 : 0) : -1;
     const char* mpg = getenv("GATOR_MDR_PERSIST_GRID");
@@ -365,6 +376,8 @@ void fused_destroy(gator_ctx* c) {
         if (c->fused->sets[i].ws) (void)hipFree(c->fused->sets[i].ws);
         if (c->fused->sets[i].vcp16) (void)hipFree(c->fused->sets[i].vcp16);
     }
+    graphs_clear(c->fused);
+    if (c->fused->cap_stream) (void)hipStreamDestroy((hipStream_t)c->fused->cap_stream);
     if (c->fused->aux_stream) (void)hipStreamDestroy((hipStream_t)c->fused->aux_stream);
     if (c->fused->ev_fork) (void)hipEventDestroy((hipEvent_t)c->fused->ev_fork);
     if (c->fused->ev_join) (void)hipEventDestroy((hipEvent_t)c->fused->ev_join);
@@ -459,6 +472,69 @@ int fused_mdr_forward(gator_ctx* c, const float* pc, int B, float* verts, void* 
 
 static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream, bool bf16, float* joints = nullptr);
 
+int fused_set_graph_replay(gator_ctx* c, int on) {
+    FusedState* f = c->fused;
+    if (!f) return fail(GATOR_EUNSUPPORTED, "gator_set_graph_replay: fused ctx only");
+    if (on >= 0) {
+        if (!on && f->graph_replay) { GATOR_HIP_CHECK(hipDeviceSynchronize()); graphs_clear(f); }
+        f->graph_replay = on != 0;
+    }
+    return (int)std::min<unsigned long long>(f->graph_launches, 0x7fffffffull);
+}
+
+// The forward of fused_forward_one replayed from a hipGraph (see FusedState::GraphSlot).  Runs inside a WsScope.
+static int fused_forward_graph(gator_ctx* c, const float* pose2d, int B, float* verts, float* pose3d, void* stream, bool bf16) {
+    FusedState* f = c->fused;
+    int rc = fused_ensure_ws(c, B);                      // may reallocate: before the key is formed, never inside a capture
+    if (rc) return rc;
+    FusedState::GraphSlot* slot = nullptr;
+    for (auto& g : f->graphs)
+        if (g.B == B && g.in == pose2d && g.verts == verts && g.pose3d == pose3d && g.bf16 == bf16 && g.tiled == f->gat_tiled && g.persist == f->mdr_persist && g.ws == f->ws) { slot = &g; break; }
+    if (!slot) {                                         // first sight: remember the key, run directly
+        if ((int)f->graphs.size() >= FusedState::kGraphSlots) {
+            auto lru = std::min_element(f->graphs.begin(), f->graphs.end(), [](const FusedState::GraphSlot& a, const FusedState::GraphSlot& b) { return a.used < b.used; });
+            if (lru->exec) GATOR_HIP_CHECK(hipDeviceSynchronize());      // a replay of it may still be running
+            graph_slot_free(*lru);
+            f->graphs.erase(lru);
+        }
+        FusedState::GraphSlot g;
+        g.B = B; g.in = pose2d; g.verts = verts; g.pose3d = pose3d; g.bf16 = bf16; g.tiled = f->gat_tiled; g.persist = f->mdr_persist; g.ws = f->ws;
+        g.used = ++f->graph_clock;
+        f->graphs.push_back(g);
+        return fused_forward_one(c, pose2d, B, verts, pose3d, stream, bf16);
+    }
+    slot->used = ++f->graph_clock;
+    if (!slot->exec) {                                   // second sight: capture on the private stream
+        if (!f->cap_stream) {
+            hipStream_t s2;
+            GATOR_HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            f->cap_stream = s2;
+        }
+        hipStream_t cs = (hipStream_t)f->cap_stream;
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ex = nullptr;
+        bool ok = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            rc = fused_forward_one(c, pose2d, B, verts, pose3d, cs, bf16);
+            ok = hipStreamEndCapture(cs, &g) == hipSuccess && rc == GATOR_OK && g != nullptr;
+            if (ok) ok = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (!ok) {                                       // not capturable here: fall back to direct launches for good
+            (void)hipGetLastError();
+            if (ex) (void)hipGraphExecDestroy(ex);
+            if (g) (void)hipGraphDestroy(g);
+            f->graph_replay = false;
+            if (rc) return rc;
+            return fused_forward_one(c, pose2d, B, verts, pose3d, stream, bf16);
+        }
+        slot->graph = g; slot->exec = ex;
+    }
+    GATOR_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)slot->exec, (hipStream_t)stream));
+    ++f->graph_launches;
+    c->set_tap(TAP_FEAT, f->feat, (int64_t)B * c->J * kC);
+    return GATOR_OK;
+}
+
 // Sub-batch pipelining: with >= 2 x 64 samples the batch runs as two halves on two streams (fork/join by events, so the
 // caller's stream semantics are unchanged and the pattern is graph-capturable).  Samples are independent and every kernel
 // is batch-size invariant bit for bit, so the result is identical; the gain (+8 % at B=256) comes from one half's kernels
@@ -469,6 +545,7 @@ int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float*
     const int want = c->subbatch_streams > 0 ? c->subbatch_streams : env_split;
     if (want < 2 || B < 128) {
         WsScope ws(f, 0);
+        if (f->graph_replay && !c->profiling && !c->block_taps) return fused_forward_graph(c, pose2d, B, verts, pose3d, stream, bf16);
         return fused_forward_one(c, pose2d, B, verts, pose3d, stream, bf16);
     }
     if (!f->aux_stream) {

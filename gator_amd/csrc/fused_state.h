@@ -1,6 +1,7 @@
 // State of the fused path: packed (MFMA-operand-order) weights and the per-batch workspace.
 #pragma once
 #include "internal.h"
+#include <vector>
 
 namespace gator {
 
@@ -92,6 +93,21 @@ struct FusedState : FusedWs {
     const float* head_b = nullptr;      // [32]
     const float* tok_base = nullptr;    // [14][2][4][64][4]  v431 part of get_verts_feature + bias + pos_v  (T-layout tiles)
     const float* tok_w3 = nullptr;
+    // hipGraph replay of the full forward (gator_set_graph_replay / GATOR_GRAPH=1).  A forward is identified by (batch, the three
+    // caller pointers, precision, encoder pin, persistent-launch state, workspace): the first time a key is seen the forward runs
+    // directly (lazy allocations happen there), the second time it is captured on a private stream, from then on one hipGraphLaunch
+    // on the caller's stream replaces the six launches.  Keys are kept LRU (kGraphSlots); anything unexpected switches the feature off.
+    struct GraphSlot {
+        int B = 0; const void *in = nullptr, *verts = nullptr, *pose3d = nullptr; bool bf16 = false;
+        int tiled = 0, persist = 0; const void* ws = nullptr;
+        void *graph = nullptr, *exec = nullptr;
+        unsigned long long used = 0;
+    };
+    static constexpr int kGraphSlots = 8;
+    bool graph_replay = false;
+    void* cap_stream = nullptr;
+    std::vector<GraphSlot> graphs;
+    unsigned long long graph_clock = 0, graph_launches = 0;
     // sub-batch pipelining (two half-batches on two streams: one half's kernel tails are filled by the other's work)
     FusedWs sets[2];
     void* aux_stream = nullptr;

@@ -122,6 +122,7 @@ int fused_set_joint_regressor(gator_ctx* c, const int32_t* row, const int32_t* c
 int fused_forward_joints(gator_ctx* c, const float* pose2d, int B, float* joints, float* pose3d, float* verts, void* stream);
 int fused_set_encoder(gator_ctx* c, int mode);
 void fused_disable_persist(gator_ctx* c);
+int fused_set_graph_replay(gator_ctx* c, int on);          // returns the number of graph launches so far (>= 0)
 // samples of a batch of B that the sample-tiled encoder takes under the policy in force (unpinned: under the ctx's own AUTO policy)
 int fused_tiled_samples(const gator_ctx* c, int B, bool unpinned = false);      // from now on the four MDR stages run as four launches on this ctx
 }  // namespace gator

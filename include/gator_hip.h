@@ -138,6 +138,14 @@ int gator_set_encoder(gator_ctx* ctx, int32_t mode);
  * What a sharded run pins for every call so that the rule lives in one place (gator_amd/parallel.py). */
 int gator_encoder_for_batch(gator_ctx* ctx, int32_t batch);
 
+/* hipGraph replay of repeated forwards on a fused ctx (off by default; GATOR_GRAPH=1 switches it on at gator_create).  A forward is
+ * identified by (batch, the three pointers, precision, encoder pin): the second time the same call is seen it is captured on a private
+ * stream, from then on gator_forward_f32 / _bf16 is ONE hipGraphLaunch on the caller's stream (same kernels, same results bit for
+ * bit; up to 8 calls are remembered, least recently used first out).  Needs stable pointers (pre-allocated outputs); a call that
+ * is profiled, tapped or split into sub-batches runs directly.  on = 1 / 0 switches, on < 0 only queries; returns the number of
+ * graph launches so far (>= 0) or a negative error. */
+int gator_set_graph_replay(gator_ctx* ctx, int32_t on);
+
 /* Measurement hook (bench.py `roofline`): gator_profile_enable(ctx, n) with n >= 1 brackets every stage launch of every
  * n-th forward by a hipEvent pair recorded on the launch stream (n = 0 switches it off).  gator_profile_read synchronises those events and returns, per stage name
  * ('\n'-separated in `names`), the summed duration in ms and the number of launches since the last enable/read. */
