@@ -321,7 +321,7 @@ __device__ __forceinline__ f32x16 ln_stats(const float* ST, const f32x16& xw, co
 // ---- token rows that do not exist.  A tile whose REGISTERS run over tokens (C layout: v[r] <-> token kap(r) + 4h; S^T and P^T with
 // the key on the row) has live data only in registers r < LR: tokens 0 .. J-1 with J = 17 / 19 sit in r <= 8 / 10.  The rows behind
 // them hold products against zero operand rows or masked scores (probability exactly 0): every instruction spent on them is wasted,
-// and the helper waves are the long side of most steps.  LR (even: 10 for J <= 18, 12 for J <= 20, else 16) is a template
+// and the helper waves are the long side of most steps.  LR (even: 10 for J <= 18, 12 for J <= 20; 16 = every row, the six-product form) is a template
 // parameter of the kernel; skipping dead rows changes no bit of a live value (sums lose terms that are exactly +0).
 template <int LR>
 __device__ __forceinline__ X2 x2_split_rows(const f32x16& v) {     // x2_split with zero halves for the dead rows
@@ -1020,7 +1020,6 @@ int gat8_prepare_device() {
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
-    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     return GATOR_OK;
 }
 
@@ -1116,7 +1115,7 @@ int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* 
     if (!f->gat8_h4) k_gat8<false, 16><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else if (c->J <= 18) k_gat8<true, 10><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else if (c->J <= 20) k_gat8<true, 12><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
-    else k_gat8<true, 16><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else return fail(GATOR_EUNSUPPORTED, "k_gat8: more than 20 joints (gator_create admits 17 and 19)");
     GATOR_HIP_CHECK(hipGetLastError());
 #ifdef GATOR_DIAG
     if (a.stamps) {     // diagnostic build: synchronous read-back; blocks 1..5 averaged (block 0 carries the cold start)
