@@ -226,7 +226,9 @@ def pmc_digest(B):
     for name in ('r04_pmc_summary_B256.json', 'r03_pmc_summary_B256.json', 'r02_pmc_summary_B256.json', 'r01_pmc_summary_B256.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
-            return json.load(open(path)), name
+            prov = os.path.join(ROOT, 'profiles', name.replace('_pmc_summary_B256.json', '_pmc_provenance.json'))
+            commit = json.load(open(prov)).get('commit') if os.path.exists(prov) else None
+            return json.load(open(path)), (name + (' @ ' + commit if commit else ''))
     return None, None
 
 

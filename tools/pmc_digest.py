@@ -75,6 +75,17 @@ def main():
                     d['valu_active_over_busy'] = round(avg.get('SQ_ACTIVE_INST_VALU', 0) / avg['SQ_BUSY_CYCLES'], 4)
     rows = sorted(summary.values(), key=lambda r: -r.get('avg_us', 0))
     json.dump(rows, open('profiles/%s_pmc_summary_B256.json' % tag, 'w'), indent=1)
+    # where the digest comes from: the commit checked out when it was made (the library that ran is built from it) -- bench.py
+    # prints it beside every digest-derived field
+    try:
+        import subprocess
+        head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+        dirty = bool(subprocess.run(['git', 'status', '--porcelain', '--', 'gator_amd/csrc'], capture_output=True, text=True).stdout.strip())
+    except OSError:
+        head, dirty = None, None
+    json.dump({'digest': '%s_pmc_summary_B256.json' % tag, 'commit': head, 'kernel_sources_modified': dirty,
+               'command': 'tools/profile_round.sh %s (bench.py --no-cpu-baseline --no-variants at B = 256)' % tag},
+              open('profiles/%s_pmc_provenance.json' % tag, 'w'), indent=1)
     for r in rows:
         print(r)
 
