@@ -30,13 +30,33 @@ __device__ __forceinline__ f32x16 x2_mma_agpr0(const X2& A, const X2& B) {
     mfma_acc(c, A.p[0][1], B.p[0][1]);
     return c;
 }
+
+// the 16x16x32 shape: one 32x32 (k = 32) product = 4 output quadrants x 1 MFMA of 16 cycles instead of 2 x 32 cycles; timing only
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mma16_pair(f32x16& acc, const f16x8& a0, const f16x8& b0, const f16x8& a1, const f16x8& b1) {
+    f32x4v q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { q[i][0] = acc[4 * i]; q[i][1] = acc[4 * i + 1]; q[i][2] = acc[4 * i + 2]; q[i][3] = acc[4 * i + 3]; }
+    q[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, q[0], 0, 0, 0);
+    q[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, q[1], 0, 0, 0);
+    q[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, q[2], 0, 0, 0);
+    q[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, q[3], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[4 * i] = q[i][0]; acc[4 * i + 1] = q[i][1]; acc[4 * i + 2] = q[i][2]; acc[4 * i + 3] = q[i][3]; }
+}
+__device__ __forceinline__ f32x16 x2_mma16(const X2& A, const X2& B, f32x16 acc) {      // three products, each both k-steps at once
+    mma16_pair(acc, A.p[1][0], B.p[0][0], A.p[1][1], B.p[0][1]);
+    mma16_pair(acc, A.p[0][0], B.p[1][0], A.p[0][1], B.p[1][1]);
+    mma16_pair(acc, A.p[0][0], B.p[0][0], A.p[0][1], B.p[0][1]);
+    return acc;
+}
 #define ATTN_PV(VB, PX) { O2 = x2_mma_small(VB, PX, O2); O = x2_mma_main(VB, PX, O); }
 #define ATTN_TILE_X2(KT, KB, VB) ATTN_TILE_CUT(KT, KB, VB, 0)
 #define ATTN_TILE_CUT(KT, KB, VB, CUT_)                                                                            \
     {                                                                                                       \
         __builtin_amdgcn_s_setprio(0);                                                                      \
         f32x16 S;                                                                                           \
-        if constexpr ((CUT & 16) != 0) S = x2_mma_agpr0(KB, qx); else if constexpr ((CUT & 4) == 0) S = x2_mma(KB, qx, zero16()); else { _Pragma("unroll") for (int r = 0; r < 16; ++r) S[r] = (float)KB.p[0][r >> 3][r & 7] + (float)qx.p[0][r >> 3][r & 7]; } \
+        if constexpr ((CUT & 32) != 0) S = x2_mma16(KB, qx, zero16()); else if constexpr ((CUT & 16) != 0) S = x2_mma_agpr0(KB, qx); else if constexpr ((CUT & 4) == 0) S = x2_mma(KB, qx, zero16()); else { _Pragma("unroll") for (int r = 0; r < 16; ++r) S[r] = (float)KB.p[0][r >> 3][r & 7] + (float)qx.p[0][r >> 3][r & 7]; } \
         __builtin_amdgcn_s_setprio(1);                                                                      \
         float bm = -1e30f;                                                                                  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
@@ -65,7 +85,7 @@ __device__ __forceinline__ f32x16 x2_mma_agpr0(const X2& A, const X2& B) {
         X2 px_;                                                                                             \
         if constexpr ((CUT & 2) == 0) px_ = x2_split(S); else { _Pragma("unroll") for (int r = 0; r < 16; ++r) { px_.p[0][r >> 3][r & 7] = (_Float16)S[r]; } px_.p[1][0] = px_.p[0][1]; px_.p[1][1] = px_.p[0][0]; } \
         __builtin_amdgcn_s_setprio(0);                                                                      \
-        if constexpr ((CUT & 16) != 0) { mfma_acc(O2, VB.p[1][0], px_.p[0][0]); mfma_acc(O2, VB.p[0][0], px_.p[1][0]); mfma_acc(O2, VB.p[1][1], px_.p[0][1]); mfma_acc(O2, VB.p[0][1], px_.p[1][1]); mfma_acc(O, VB.p[0][0], px_.p[0][0]); mfma_acc(O, VB.p[0][1], px_.p[0][1]); } else if constexpr ((CUT & 4) == 0) { ATTN_PV(VB, px_) } else { _Pragma("unroll") for (int r = 0; r < 16; ++r) O[r] += (float)px_.p[0][r >> 3][r & 7] * (float)VB.p[0][r >> 3][r & 7]; } \
+        if constexpr ((CUT & 32) != 0) { O = x2_mma16(VB, px_, O); } else if constexpr ((CUT & 16) != 0) { mfma_acc(O2, VB.p[1][0], px_.p[0][0]); mfma_acc(O2, VB.p[0][0], px_.p[1][0]); mfma_acc(O2, VB.p[1][1], px_.p[0][1]); mfma_acc(O2, VB.p[0][1], px_.p[1][1]); mfma_acc(O, VB.p[0][0], px_.p[0][0]); mfma_acc(O, VB.p[0][1], px_.p[0][1]); } else if constexpr ((CUT & 4) == 0) { ATTN_PV(VB, px_) } else { _Pragma("unroll") for (int r = 0; r < 16; ++r) O[r] += (float)px_.p[0][r >> 3][r & 7] * (float)VB.p[0][r >> 3][r & 7]; } \
     }
 // DB = true: the shipped form (next tile's K / V in flight in a second register set); false: one set, refilled right behind its last use
 template <bool DB, int CUT = 0>
@@ -263,6 +283,8 @@ int main() {
     run<2, false, 16>(q, kv, out, n_cu, "S, O, O2 in AGPRs (inline-asm MFMAs), 2 waves");
     run<1, false, 16>(q, kv, out, n_cu, "S, O, O2 in AGPRs, 1 wave / SIMD");
     run<3, false, 16>(q, kv, out, n_cu, "S, O, O2 in AGPRs, 3 waves / SIMD");
+    run<2, false, 32>(q, kv, out, n_cu, "the same matrix cycles on the 16x16x32 shape, 2 waves");
+    run<2, false, 0>(q, kv, out, n_cu, "2 waves / SIMD, one K/V set (again)");
     printf("8-wave workgroups (2 waves / SIMD), software-pipelined loop (S of the next tile issued behind P.V):\n");
     run_pp<0>(q, kv, out, n_cu, "no barrier (free-running pair)");
     run_pp<2>(q, kv, out, n_cu, "ping-pong: barrier after each half step");
