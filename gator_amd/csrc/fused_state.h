@@ -9,7 +9,7 @@ constexpr int kVT = 14;                 // 32-token tiles per sample (431 -> 448
 constexpr int kOB = 216;                // 32-vertex output blocks of the upsample GEMM (6890 -> 6912)
 constexpr int kCB = 14;                 // 32-wide k blocks over the 431 coarse vertices
 constexpr int kTile = 32 * 32;          // floats in one packed 32x32 tile ([4 g][64 lanes][4])
-constexpr int kMdrCtrChunks = 64;       // persistent MDR launches one forward may be cut into (launch_mdr: chunks of 320 .. 640 samples)
+constexpr int kMdrCtrChunks = 64;       // persistent MDR launches one forward may be cut into (launch_mdr: chunks of 256 .. 511 samples)
 // words of k_mdr_persist's counters for a forward of B samples: per launch a 32-word header (tickets, error flag) + 4 counts per sample
 __host__ __device__ inline size_t mdr_ctr_words(int B) { return (size_t)32 * kMdrCtrChunks + (size_t)4 * B; }
 

@@ -1243,15 +1243,16 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         StageTimer tm(c, "mdr_layers", stream);
         int grid = 2 * f->n_cu;             // two workgroups per CU is what the registers allow; any grid drains the queues
         if (f->mdr_persist_grid > 0) grid = f->mdr_persist_grid;      // GATOR_MDR_PERSIST_GRID (tests: a grid that leaves XCDs without a workgroup)
-        // A large batch runs as several launches over chunks of 320 .. 640 samples.  The tickets are stage-major, so a sample's Q/K/V/residual
+        // A large batch runs as several launches over chunks of 256 .. 511 samples.  The tickets are stage-major, so a sample's Q/K/V/residual
         // tiles (448 KB) are read one stage after they were written: at B = 256 / 384 the 115 / 172 MB in between stay in the Infinity
         // Cache, at B = 512 and above they do not and the launch costs 1.545 - 1.565 us per sample instead of 1.495 (measured, round 4).
         // Chunks are independent (a tile depends on its own sample only) and each writes its own tiles exactly once, so the hand-off
         // rules of the kernel hold per launch; results are bitwise those of one launch.
-        // Chunk size, measured (MDR stage, ms): B = 512: one launch 0.787, 2 x 256 0.835; B = 1024: one launch 1.560, 3 x 342 1.533, 4 x 256
-        // 1.649; B = 2048: one launch 3.246, 6 x 342 3.064, 8 x 256 3.270 -- launches of 320 .. 400 samples are the efficient ones
-        // (1.495 us per sample), 256-sample launches inside a larger forward are not (1.63).  So: floor(B / 320) launches.
-        int nch = f->mdr_persist_chunk > 0 ? (B + f->mdr_persist_chunk - 1) / f->mdr_persist_chunk : B / 320;
+        // Chunk size, measured at the end of round 4 (MDR stage in ms, one box, two repetitions; GATOR_MDR_PERSIST_CHUNK): B = 512: one
+        // launch 0.79, 2 x 256 0.76; B = 1024: 3 x 342 1.525, 4 x 256 1.49; B = 2048: 6 x 342 2.99 - 3.18, 8 x 256 2.97 - 3.00; B = 4096:
+        // 12 x 342 6.43, 16 x 256 6.34 -- so floor(B / 256) launches.  (Every chunk using the first chunk's tile region again -- legal: a
+        // chunk-local sample keeps its XCD and a launch starts with an empty L1 -- changes nothing: the tiles are written before they are read.)
+        int nch = f->mdr_persist_chunk > 0 ? (B + f->mdr_persist_chunk - 1) / f->mdr_persist_chunk : B / 256;
         if (nch < 1) nch = 1;
         if (nch > kMdrCtrChunks) nch = kMdrCtrChunks;
         const size_t tq = f->mdr_x3 == 1 ? kTileX3 : kTile;
