@@ -490,6 +490,8 @@ extern "C" int gator_get_tap(gator_ctx* c, const char* name, float* dst, int64_t
             n = c->taps[TAP_GAT_BLOCKS].n / kDepth;
             src = c->taps[TAP_GAT_BLOCKS].p + (int64_t)blk * n;
         }
+        if (!src && (!strcmp(name, "mdr_lbf2") || blk >= 0))
+            return fail(GATOR_EMISSING, "gator_get_tap: '%s' is recorded only after gator_enable_block_taps(ctx, 1) (fused ctx: its stores cost time)", name);
         if (!src) return fail(GATOR_EMISSING, "gator_get_tap: no tap named '%s' from the last forward", name);
     }
     if (count) *count = n;

@@ -610,7 +610,7 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         else { vf[0] += y0; vf[1] += y1; }
     }
     if (MODE == 2) {
-        if (token < kV) {
+        if (a.lbf != nullptr && token < kV) {      // the "mdr_lbf2" tap (110 KB per sample): only when taps are recorded
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -1178,7 +1178,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
                         {f->vf + 2 * per, f->q + 2 * perq, f->k + 2 * perq, f->v + 2 * perq}};
     MdrArgs a{};
     a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.xout = pc ? nullptr : x_out; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
-    a.head_w = f->mdr_x3 ? f->wxbuf + (size_t)(f->head_w - f->lay[0].wq) / kTile * kTileX3 : f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = f->lbf;
+    a.head_w = f->mdr_x3 ? f->wxbuf + (size_t)(f->head_w - f->lay[0].wq) / kTile * kTileX3 : f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = c->block_taps ? f->lbf : nullptr;      // the "mdr_lbf2" tap costs 110 KB of stores per sample: recorded with the block taps only
     a.lin_s = f->mdr_x3 == 2 ? std::ldexp(kActScale, f->mdr_wshift) : 1.0f;      // 4-product linears: 16 x activations, 2^wshift x weights
     a.lin_inv = 1.0f / a.lin_s;
     const int nwg = (B * kVT + 3) / 4;
@@ -1270,7 +1270,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
                 if (s.pc) s.pc += (size_t)b0 * c->J * 133;
                 if (s.xout) s.xout += (size_t)b0 * c->J * 3;
                 s.hf += (size_t)b0 * kV * 32;
-                s.lbf += (size_t)b0 * kV * kE;
+                if (s.lbf) s.lbf += (size_t)b0 * kV * kE;
             }
             pc_.ctr = f->mdr_ctr + plan.block(ch);
             if (f->mdr_x3 == 2) k_mdr_persist<2><<<grid, 256, 0, st>>>(pc_);
@@ -1311,7 +1311,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         else k_mdr_head<512, false><<<B, 512, 0, st>>>(ha);
     }
     GATOR_HIP_CHECK(hipGetLastError());
-    c->set_tap(TAP_MDR_LBF2, f->lbf, (int64_t)B * kV * kE);
+    c->set_tap(TAP_MDR_LBF2, c->block_taps ? f->lbf : nullptr, c->block_taps ? (int64_t)B * kV * kE : 0);
     c->set_tap(TAP_VERT431, f->vc, (int64_t)B * kV * 3);
     return GATOR_OK;
 }

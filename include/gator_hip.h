@@ -119,7 +119,8 @@ int gator_upsample_f32(gator_ctx* ctx, const float* vert431, int32_t batch, floa
  * dst is a device pointer with room for `capacity` floats; *count receives the element count. */
 int gator_get_tap(gator_ctx* ctx, const char* name, float* dst, int64_t capacity, int64_t* count, void* stream);
 /* Additional taps "gat_block0" .. "gat_block5" [B,J,128]: the residual stream after each GATBlock (lib/models/GAT.py:33-43,
- * :145-147).  Off by default (the stores cost time); fused ctx only.  Taps never outlive the next call on the ctx; the "feat" tap
+ * :145-147).  Off by default (the stores cost time); fused ctx only.  On a fused ctx the same switch also governs "mdr_lbf2" (110 KB of
+ * stores per sample that nothing else reads): without it gator_get_tap("mdr_lbf2") returns GATOR_EMISSING.  Taps never outlive the next call on the ctx; the "feat" tap
  * of the stand-alone gator_gat_forward_f32 aliases the caller's `feat` buffer. */
 int gator_enable_block_taps(gator_ctx* ctx, int32_t on);
 

@@ -45,7 +45,13 @@ def test_golden_forward(built):
 def test_golden_taps(built):
     name, impl, z, m = built
     B, J = z['pose2d'].shape[:2]
-    m(torch.from_numpy(z['pose2d']).cuda())
+    x = torch.from_numpy(z['pose2d']).cuda()
+    m(x)
+    if impl == 'fused':      # the fused path stores "mdr_lbf2" (110 KB per sample that nothing reads) only with the tap switch on
+        with pytest.raises(RuntimeError, match='gator_enable_block_taps'):
+            m.get_tap('mdr_lbf2', (B, 431, 64))
+        m.enable_block_taps(True)
+        m(x)
     for tap, shape in (('hop_path_bias', (8, J, J)), ('feat', (B, J, 128)), ('mdr_lbf2', (B, 431, 64)), ('vert431', (B, 431, 3))):
         t = m.get_tap(tap, shape).cpu().numpy().astype(np.float64)
         ref = z[tap].astype(np.float64)
