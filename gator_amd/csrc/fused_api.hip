@@ -545,7 +545,11 @@ int fused_forward(gator_ctx* c, const float* pose2d, int B, float* verts, float*
     const int want = c->subbatch_streams > 0 ? c->subbatch_streams : env_split;
     if (want < 2 || B < 128) {
         WsScope ws(f, 0);
-        if (f->graph_replay && !c->profiling && !c->block_taps) return fused_forward_graph(c, pose2d, B, verts, pose3d, stream, bf16);
+        if (f->graph_replay && !c->profiling && !c->block_taps) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;      // a caller that is capturing the forward itself gets the plain launches
+            if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+            if (cs == hipStreamCaptureStatusNone) return fused_forward_graph(c, pose2d, B, verts, pose3d, stream, bf16);
+        }
         return fused_forward_one(c, pose2d, B, verts, pose3d, stream, bf16);
     }
     if (!f->aux_stream) {

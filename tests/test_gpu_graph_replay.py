@@ -102,3 +102,31 @@ def test_graph_replay_on_a_side_stream():
         s.synchronize()
     assert torch.equal(v, want[0]) and torch.equal(p, want[1])
     assert m.graph_launches() == 3
+
+
+@pytest.mark.timeout(300)
+def test_graph_replay_steps_aside_for_a_caller_that_captures():
+    """torch.cuda.CUDAGraph around a module whose library-level replay is on: the forward is captured by the caller as plain launches."""
+    z, ref = build_model('h36m17_bn', 'fused')
+    z, m = build_model('h36m17_bn', 'fused')
+    m.set_graph_replay(True)
+    B = 64
+    x = _x(B, 17, 7)
+    want = ref(x)
+    out = (torch.empty(B, 6890, 3, device='cuda'), torch.empty(B, 17, 3, device='cuda'))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m(x, out=out)
+        m(x, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    n = m.graph_launches()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        m(x, out=out)
+    out[0].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
+    assert m.graph_launches() == n                         # nothing was replayed by the library inside the caller's capture
