@@ -37,19 +37,26 @@ __global__ void k_preprocess(const float* __restrict__ in, int B, int jin, int c
 // 3x3 SVD by one-sided Jacobi (Hestenes) in fp64: G = H V is driven to orthogonal columns; s_i = |G_i|, U_i = G_i / s_i.
 __device__ void svd3(const double H[3][3], double U[3][3], double s[3], double V[3][3]) {
     double G[3][3];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) { G[i][j] = H[i][j]; V[i][j] = i == j ? 1.0 : 0.0; }
+#pragma unroll 1
     for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0.0;
+#pragma unroll
         for (int p = 0; p < 2; ++p)
+#pragma unroll
             for (int q = p + 1; q < 3; ++q) {
                 double a = 0.0, bq = 0.0, c = 0.0;
+#pragma unroll
                 for (int i = 0; i < 3; ++i) { a += G[i][p] * G[i][p]; bq += G[i][q] * G[i][q]; c += G[i][p] * G[i][q]; }
                 off = fmax(off, fabs(c) / (sqrt(a * bq) + 1e-300));
                 if (fabs(c) <= 1e-300) continue;
                 const double zeta = (bq - a) / (2.0 * c);
                 const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+#pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const double gp = G[i][p], gq = G[i][q];
                     G[i][p] = cs * gp - sn * gq;  G[i][q] = sn * gp + cs * gq;
@@ -59,18 +66,24 @@ __device__ void svd3(const double H[3][3], double U[3][3], double s[3], double V
             }
         if (off < 1e-15) break;
     }
+#pragma unroll
     for (int j = 0; j < 3; ++j) s[j] = sqrt(G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j]);
     // sort descending (the reflection fix below must hit the SMALLEST singular value, as numpy's s[-1] does)
+#pragma unroll
     for (int i = 0; i < 2; ++i)
+#pragma unroll
         for (int j = i + 1; j < 3; ++j)
             if (s[j] > s[i]) {
                 const double ts = s[i]; s[i] = s[j]; s[j] = ts;
+#pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const double tg = G[r][i]; G[r][i] = G[r][j]; G[r][j] = tg;
                     const double tv = V[r][i]; V[r][i] = V[r][j]; V[r][j] = tv;
                 }
             }
+#pragma unroll
     for (int j = 0; j < 3; ++j)
+#pragma unroll
         for (int i = 0; i < 3; ++i) U[i][j] = s[j] > 1e-300 ? G[i][j] / s[j] : 0.0;
     if (s[2] <= 1e-14 * s[0]) {      // rank-deficient covariance (coplanar points): complete U with the cross product
         U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
@@ -82,25 +95,39 @@ __device__ void svd3(const double H[3][3], double U[3][3], double s[3], double V
 // rigid_transform_3D + rigid_align (lib/coord_utils.py:127-149): H = (A-ca)^T (B-cb) / n = U S V^T; R = V U^T, with the reflection
 // fix (det R < 0: s3 := -s3, V[:,2] := -V[:,2]); c = sum(s) / sum_axis var(A); t = -(cR) ca + cb; out = cR A + t.
 // similarity (Procrustes) fit of n points a onto t, fp64: aligned = c R a + tr   (lib/coord_utils.py:127-142)
-__device__ void rigid_fit(const double (*a)[3], const double (*t)[3], int n, double& c, double (&R)[3][3], double (&tr)[3]) {
+// The point sets live in LDS, one column per thread ([point][axis][thread]: conflict-free, no per-thread private arrays)
+struct Pts {
+    double* p; int tid, nt;
+    __device__ double& operator()(int i, int k) const { return p[(size_t)(i * 3 + k) * nt + tid]; }
+};
+__device__ void rigid_fit(const Pts& a, const Pts& t, int n, double& c, double (&R)[3][3], double (&tr)[3]) {
     double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
     for (int i = 0; i < n; ++i)
-        for (int k = 0; k < 3; ++k) { ca[k] += a[i][k]; cb[k] += t[i][k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ca[k] += a(i, k); cb[k] += t(i, k); }
+#pragma unroll
     for (int k = 0; k < 3; ++k) { ca[k] /= n; cb[k] /= n; }
     double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, var = 0.0;
     for (int i = 0; i < n; ++i) {
         double da[3], db[3];
-        for (int k = 0; k < 3; ++k) { da[k] = a[i][k] - ca[k]; db[k] = t[i][k] - cb[k]; var += da[k] * da[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { da[k] = a(i, k) - ca[k]; db[k] = t(i, k) - cb[k]; var += da[k] * da[k]; }
+#pragma unroll
         for (int r = 0; r < 3; ++r)
+#pragma unroll
             for (int cc = 0; cc < 3; ++cc) H[r][cc] += da[r] * db[cc];
     }
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
         for (int cc = 0; cc < 3; ++cc) H[r][cc] /= n;
     var /= n;
     double U[3][3], s[3], V[3][3];
     svd3(H, U, s, V);
     auto mkR = [&]() {
+#pragma unroll
         for (int r = 0; r < 3; ++r)
+#pragma unroll
             for (int cc = 0; cc < 3; ++cc) R[r][cc] = V[r][0] * U[cc][0] + V[r][1] * U[cc][1] + V[r][2] * U[cc][2];
     };
     mkR();
@@ -108,28 +135,34 @@ __device__ void rigid_fit(const double (*a)[3], const double (*t)[3], int n, dou
                        R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
     if (det < 0.0) {
         s[2] = -s[2];
+#pragma unroll
         for (int r = 0; r < 3; ++r) V[r][2] = -V[r][2];
         mkR();
     }
     c = (s[0] + s[1] + s[2]) / var;
+#pragma unroll
     for (int r = 0; r < 3; ++r) tr[r] = cb[r] - c * (R[r][0] * ca[0] + R[r][1] * ca[1] + R[r][2] * ca[2]);
 }
 
 constexpr int kMaxPts = 32;
+constexpr size_t kPtsLds = (size_t)2 * kMaxPts * 3 * 64 * sizeof(double);      // 96 KB: the two point sets of a 64-thread block
 __global__ void k_rigid_align(const float* __restrict__ A, const float* __restrict__ Bt, int nb, int n, float* __restrict__ out) {
+    extern __shared__ double pts_lds[];                  // [2][kMaxPts][3][blockDim.x]
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const float* a = A + (size_t)b * n * 3;
     const float* t = Bt + (size_t)b * n * 3;
-    double pa[kMaxPts][3], pt[kMaxPts][3];
+    const Pts pa{pts_lds, (int)threadIdx.x, (int)blockDim.x}, pt{pts_lds + (size_t)kMaxPts * 3 * blockDim.x, (int)threadIdx.x, (int)blockDim.x};
     for (int i = 0; i < n; ++i)
-        for (int k = 0; k < 3; ++k) { pa[i][k] = a[i * 3 + k]; pt[i][k] = t[i * 3 + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pa(i, k) = a[i * 3 + k]; pt(i, k) = t[i * 3 + k]; }
     double c, R[3][3], tr[3];
     rigid_fit(pa, pt, n, c, R, tr);
     float* o = out + (size_t)b * n * 3;
     for (int i = 0; i < n; ++i)
+#pragma unroll
         for (int r = 0; r < 3; ++r)
-            o[i * 3 + r] = (float)(c * (R[r][0] * pa[i][0] + R[r][1] * pa[i][1] + R[r][2] * pa[i][2]) + tr[r]);
+            o[i * 3 + r] = (float)(c * (R[r][0] * pa(i, 0) + R[r][1] * pa(i, 1) + R[r][2] * pa(i, 2)) + tr[r]);
 }
 
 // Per-sample evaluation errors in one launch (data/PW3D/dataset.py:273-286, 337-375): err[b][0] = mean distance of the root-aligned
@@ -138,9 +171,10 @@ __global__ void k_joint_errors(const float* __restrict__ P, const float* __restr
                                int root, float scale, float* __restrict__ err) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
+    extern __shared__ double pts_lds[];                  // [2][kMaxPts][3][blockDim.x]
     const float* p = P + (size_t)b * nj * 3;
     const float* t = T + (size_t)b * nj * 3;
-    double pa[kMaxPts][3], pt[kMaxPts][3];
+    const Pts pa{pts_lds, (int)threadIdx.x, (int)blockDim.x}, pt{pts_lds + (size_t)kMaxPts * 3 * blockDim.x, (int)threadIdx.x, (int)blockDim.x};
     double e0 = 0.0;
     for (int i = 0; i < ne; ++i) {
         const int j = idx ? idx[i] : i;
@@ -149,7 +183,7 @@ __global__ void k_joint_errors(const float* __restrict__ P, const float* __restr
             // float32 arithmetic where the reference has it: mesh * 1000, pred - pred[root], target - target[root], their difference
             const float pj = p[j * 3 + k] * scale, pr = p[root * 3 + k] * scale;
             const float dp = pj - pr, dt = t[j * 3 + k] - t[root * 3 + k];
-            pa[i][k] = dp; pt[i][k] = dt;
+            pa(i, k) = dp; pt(i, k) = dt;
             const float d = dp - dt;
             d2 += (double)d * (double)d;
         }
@@ -161,8 +195,8 @@ __global__ void k_joint_errors(const float* __restrict__ P, const float* __restr
     for (int i = 0; i < ne; ++i) {
         double d2 = 0.0;
         for (int r = 0; r < 3; ++r) {
-            const double al = (double)(float)(c * (R[r][0] * pa[i][0] + R[r][1] * pa[i][1] + R[r][2] * pa[i][2]) + tr[r]);
-            d2 += (al - pt[i][r]) * (al - pt[i][r]);
+            const double al = (double)(float)(c * (R[r][0] * pa(i, 0) + R[r][1] * pa(i, 1) + R[r][2] * pa(i, 2)) + tr[r]);
+            d2 += (al - pt(i, r)) * (al - pt(i, r));
         }
         e1 += sqrt(d2);
     }
@@ -296,14 +330,18 @@ extern "C" int gator_joint_errors_f32(const float* pred_joints, const float* tar
         return fail(GATOR_EINVAL, "gator_joint_errors_f32: bad arguments");
     const int ne = eval_joints ? n_eval : n_joint;
     if (ne < 3 || ne > 32) return fail(GATOR_EINVAL, "gator_joint_errors_f32: 3..32 evaluation joints");
-    k_joint_errors<<<(batch + 63) / 64, 64, 0, (hipStream_t)stream>>>(pred_joints, target_joints, batch, n_joint, eval_joints, ne, root, pred_scale, errors);
+    static const hipError_t lds_ok_ = hipFuncSetAttribute((const void*)k_joint_errors, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPtsLds);      // 96 KB > the 64 KB default
+    GATOR_HIP_CHECK(lds_ok_);
+    k_joint_errors<<<(batch + 63) / 64, 64, kPtsLds, (hipStream_t)stream>>>(pred_joints, target_joints, batch, n_joint, eval_joints, ne, root, pred_scale, errors);
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;
 }
 
 extern "C" int gator_rigid_align_f32(const float* a, const float* b, int32_t batch, int32_t n_points, float* aligned, void* stream) {
     if (!a || !b || !aligned || batch <= 0 || n_points < 3 || n_points > 32) return fail(GATOR_EINVAL, "gator_rigid_align_f32: bad arguments (3..32 points)");
-    k_rigid_align<<<(batch + 63) / 64, 64, 0, (hipStream_t)stream>>>(a, b, batch, n_points, aligned);
+    static const hipError_t lds_ok_ = hipFuncSetAttribute((const void*)k_rigid_align, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPtsLds);      // 96 KB > the 64 KB default
+    GATOR_HIP_CHECK(lds_ok_);
+    k_rigid_align<<<(batch + 63) / 64, 64, kPtsLds, (hipStream_t)stream>>>(a, b, batch, n_points, aligned);
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;
 }

@@ -14,7 +14,6 @@ HOT = ('k_gat<true', 'k_gat8', 'k_gat_lifter', 'k_gat_joint', 'k_gat_tiled<', 'k
 SCRATCH_BUDGET = {
     'k_gat_tiled<17, false>': 292, 'k_gat_tiled<19, false>': 300,     # 74 spilled VGPRs, stored once before the block loop and re-read once per block
     'k_gat_tiled<17, true>': 164, 'k_gat_tiled<19, true>': 192,       # the four-product form (default): operands on two planes free 32 registers
-    'k_joint_errors': 1552, 'k_rigid_align': 1552,      # fp64 3x3 Jacobi SVD per sample with dynamically indexed 3x3 arrays
 }
 _FIELD = re.compile(r'remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)')
 _NAME = re.compile(r'remark:\s+Function Name: (\S+)')
