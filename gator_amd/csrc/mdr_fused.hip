@@ -1251,7 +1251,9 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         // Chunk size, measured at the end of round 4 (MDR stage in ms, one box, two repetitions; GATOR_MDR_PERSIST_CHUNK): B = 512: one
         // launch 0.79, 2 x 256 0.76; B = 1024: 3 x 342 1.525, 4 x 256 1.49; B = 2048: 6 x 342 2.99 - 3.18, 8 x 256 2.97 - 3.00; B = 4096:
         // 12 x 342 6.43, 16 x 256 6.34 -- so floor(B / 256) launches.  (Every chunk using the first chunk's tile region again -- legal: a
-        // chunk-local sample keeps its XCD and a launch starts with an empty L1 -- changes nothing: the tiles are written before they are read.)
+        // chunk-local sample keeps its XCD and a launch starts with an empty L1 -- changes nothing: the tiles are written before they are read.
+        // Odd chunks on a second, low-priority stream so that a chunk's workgroups move into the slots the previous chunk's tail frees:
+        // nothing either, B = 512 .. 2048, two repetitions.)
         int nch = f->mdr_persist_chunk > 0 ? (B + f->mdr_persist_chunk - 1) / f->mdr_persist_chunk : B / 256;
         if (nch < 1) nch = 1;
         if (nch > kMdrCtrChunks) nch = kMdrCtrChunks;
