@@ -496,8 +496,12 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
     typedef typename std::conditional<H4, X2, X3>::type OT;
     const float inv = H4 ? a.lin_inv : 1.0f;
     // operand tile of a true-scale register tile; pick-up of a raw product tile with what is added to it
+    // Token lanes that do not exist (15 of a tile's 32 at J = 17) store ZERO operands: no live value changes (a token's row never
+    // meets another token's except through the masked J x J operators), but the MFMAs stop toggling on 47 % of their columns and
+    // the chip holds a higher clock -- k_gat8 163.7 -> 159.7 us on one box, bit-identical results (DESIGN.md 4c on why data matters).
+    const float op16 = ((threadIdx.x & 31) < a.J) ? 16.0f : 0.0f;
     auto st_opnd = [&](float* dst, int lane_, const f32x16& v) {
-        if constexpr (H4) x2_store(dst, lane_, x2_split(v * 16.0f)); else x3_store(dst, lane_, x3_split(v));
+        if constexpr (H4) x2_store(dst, lane_, x2_split(v * op16)); else x3_store(dst, lane_, x3_split(v));
     };
     auto pick = [&](const float* raw, int lane_, const f32x16& add) {
         if constexpr (H4) return fma16(load_block(raw, lane_), inv, add); else return load_block(raw, lane_) + add;
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         // ---- step 2: q
         const f32x16 q = pick(R0w, lane, bq);
         X2 qx;                                                 // H4: q on two planes already here (the helper has slack in this step)
-        if constexpr (H4) qx = x2_split(q * 16.0f);
+        if constexpr (H4) qx = x2_split(q * op16);            // (op16: zero for the token lanes that do not exist)
         if (warm) warm_weights(0, (a.pf_loads + 1) / 2);
         GAT8_BAR(2);
         // ---- step 3: k; scores and softmax of heads 2w, 2w+1 (modules.py:121-133): S^T[key][query], query on the lane
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             const f32x16 k = pick(R1w, lane, bk);
             float sscale = 0.25f;
             if constexpr (H4) {      // q, k on two fp16 planes of 16 x value: a head's 16 channels are exactly one k-step (registers 0..7 | 8..15)
-                const X2 kx = x2_split(k * 16.0f);
+                const X2 kx = x2_split(k * op16);
                 sa = GATOR_MFMA_F16(kx.p[1][0], qx.p[0][0], sa);
                 sb = GATOR_MFMA_F16(kx.p[1][1], qx.p[0][1], sb);
                 sa = GATOR_MFMA_F16(kx.p[0][0], qx.p[1][0], sa);
@@ -787,8 +791,8 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
                 for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) { va.p[pl][ks] = lo ? vx.p[pl][ks] : z; vbx.p[pl][ks] = lo ? z : vx.p[pl][ks]; }
-                pa = x2_split_rows<LR>(sa * 64.0f);
-                pb = x2_split_rows<LR>(sb * 64.0f);
+                pa = x2_split_rows<LR>(sa * (4.0f * op16));          // x 64, or zero for a query lane that does not exist
+                pb = x2_split_rows<LR>(sb * (4.0f * op16));
                 O = x2_mma_step(va, pa, 0, O);
                 Ob = x2_mma_step(vbx, pb, 0, Ob);
             } else {
@@ -806,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             if constexpr (H4) {
                 O = x2_mma_step(va, pa, 1, O);
                 Ob = x2_mma_step(vbx, pb, 1, Ob);
-                x2_store(Bq + w * kTileX3, lane, x2_split((O + Ob) * (16.0f / 1024.0f)));      // AT[w]: O carries 16 x 64
+                x2_store(Bq + w * kTileX3, lane, x2_split((O + Ob) * (op16 * (1.0f / 1024.0f))));      // AT[w]: O carries 16 x 64
             } else {
 #pragma unroll
                 for (int r = 8; r < 16; ++r) {
