@@ -110,7 +110,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='samples per GPU per step (default 256, or the preset)')
     ap.add_argument('--joints', type=int, default=None)
     ap.add_argument('--impl', default=os.environ.get('GATOR_AMD_IMPL', 'fused'))
-    ap.add_argument('--precision', default=None, choices=['f32', 'bf16'], help='bf16: vertex regressor on bf16 MFMA (config 3)')
+    ap.add_argument('--precision', default=None, choices=['f32', 'bf16'],
+                    help='bf16 = gator_forward_bf16, the 16-bit operand mode of BASELINE config 3: MDR layers on one fp16 activation plane (dtype f16 in the line)')
     ap.add_argument('--mode', default=None, choices=['gather', 'eval'],
                     help='N>1: all-gather the vertices (config 4) or the all-reduce-only evaluation mode (config 5)')
     ap.add_argument('--subbatch-variant', action='store_true', help='also time the sub-batch-streams=2 mode (extra key)')
@@ -172,16 +173,22 @@ STAGE_PRODUCTS = {'mdr_layer0': [(_CA, 3), (48.7 - _CA, 4)],
                   # (QK^T + PV, 0.89 MFLOP) on two fp16 planes = 3 products, the hop aggregations (0.50) against exact 0/1 fp16 masks = 2,
                   # the MGCN adjacency product (0.89) on the fp32-input MFMA (= 16 in units of the 16-bit rate)
                   'gat': [(54.4, 4), (0.89, 3), (0.50, 2), (56.66 - 54.4 - 0.89 - 0.50, 16)]}
+# BASELINE config 3 (--precision bf16 = gator_forward_bf16, round 5): the MDR layers on ONE fp16 activation plane -- attention cores one
+# product, token-wise linears two (weights on two planes) -- encoder and vertex regressor as in the fp32 configuration
+STAGE_PRODUCTS_C3 = {'mdr_layer0': [(_CA, 1), (48.7 - _CA, 2)], 'mdr_layer': [(_SA + _CA, 1), (99.2 - _SA - _CA, 2)],
+                     'mdr_attn_head': [(_SA, 1), (51.4 - _SA, 2)], 'mdr_layers': [(3 * _SA + 3 * _CA, 1), (298.5 - 3 * _SA - 3 * _CA, 2)]}
 PEAK_X2_TFLOPS = round(PEAK_BF16_TFLOPS / 3, 1)
 
 
-def stage_pipe(stage, impl):
+def stage_pipe(stage, impl, precision='f32'):
     """-> (pipe name, peak TFLOP/s of fp32-equivalent work) for a profiled stage.  A stage that mixes split forms is priced
     against the time-weighted ceiling of the arithmetic it executes: total / sum(part_i / (2500 / products_i))."""
     sw = STAGE_X3_SWITCH.get(stage)
     mode = os.environ.get(sw, '2' if sw in ('GATOR_MDR_X3', 'GATOR_UPSAMPLE_X3') else '1') if sw else '0'
     if impl == 'fused' and sw is not None and mode != '0':
         parts = STAGE_PRODUCTS.get(stage) if mode == '2' else None
+        if precision == 'bf16' and mode == '2' and stage in STAGE_PRODUCTS_C3 and os.environ.get('GATOR_C3_MDR', '1') != '0':
+            parts = STAGE_PRODUCTS_C3[stage]
         if stage == 'gat':      # the four-product form is k_gat8's (GATOR_GAT8_H4, default on); k_gat / k_gat_tiled run six
             parts = STAGE_PRODUCTS['gat'] if (os.environ.get('GATOR_GAT8', '1') != '0' and os.environ.get('GATOR_GAT8_H4', '1') != '0') else None
         if parts:
@@ -338,7 +345,7 @@ def cpu_baseline(model, base, alpha, J):
             'per_batch': {str(k): round(v, 1) for k, v in per_b.items()}}
 
 
-def parity_check(model, base, alpha, J, x, verts, n=32):
+def parity_check(model, base, alpha, J, x, verts, n=32, bar_mm=1e-3):
     """The checker leg beside cpu_baseline (never timed, never the product path): the fp64 oracle on the first `n` samples of the
     batch that was timed, against the vertices the timed forward wrote for them."""
     import numpy as np
@@ -353,7 +360,7 @@ def parity_check(model, base, alpha, J, x, verts, n=32):
     err = np.abs(verts[:n].cpu().numpy().astype(np.float64) - ref.numpy()) * 1e3
     return {'max_err_mm': float('%.3e' % err.max()), 'rms_err_mm': float('%.3e' % np.sqrt((err ** 2).mean())), 'samples': int(n),
             'coordinates': int(err.size), 'against': 'fp64 oracle (torch-CPU restatement of the reference forward), first %d samples of the timed batch' % n,
-            'bar_mm': 1e-3}
+            'bar_mm': bar_mm}
 
 
 def main():
@@ -452,7 +459,7 @@ def main():
                 ach = mflop * 1e6 * B / avg_s / 1e12
                 rows, digest = pmc_digest(B)
                 traffic = pmc_traffic(rows, stage)
-                pipe, peak = stage_pipe(stage, a.impl)
+                pipe, peak = stage_pipe(stage, a.impl, a.precision)
                 designed = STAGE_BYTES.get(stage)
                 fwd_bytes = pmc_forward_bytes(rows)
                 row = pmc_row(rows, stage)
@@ -481,18 +488,22 @@ def main():
             roof = {'bound': 'mfma', 'kernel': 'whole forward', 'achieved': round(per_gpu_tf, 2), 'peak': PEAK_F32_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(per_gpu_tf / PEAK_F32_TFLOPS, 4), 'traffic': None}
         jset = {17: 'Human3.6M 17-joint', 19: 'COCO 19-joint'}.get(J, '%d-joint' % J)
-        prec = 'fp32' if a.precision == 'f32' else 'fp32 encoder/head + bf16-MFMA vertex regressor'
+        prec = 'fp32' if a.precision == 'f32' else '16-bit operand mode (MDR layers on one fp16 activation plane; encoder and vertex regressor on two)'
         tail = ''
         if world > 1:
             tail = (', RCCL all-gather of [%d,6890,3] vertices' % (B * world)) if a.mode == 'gather' else \
                 ', on-device joint regression + MPJPE/PA-MPJPE sums, RCCL all-reduce only'
         line = {'metric': 'meshes/sec (B=%d, J=%d) GATOR forward' % (B, J), 'value': round(value, 1), 'unit': 'meshes/sec',
                 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
-                'scaling': 'weak', 'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic',
+                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if a.precision == 'f32' else 'f16', 'data': 'synthetic',
                 # what `dtype` covers: fp32 in / out / accumulation; the products run on the 16-bit MFMA with split operands (weights exact on
                 # three planes; activations, attention operands and the vertex regressor's operands on two = rounded to 22 bits).  The
                 # build with no rounded operand is the `exact_split` entry of `variants`; parity of both: tests/test_gpu_x3.py.
-                'arithmetic': 'fp32 values, split-precision 16-bit MFMA products: weights exact (3 planes), activations / attention / vertex-regressor operands rounded to 22 bits (2 planes); measured error of this run: `parity`',
+                'arithmetic': ('fp32 values, split-precision 16-bit MFMA products: weights exact (3 planes), activations / attention / vertex-regressor operands rounded to 22 bits (2 planes); measured error of this run: `parity`'
+                               if a.precision == 'f32' else
+                               'gator_forward_bf16 (BASELINE config 3): fp32 in / out / accumulate / softmax / norms / GELU / residual stream; the three MDR layers and the head features take their '
+                               'activations, Q, K, V and probabilities as ONE fp16 plane (weights on two), the encoder and the vertex regressor keep two-plane operands (one plane there costs '
+                               'millimetres: profiles/r05_emulate_16bit.txt); measured error of this run: `parity` (bar: 1 mm max, 0.2 mm rms)'),
                 'config': {'workload': 'B=%d synthetic %s poses per GPU, GAT+MDR forward %s%s' % (B, jset, prec, tail),
                            'baseline_config': baseline_config_of(a, world),
                            'batch_per_gpu': B, 'global_batch': B * world, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world,
@@ -515,19 +526,27 @@ def main():
             # fp32-input MFMA, `k_gat` the previous one-sample-per-workgroup encoder, `four MDR launches` the per-stage form of the
             # MDR layers (bitwise the same results as the persistent launch).
             variants = {}
-            for vname, env in (('headline, re-measured with the variants\' protocol (5 blocks, later in the run: clocks drift)', {}),
+            vlist = (('headline, re-measured with the variants\' protocol (5 blocks, later in the run: clocks drift)', {}),
                                ('exact_split (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 GATOR_GAT_TILED_H4=0)',
                                 {'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1', 'GATOR_GAT8_H4': '0', 'GATOR_GAT_TILED_H4': '0'}),
                                ('six-product encoder (GATOR_GAT8_H4=0)', {'GATOR_GAT8_H4': '0'}),
                                ('three-plane vertex regressor (GATOR_UPSAMPLE_X3=1)', {'GATOR_UPSAMPLE_X3': '1'}),
                                ('fp32_mfma (GATOR_GAT_X3=0 GATOR_MDR_X3=0 GATOR_UPSAMPLE_X3=0)', {'GATOR_GAT_X3': '0', 'GATOR_MDR_X3': '0', 'GATOR_UPSAMPLE_X3': '0'}),
                                ('four MDR launches instead of the persistent one (GATOR_MDR_PERSIST=0)', {'GATOR_MDR_PERSIST': '0'}),
-                               ('k_gat encoder (GATOR_GAT8=0)', {'GATOR_GAT8': '0'})):
+                               ('k_gat encoder (GATOR_GAT8=0)', {'GATOR_GAT8': '0'}))
+            if a.precision != 'f32':      # config 3: what the 16-bit mode buys -- the fp32 build at the same shape, same box, same process
+                vlist = (vlist[0],
+                         ('fp32 build at this shape (gator_forward_f32)', {'_precision': 'f32'}),
+                         ('round 4 form of config 3: bf16 vertex regressor only (GATOR_C3_MDR=0 GATOR_C3_UPSAMPLE_BF16=1)', {'GATOR_C3_MDR': '0', 'GATOR_C3_UPSAMPLE_BF16': '1'}),
+                         ('four MDR launches instead of the persistent one (GATOR_MDR_PERSIST=0)', {'GATOR_MDR_PERSIST': '0'}))
+            for vname, env in vlist:
+                env = dict(env)
+                vprec = env.pop('_precision', a.precision)
                 old = {k: os.environ.get(k) for k in env}
                 os.environ.update(env)
                 try:
                     mv, _, _ = build_model(J, a.impl, dev)
-                    mv.precision = a.precision
+                    mv.precision = vprec
                     for _ in range(a.warmup):
                         mv(x)
                     dv = sorted(block(lambda: mv(x), a.steps)[0] for _ in range(5))[2]
@@ -573,6 +592,9 @@ def main():
             except Exception as e:
                 variants['headline with the library replaying the forward from a hipGraph (gator_set_graph_replay)'] = {'error': str(e)[:200]}
             line['variants'] = variants
+            f32v = variants.get('fp32 build at this shape (gator_forward_f32)')
+            if f32v and 'value' in f32v:      # config 3's own bar (round-4 review): >= 1.6 x the fp32 build on the same box
+                line['vs_fp32_build_same_box'] = round(value / f32v['value'], 3)
         if world == 1 and B >= 128 and a.subbatch_variant:
             # same workload with the library's sub-batch pipelining (two half-batches on two streams; bit-identical results).
             # Reported beside the headline, not as it: concurrent streams make per-kernel durations (and so `roofline`) ambiguous.
@@ -584,8 +606,8 @@ def main():
             d2 = sorted(block(lambda: m2(x), a.steps)[0] for _ in range(5))[2]
             line['subbatch_streams_2'] = {'value': round(B * a.steps / d2, 1), 'ms_per_step': round(d2 / a.steps * 1e3, 4)}
         if world == 1 and not a.no_cpu_baseline:
-            if a.mode == 'gather' and a.precision == 'f32':
-                line['parity'] = parity_check(model, base, alpha, J, x, out[0])
+            if a.mode == 'gather':
+                line['parity'] = parity_check(model, base, alpha, J, x, out[0], bar_mm=1e-3 if a.precision == 'f32' else 1.0)
             line['cpu_baseline'] = cpu_baseline(model, base, alpha, J)
         result = json.dumps(line)
     else:

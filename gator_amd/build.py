@@ -46,13 +46,20 @@ def build(force=False, verbose=True, diag=False):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.rsplit('.', 1)[0] + '.o')
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            is_hip = s.endswith('.hip')
-            extra = os.environ.get('GATOR_HIPCC_FLAGS_' + s.rsplit('.', 1)[0], '').split()      # A/B builds of one source (e.g. -fno-slp-vectorize)
+        is_hip = s.endswith('.hip')
+        extra = os.environ.get('GATOR_HIPCC_FLAGS_' + s.rsplit('.', 1)[0], '').split()      # A/B builds of one source (e.g. -fno-slp-vectorize)
+        # the per-source extra flags are part of an object's identity: a stamp beside it records them, and a change (set or unset)
+        # forces a rebuild -- an A/B object is never silently reused by a production build, nor the other way round
+        stamp = obj + '.flags'
+        want = ' '.join(extra + (NO_PK if s in NO_PK_SOURCES else []))
+        have = open(stamp).read() if os.path.exists(stamp) else ''
+        if force or want != have or _stale(obj, [src] + hdrs):
             cmd = [hipcc] + FLAGS + extra + (['-DGATOR_DIAG=1'] if diag else []) + (NO_PK if s in NO_PK_SOURCES else []) + \
                 (['-x', 'hip', '-Rpass-analysis=kernel-resource-usage'] if is_hip else []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
+            with open(stamp, 'w') as fh:
+                fh.write(want)
             procs.append((s, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
     from . import kernel_resources as kr
     remarks = {}

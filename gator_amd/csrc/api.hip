@@ -278,20 +278,24 @@ extern "C" int gator_create(const gator_tensor* tensors, int32_t n, const gator_
 }
 
 // What a kernel left in the ctx's sticky status word (an EARLIER call's failure: nothing here synchronises).  Reported once, then cleared.
-static int take_device_status(gator_ctx* c, const char* fn) {
-    const unsigned st = c->status_host ? __atomic_exchange_n(c->status_host, 0u, __ATOMIC_RELAXED) : 0u;
+// `executed`: the report rides on an entry point that has queued its own work normally (finish_fwd): the caller's buffers are being written.
+static int report_device_status(gator_ctx* c, unsigned st, const char* fn, bool executed) {
+    const char* tail = executed ? "  THIS call was queued normally; its outputs are valid unless the next call reports again." : "";
     if (st == DEV_PERSIST_INCOMPLETE) {
         fused_disable_persist(c);        // e.g. an XCD without workgroups (CU mask): its queue is never served.  The four-launch form has no such dependency.
         return fail(GATOR_EDEVICE, "%s: an earlier forward on this ctx did not complete its persistent MDR launch (a sample's stage tiles were never "
                                    "finished: an XCD without workgroups, or the hang guard); the vertices of that forward are NaN.  This ctx now uses the "
-                                   "four-launch form of the MDR stages (same results); GATOR_MDR_PERSIST=0 selects it from the start", fn);
+                                   "four-launch form of the MDR stages (same results); GATOR_MDR_PERSIST=0 selects it from the start.%s", fn, tail);
     }
     if (st == DEV_NONFINITE)
-        return fail(GATOR_EDEVICE, "%s: an earlier forward on this ctx produced non-finite or out-of-range coarse vertices (|vert431| must stay below 4094 m, "
-                                   "and every activation that feeds a token-wise linear below 4094: they travel as fp16 planes of 16 x value).  "
-                                   "GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 GATOR_GAT_TILED_H4=0 select the bf16 forms without that range limit", fn);
+        return fail(GATOR_EDEVICE, "%s: an earlier forward on this ctx produced non-finite or out-of-range coarse vertices.  Either its input poses "
+                                   "were not finite (the reference returns NaN for those too), or the weights drive an activation out of the default "
+                                   "arithmetic's range (|vert431| must stay below 4094 m, and every activation that feeds a token-wise linear below "
+                                   "4094: they travel as fp16 planes of 16 x value); GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 "
+                                   "GATOR_GAT_TILED_H4=0 select the bf16 forms without that range limit.%s", fn, tail);
     return GATOR_OK;
 }
+static unsigned take_status_word(gator_ctx* c) { return c->status_host ? __atomic_exchange_n(c->status_host, 0u, __ATOMIC_RELAXED) : 0u; }
 
 extern "C" int gator_device_status(gator_ctx* c, int32_t sync) {
     if (!c) return fail(GATOR_EINVAL, "gator_device_status: null ctx");
@@ -299,19 +303,34 @@ extern "C" int gator_device_status(gator_ctx* c, int32_t sync) {
         GATOR_HIP_CHECK(hipSetDevice(c->device));
         GATOR_HIP_CHECK(hipDeviceSynchronize());
     }
-    return take_device_status(c, "gator_device_status");
+    unsigned st = c->deferred_status ? c->deferred_status : take_status_word(c);
+    c->deferred_status = 0;
+    return report_device_status(c, st, "gator_device_status", false);
 }
 
+// Entry of every forward.  An earlier call's device status does NOT stop this one (round-4 advice: a NaN input pose, for which the
+// reference just returns NaN, must not make the next unrelated forward a no-op with stale output buffers, nor keep one rank of a
+// sharded run out of its collective): the word is taken here -- the persistent-launch failure already switches the ctx to four
+// launches for THIS call -- the call runs, and finish_fwd returns GATOR_EDEVICE once it is queued.
 static int check_fwd(gator_ctx* c, const void* a, const void* b, int B, const char* fn) {
     if (!c || !a || !b || B <= 0) return fail(GATOR_EINVAL, "%s: null pointer or batch <= 0", fn);
-    if (int st = take_device_status(c, fn)) return st;
+    if (const unsigned st = take_status_word(c)) {
+        c->deferred_status = st;
+        if (st == DEV_PERSIST_INCOMPLETE) fused_disable_persist(c);
+    }
     c->profiling = c->prof_stride > 0 && (c->prof_calls++ % c->prof_stride) == 0;
     GATOR_HIP_CHECK(hipSetDevice(c->device));
     c->clear_taps();        // a tap never outlives the forward that produced it (workspaces may be re-allocated below)
     return c->impl == GATOR_IMPL_BASIC ? ensure_workspace(c, B) : GATOR_OK;     // the fused entry points size their own workspace
 }
+static int finish_fwd(gator_ctx* c, int rc, const char* fn) {
+    if (rc != GATOR_OK || !c || !c->deferred_status) return rc;
+    const unsigned st = c->deferred_status;
+    c->deferred_status = 0;
+    return report_device_status(c, st, fn, true);
+}
 
-extern "C" int gator_gat_forward_f32(gator_ctx* c, const float* pose2d, int32_t B, float* x_out, float* feat, void* stream) {
+static int gat_forward_f32_impl(gator_ctx* c, const float* pose2d, int32_t B, float* x_out, float* feat, void* stream) {
     int rc = check_fwd(c, pose2d, x_out, B, "gator_gat_forward_f32");
     if (rc) return rc;
     if (!feat) return fail(GATOR_EINVAL, "gator_gat_forward_f32: feat is null");
@@ -322,23 +341,26 @@ extern "C" int gator_gat_forward_f32(gator_ctx* c, const float* pose2d, int32_t 
     if (rc == GATOR_OK) c->set_tap(TAP_FEAT, feat, (int64_t)B * c->J * kC);
     return rc;
 }
+extern "C" int gator_gat_forward_f32(gator_ctx* c, const float* pose2d, int32_t B, float* x_out, float* feat, void* stream) { return finish_fwd(c, gat_forward_f32_impl(c, pose2d, B, x_out, feat, stream), "gator_gat_forward_f32"); }
 
-extern "C" int gator_mdr_forward_f32(gator_ctx* c, const float* pc, int32_t B, float* verts, void* stream) {
+static int mdr_forward_f32_impl(gator_ctx* c, const float* pc, int32_t B, float* verts, void* stream) {
     int rc = check_fwd(c, pc, verts, B, "gator_mdr_forward_f32");
     if (rc) return rc;
     if (!(c->parts & GATOR_PART_MDR)) return fail(GATOR_EUNSUPPORTED, "gator_mdr_forward_f32: ctx was created without the MDR weights");
     c->last_batch = B;
     return c->impl == GATOR_IMPL_BASIC ? basic_mdr_forward(c, pc, B, verts, stream) : fused_mdr_forward(c, pc, B, verts, stream);
 }
+extern "C" int gator_mdr_forward_f32(gator_ctx* c, const float* pc, int32_t B, float* verts, void* stream) { return finish_fwd(c, mdr_forward_f32_impl(c, pc, B, verts, stream), "gator_mdr_forward_f32"); }
 
-extern "C" int gator_upsample_f32(gator_ctx* c, const float* vert431, int32_t B, float* verts, void* stream) {
+static int upsample_f32_impl(gator_ctx* c, const float* vert431, int32_t B, float* verts, void* stream) {
     int rc = check_fwd(c, vert431, verts, B, "gator_upsample_f32");
     if (rc) return rc;
     if (!(c->parts & GATOR_PART_MDR)) return fail(GATOR_EUNSUPPORTED, "gator_upsample_f32: ctx was created without the MDR weights");
     return c->impl == GATOR_IMPL_BASIC ? basic_upsample(c, vert431, B, verts, stream) : fused_upsample(c, vert431, B, verts, stream);
 }
+extern "C" int gator_upsample_f32(gator_ctx* c, const float* vert431, int32_t B, float* verts, void* stream) { return finish_fwd(c, upsample_f32_impl(c, vert431, B, verts, stream), "gator_upsample_f32"); }
 
-extern "C" int gator_forward_f32(gator_ctx* c, const float* pose2d, int32_t B, float* verts, float* pose3d, void* stream) {
+static int forward_f32_impl(gator_ctx* c, const float* pose2d, int32_t B, float* verts, float* pose3d, void* stream) {
     int rc = check_fwd(c, pose2d, verts, B, "gator_forward_f32");
     if (rc) return rc;
     if (!pose3d) return fail(GATOR_EINVAL, "gator_forward_f32: pose3d is null");
@@ -356,6 +378,7 @@ extern "C" int gator_forward_f32(gator_ctx* c, const float* pose2d, int32_t B, f
     StageTimer t(c, "mdr+upsample", stream);
     return basic_mdr_forward(c, pc, B, verts, stream);
 }
+extern "C" int gator_forward_f32(gator_ctx* c, const float* pose2d, int32_t B, float* verts, float* pose3d, void* stream) { return finish_fwd(c, forward_f32_impl(c, pose2d, B, verts, pose3d, stream), "gator_forward_f32"); }
 
 static void prof_clear(gator_ctx* c, bool destroy = false) {
     for (auto& r : c->prof) { c->ev_pool.push_back(r.start); c->ev_pool.push_back(r.stop); }
@@ -419,7 +442,7 @@ extern "C" int gator_set_joint_regressor(gator_ctx* c, const int32_t* coo_row, c
     return fused_set_joint_regressor(c, coo_row, coo_col, coo_val, nnz, n_joint);
 }
 
-extern "C" int gator_forward_joints_f32(gator_ctx* c, const float* pose2d, int32_t B, float* joints, float* pose3d, float* verts, void* stream) {
+static int forward_joints_f32_impl(gator_ctx* c, const float* pose2d, int32_t B, float* joints, float* pose3d, float* verts, void* stream) {
     int rc = check_fwd(c, pose2d, joints, B, "gator_forward_joints_f32");
     if (rc) return rc;
     if (!pose3d) return fail(GATOR_EINVAL, "gator_forward_joints_f32: pose3d is null");
@@ -428,8 +451,9 @@ extern "C" int gator_forward_joints_f32(gator_ctx* c, const float* pose2d, int32
     c->last_batch = B;
     return fused_forward_joints(c, pose2d, B, joints, pose3d, verts, stream);
 }
+extern "C" int gator_forward_joints_f32(gator_ctx* c, const float* pose2d, int32_t B, float* joints, float* pose3d, float* verts, void* stream) { return finish_fwd(c, forward_joints_f32_impl(c, pose2d, B, joints, pose3d, verts, stream), "gator_forward_joints_f32"); }
 
-extern "C" int gator_forward_bf16(gator_ctx* c, const float* pose2d, int32_t B, float* verts, float* pose3d, void* stream) {
+static int forward_bf16_impl(gator_ctx* c, const float* pose2d, int32_t B, float* verts, float* pose3d, void* stream) {
     int rc = check_fwd(c, pose2d, verts, B, "gator_forward_bf16");
     if (rc) return rc;
     if (!pose3d) return fail(GATOR_EINVAL, "gator_forward_bf16: pose3d is null");
@@ -439,14 +463,16 @@ extern "C" int gator_forward_bf16(gator_ctx* c, const float* pose2d, int32_t B, 
     c->clear_taps();
     return fused_forward(c, pose2d, B, verts, pose3d, stream, true);
 }
+extern "C" int gator_forward_bf16(gator_ctx* c, const float* pose2d, int32_t B, float* verts, float* pose3d, void* stream) { return finish_fwd(c, forward_bf16_impl(c, pose2d, B, verts, pose3d, stream), "gator_forward_bf16"); }
 
-extern "C" int gator_upsample_bf16(gator_ctx* c, const float* vert431, int32_t B, float* verts, void* stream) {
+static int upsample_bf16_impl(gator_ctx* c, const float* vert431, int32_t B, float* verts, void* stream) {
     int rc = check_fwd(c, vert431, verts, B, "gator_upsample_bf16");
     if (rc) return rc;
     if (!(c->parts & GATOR_PART_MDR) || c->impl != GATOR_IMPL_FUSED)
         return fail(GATOR_EUNSUPPORTED, "gator_upsample_bf16: needs a fused ctx with the MDR weights");
     return fused_upsample_bf16(c, vert431, B, verts, stream);
 }
+extern "C" int gator_upsample_bf16(gator_ctx* c, const float* vert431, int32_t B, float* verts, void* stream) { return finish_fwd(c, upsample_bf16_impl(c, vert431, B, verts, stream), "gator_upsample_bf16"); }
 
 extern "C" int gator_enable_block_taps(gator_ctx* c, int32_t on) {
     if (!c) return fail(GATOR_EINVAL, "gator_enable_block_taps: null ctx");

@@ -323,6 +323,18 @@ extern "C" int gator_preprocess_pose2d_f32(const float* joints, int32_t batch, i
     return GATOR_OK;
 }
 
+// 96 KB of dynamic LDS > the 64 KB default: raised once PER DEVICE (the attribute belongs to the device's copy of the function; a
+// process that evaluates on a second GPU, or whose first call failed transiently, must not inherit a cached answer)
+static int raise_pts_lds(const void* fn, bool (&done)[64]) {
+    int dev = 0;
+    GATOR_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        GATOR_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gator::kPtsLds));
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+    return GATOR_OK;
+}
+
 extern "C" int gator_joint_errors_f32(const float* pred_joints, const float* target_joints, int32_t batch, int32_t n_joint,
                                       const int32_t* eval_joints, int32_t n_eval, int32_t root, float pred_scale, float* errors, void* stream) {
     using namespace gator;
@@ -330,8 +342,8 @@ extern "C" int gator_joint_errors_f32(const float* pred_joints, const float* tar
         return fail(GATOR_EINVAL, "gator_joint_errors_f32: bad arguments");
     const int ne = eval_joints ? n_eval : n_joint;
     if (ne < 3 || ne > 32) return fail(GATOR_EINVAL, "gator_joint_errors_f32: 3..32 evaluation joints");
-    static const hipError_t lds_ok_ = hipFuncSetAttribute((const void*)k_joint_errors, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPtsLds);      // 96 KB > the 64 KB default
-    GATOR_HIP_CHECK(lds_ok_);
+    static bool lds_raised_[64] = {};
+    if (int rc = raise_pts_lds((const void*)k_joint_errors, lds_raised_)) return rc;
     k_joint_errors<<<(batch + 63) / 64, 64, kPtsLds, (hipStream_t)stream>>>(pred_joints, target_joints, batch, n_joint, eval_joints, ne, root, pred_scale, errors);
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;
@@ -339,8 +351,8 @@ extern "C" int gator_joint_errors_f32(const float* pred_joints, const float* tar
 
 extern "C" int gator_rigid_align_f32(const float* a, const float* b, int32_t batch, int32_t n_points, float* aligned, void* stream) {
     if (!a || !b || !aligned || batch <= 0 || n_points < 3 || n_points > 32) return fail(GATOR_EINVAL, "gator_rigid_align_f32: bad arguments (3..32 points)");
-    static const hipError_t lds_ok_ = hipFuncSetAttribute((const void*)k_rigid_align, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPtsLds);      // 96 KB > the 64 KB default
-    GATOR_HIP_CHECK(lds_ok_);
+    static bool lds_raised_[64] = {};
+    if (int rc = raise_pts_lds((const void*)gator::k_rigid_align, lds_raised_)) return rc;
     k_rigid_align<<<(batch + 63) / 64, 64, kPtsLds, (hipStream_t)stream>>>(a, b, batch, n_points, aligned);
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;

@@ -234,6 +234,13 @@ int fused_create(gator_ctx* c, void* stream) {
     const char* mx3 = getenv("GATOR_MDR_X3");
     f->mdr_x3 = mx3 ? atoi(mx3) : 2;
     if (f->mdr_x3 < 0 || f->mdr_x3 > 2) return fail(GATOR_EINVAL, "GATOR_MDR_X3 must be 0, 1 or 2");
+    // BASELINE config 3 (gator_forward_bf16): which stages run on ONE 16-bit operand plane.  Default: the MDR layers (one fp16 activation
+    // plane, mdr_fused.hip XA = 3), the vertex regressor stays on its two fp16 planes (a single bf16 / fp16 plane there costs 4 / 0.5 mm:
+    // profiles/r05_emulate_16bit.txt).  GATOR_C3_MDR=0 / GATOR_C3_UPSAMPLE_BF16=1 restore round 4's form (bf16 regressor only).
+    if (const char* e = getenv("GATOR_C3_MDR")) f->c3_mdr = atoi(e) != 0;
+    if (const char* e = getenv("GATOR_C3_UPSAMPLE_BF16")) f->c3_up_bf16 = atoi(e) != 0;
+    if (f->mdr_x3 != 2) f->c3_mdr = false;
+    if (!(f->x3 && f->up_x2)) f->c3_up_bf16 = true;
     if (const char* e = getenv("GATOR_GRAPH")) f->graph_replay = atoi(e) != 0;      // hipGraph replay of repeated forwards (gator_set_graph_replay)
     const char* mper = getenv("GATOR_MDR_PERSIST");
     f->mdr_persist = mper ? (atoi(mper) != 0 ? 1 : 0) : -1;
@@ -458,9 +465,9 @@ static int fused_mdr_forward_impl(gator_ctx* c, const float* pc, int B, float* v
     int rc = fused_ensure_ws(c, B);
     if (rc) return rc;
     FusedState* f = c->fused;
-    rc = launch_mdr(c, f, pc, B, stream);        // also writes the packed vertex-GEMM operand f->vcp / f->vcp3
+    rc = launch_mdr(c, f, pc, B, stream, nullptr, nullptr, bf16 && f->c3_mdr);        // also writes the packed vertex-GEMM operand f->vcp / f->vcp3
     if (rc) return rc;
-    if (bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);
+    if (bf16 && f->c3_up_bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);
     StageTimer tm(c, "upsample", stream);
     return launch_upsample_any(f, c, B, verts, stream);
 }
@@ -492,7 +499,9 @@ static int fused_forward_graph(gator_ctx* c, const float* pose2d, int B, float* 
         if (g.B == B && g.in == pose2d && g.verts == verts && g.pose3d == pose3d && g.bf16 == bf16 && g.tiled == f->gat_tiled && g.persist == f->mdr_persist && g.ws == f->ws) { slot = &g; break; }
     if (!slot) {                                         // first sight: remember the key, run directly
         if ((int)f->graphs.size() >= FusedState::kGraphSlots) {
-            auto lru = std::min_element(f->graphs.begin(), f->graphs.end(), [](const FusedState::GraphSlot& a, const FusedState::GraphSlot& b) { return a.used < b.used; });
+            // evict a key that was never captured if there is one (no replay can be in flight: no device-wide wait), else the least recently used
+            auto lru = std::min_element(f->graphs.begin(), f->graphs.end(), [](const FusedState::GraphSlot& a, const FusedState::GraphSlot& b) {
+                return (a.exec != nullptr) != (b.exec != nullptr) ? a.exec == nullptr : a.used < b.used; });
             if (lru->exec) GATOR_HIP_CHECK(hipDeviceSynchronize());      // a replay of it may still be running
             graph_slot_free(*lru);
             f->graphs.erase(lru);
@@ -531,7 +540,8 @@ static int fused_forward_graph(gator_ctx* c, const float* pose2d, int B, float* 
     }
     GATOR_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)slot->exec, (hipStream_t)stream));
     ++f->graph_launches;
-    c->set_tap(TAP_FEAT, f->feat, (int64_t)B * c->J * kC);
+    c->set_tap(TAP_FEAT, f->feat, (int64_t)B * c->J * kC);      // the same taps a direct forward leaves (launch_mdr sets vert431 only while it runs)
+    c->set_tap(TAP_VERT431, f->vc, (int64_t)B * kV * 3);
     return GATOR_OK;
 }
 
@@ -623,7 +633,7 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
         if (rc) return rc;
     }
     c->set_tap(TAP_FEAT, f->feat, (int64_t)B * c->J * kC);
-    rc = launch_mdr(c, f, nullptr, B, stream, pose3d, pose2d);      // pose_combine is never materialised on this path
+    rc = launch_mdr(c, f, nullptr, B, stream, pose3d, pose2d, bf16 && f->c3_mdr);      // pose_combine is never materialised on this path
     if (rc) return rc;
     if (joints) {      // vertex GEMM with the joint-regression epilogue (verts may be null: nothing of 82 kB/mesh is stored)
         if (!f->x3 || bf16) return fail(GATOR_EUNSUPPORTED, "gator_forward_joints_f32 needs the split-precision vertex regressor");
@@ -637,7 +647,7 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
         StageTimer tm(c, "jreg_reduce", stream);
         return launch_jreg_reduce(f, B, joints, stream);
     }
-    if (bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);
+    if (bf16 && f->c3_up_bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);
     StageTimer tm(c, "upsample", stream);
     return launch_upsample_any(f, c, B, verts, stream);
 }

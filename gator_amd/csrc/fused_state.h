@@ -74,6 +74,8 @@ struct FusedState : FusedWs {
     int mdr_persist_grid = 0;           // GATOR_MDR_PERSIST_GRID: workgroups of the persistent launch (0: two per CU)
     int mdr_wshift = 0;                 // GATOR_MDR_X3=2: wxbuf holds three fp16 planes of 2^mdr_wshift * w
     int mdr_x3 = 2;                     // GATOR_MDR_X3: 0 fp32-input MFMA; 1 exact bf16 x 3 split everywhere; 2 (default) that + the 431x431 attention on two fp16 planes
+    bool c3_mdr = true;                 // gator_forward_bf16 (BASELINE config 3): the MDR layers on one fp16 activation plane (GATOR_C3_MDR=0: fp32 form)
+    bool c3_up_bf16 = false;            // ... and the vertex regressor on one bf16 plane (GATOR_C3_UPSAMPLE_BF16=1; default: its two fp16 planes)
     bool x3 = true;                     // split-precision vertex regressor (GATOR_UPSAMPLE_X3=0: fp32-input MFMA kernel)
     bool up_x2 = true;                  // ... on two fp16 planes (default; GATOR_UPSAMPLE_X3=1: the exact three bf16 planes)
     void* up_w2 = nullptr;              // fp16 [ob/2][28][2][tap 3][plane 2][64][8]  scaled hi/lo split of upsample_conv.weight
@@ -162,6 +164,6 @@ int launch_upsample_x2(const FusedState* f, const gator_ctx* c, int B, float* ve
 // the vertex regressor the ctx was created with (fp32-input MFMA | bf16 x 3 | fp16 x 2)
 int launch_upsample_any(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints = false);
 // mdr_fused.hip
-int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream, const float* x_out = nullptr, const float* pose2d = nullptr);
+int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream, const float* x_out = nullptr, const float* pose2d = nullptr, bool half16 = false);
 
 }  // namespace gator

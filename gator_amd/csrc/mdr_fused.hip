@@ -30,6 +30,17 @@ namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
 
+// Diagnostic library only (GATOR_MDR_CUT, time-only experiments: results are meaningless): bit 0 = every weight load of a matrix reads its
+// tile 0, bit 1 = every K / V load of the 431-key attention reads key tile 0 -- the loads stay, their L2 -> L1 traffic goes (L1 hits).
+#ifdef GATOR_DIAG
+__device__ int g_mdr_wmask = -1, g_mdr_kvmask = -1;
+#define MDR_WIDX(i) ((i) & g_mdr_wmask)
+#define MDR_KVIDX(i) ((i) & g_mdr_kvmask)
+#else
+#define MDR_WIDX(i) (i)
+#define MDR_KVIDX(i) (i)
+#endif
+
 struct LayerW {   // packed tiles (MdrLayerP) + reference-layout vectors of one LBF layer
     const float *wq, *proj, *fc1, *fc2, *sa0, *sa1, *sa2, *sa3;
     const float *n1w, *n1b, *proj_b, *n2w, *n2b, *fc1_b, *fc2_b, *a2, *b2, *sa0_b, *sa1_b, *sa2_b, *sa3_b;
@@ -326,19 +337,104 @@ __device__ __forceinline__ f32x16 self_attention_head_x2(const float* __restrict
     // large-logit test green -- and the launch 12 us SLOWER.)
 #pragma unroll 1
     for (int kt = 0; kt < kVT - 2; kt += 2) {
-        X2 kn = x2_load(kbase + (size_t)(kt + 1) * 2 * kTile, lane), vn = x2_load(vbase + (size_t)(kt + 1) * 2 * kTile, lane);
+        X2 kn = x2_load(kbase + (size_t)MDR_KVIDX(kt + 1) * 2 * kTile, lane), vn = x2_load(vbase + (size_t)MDR_KVIDX(kt + 1) * 2 * kTile, lane);
         ATTN_TILE_X2(0, kb, vb)
-        kb = x2_load(kbase + (size_t)(kt + 2) * 2 * kTile, lane);
-        vb = x2_load(vbase + (size_t)(kt + 2) * 2 * kTile, lane);
+        kb = x2_load(kbase + (size_t)MDR_KVIDX(kt + 2) * 2 * kTile, lane);
+        vb = x2_load(vbase + (size_t)MDR_KVIDX(kt + 2) * 2 * kTile, lane);
         ATTN_TILE_X2(0, kn, vn)
     }
     {
-        X2 kn = x2_load(kbase + (size_t)(kVT - 1) * 2 * kTile, lane), vn = x2_load(vbase + (size_t)(kVT - 1) * 2 * kTile, lane);
+        X2 kn = x2_load(kbase + (size_t)MDR_KVIDX(kVT - 1) * 2 * kTile, lane), vn = x2_load(vbase + (size_t)MDR_KVIDX(kVT - 1) * 2 * kTile, lane);
         ATTN_TILE_X2(kVT - 2, kb, vb)
         ATTN_TILE_X2(kVT - 1, kn, vn)
     }
     l += xhalf(l);
     return (O + O2) * (((kActScale16 ? 16.0f : 1.0f) / kX2V) / l);      // kActScale16: 16 x the head's output, the operand scale of the out-projection
+}
+
+
+// ---- ONE fp16 plane ("X1", BASELINE config 3: the MDR layers in 16-bit operand mode, XA == 3) --------------------------------------------
+// Activations, Q, K, V and the probabilities are ONE fp16 plane of 16 x value (64 x for P): no split, 2 KiB tiles, 2 MFMAs per 32-deep
+// product in the attention cores (against 6) and 4 per token-wise product (weights on their two leading fp16 planes, 22 bits: against
+// 8); accumulation, softmax, norms, GELU and the residual stream stay fp32.  What that costs in accuracy is the activation rounding
+// (2^-12 relative per operand element): tools/emulate_16bit.py, profiles/r05_emulate_16bit.txt (sub-millimetre vertices).
+struct X1 { f16x8 p[2]; };          // [k-step]: 8 VGPRs
+__device__ __forceinline__ X1 x1_cvt(const f32x16& v) {
+    X1 o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.p[s][j] = (_Float16)v[8 * s + j];
+    return o;
+}
+__device__ __forceinline__ X1 x1_load(const float* __restrict__ tile, int lane) {      // also: the hi plane of an X2 tile
+    const f16x8* q = reinterpret_cast<const f16x8*>(tile) + lane;
+    X1 o;
+    o.p[0] = q[0];
+    o.p[1] = q[64];
+    return o;
+}
+__device__ __forceinline__ void x1_store(float* __restrict__ tile, int lane, const X1& v) {
+    f16x8* q = reinterpret_cast<f16x8*>(tile) + lane;
+    q[0] = v.p[0];
+    q[64] = v.p[1];
+}
+__device__ __forceinline__ f32x16 x1_mma(const X1& A, const X1& B, f32x16 acc) {
+    acc = GATOR_MFMA_F16(A.p[0], B.p[0], acc);
+    return GATOR_MFMA_F16(A.p[1], B.p[1], acc);
+}
+constexpr int kTileX1 = kTile / 2;
+#define ATTN_TILE_X1(KT, KB, VB)                                                                            \
+    {                                                                                                       \
+        f32x16 S = x1_mma(KB, qx, zero16());  /* 256 x S^T[key][query] */                                   \
+        float bm = -1e30f;                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+            float sc = S[r];                                                                                \
+            if ((KT) == kVT - 1 && kap(r) + 4 * h >= kV - 32 * (kVT - 1)) sc = -1e30f;                      \
+            S[r] = sc;                                                                                      \
+            bm = fmaxf(bm, sc);                                                                             \
+        }                                                                                                   \
+        bm = fmaxf(bm, xhalf(bm));                                                                          \
+        if (!__all(bm <= m + 2048.0f)) {      /* lazy rescale: P stays <= 2^8 (x 2^6 below) */               \
+            const float mn = fmaxf(m, bm);                                                                  \
+            const float al = __builtin_amdgcn_exp2f((m - mn) * 0.00390625f);                                \
+            O = O * al;                                                                                     \
+            l *= al;                                                                                        \
+            m = mn;                                                                                         \
+        }                                                                                                   \
+        const float off = 6.0f - m * 0.00390625f;                                                           \
+        float ps = 0.f;                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+            const float pe = __builtin_amdgcn_exp2f(fmaf(S[r], 0.00390625f, off));                          \
+            S[r] = pe;                                                                                      \
+            ps += pe;                                                                                       \
+        }                                                                                                   \
+        l += ps;                                                                                            \
+        O = x1_mma(VB, x1_cvt(S), O);                                                                       \
+    }
+template <bool kActScale16>
+__device__ __forceinline__ f32x16 self_attention_head_x1(const float* __restrict__ qt, const float* __restrict__ kbase,
+                                                         const float* __restrict__ vbase, int lane) {
+    const int h = lane >> 5;
+    const X1 qx = x1_load(qt, lane);
+    f32x16 O = zero16();
+    float m = -1e30f, l = 0.f;
+    X1 kb = x1_load(kbase, lane), vb = x1_load(vbase, lane);
+#pragma unroll 1
+    for (int kt = 0; kt < kVT - 2; kt += 2) {
+        X1 kn = x1_load(kbase + (size_t)MDR_KVIDX(kt + 1) * 2 * kTileX1, lane), vn = x1_load(vbase + (size_t)MDR_KVIDX(kt + 1) * 2 * kTileX1, lane);
+        ATTN_TILE_X1(0, kb, vb)
+        kb = x1_load(kbase + (size_t)MDR_KVIDX(kt + 2) * 2 * kTileX1, lane);
+        vb = x1_load(vbase + (size_t)MDR_KVIDX(kt + 2) * 2 * kTileX1, lane);
+        ATTN_TILE_X1(0, kn, vn)
+    }
+    {
+        X1 kn = x1_load(kbase + (size_t)MDR_KVIDX(kVT - 1) * 2 * kTileX1, lane), vn = x1_load(vbase + (size_t)MDR_KVIDX(kVT - 1) * 2 * kTileX1, lane);
+        ATTN_TILE_X1(kVT - 2, kb, vb)
+        ATTN_TILE_X1(kVT - 1, kn, vn)
+    }
+    l += xhalf(l);
+    return O * (((kActScale16 ? 16.0f : 1.0f) / kX2V) / l);
 }
 
 // ---- cross-attention over the J joint tokens (keys/values precomputed per sample by k_mdr_joint) -------------------------
@@ -399,6 +495,35 @@ __device__ __forceinline__ f32x16 cross_attention_head_x2(const float* __restric
     return x2_mma(vx, x2_split(S * inv), zero16()) * (1.0f / 64.0f);      // 16 x the head's output: the operand scale of the projection that follows
 }
 
+
+// The same on one fp16 plane (XA == 3): the hi planes of the joint K / V tiles, q and the probabilities rounded once
+__device__ __forceinline__ f32x16 cross_attention_head_x1(const float* __restrict__ kj, const float* __restrict__ vjp,
+                                                          const f32x16& qh, float qscale, int J, int lane) {
+    const int h = lane >> 5;
+    const X1 kx = x1_load(kj, lane);
+    f32x16 S = x1_mma(kx, x1_cvt(qh * qscale), zero16());                  // 256 x S^T[joint][token]
+    const X1 vx = x1_load(vjp, lane);
+    const float c = kLog2e * 0.17677669529663688110f * (1.0f / 256.0f);
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float s = (kap(r) + 4 * h < J) ? S[r] * c : -1e30f;
+        S[r] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = fmaxf(mx, xhalf(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(S[r] - mx);
+        S[r] = p;
+        sum += p;
+    }
+    sum += xhalf(sum);
+    const float inv = 64.0f / sum;
+    return x1_mma(vx, x1_cvt(S * inv), zero16()) * (1.0f / 64.0f);        // 16 x the head's output
+}
+
 // ---- weight stream of the tokenwise part: two buffers of one tile pair each (2 x 32 VGPRs).  The pair for the NEXT
 // product is requested right after the current product's MFMAs are queued, so its L2 latency hides behind them and
 // behind the co-resident wave.  MDR_PIN keeps the order (memory ops and scheduler).
@@ -406,6 +531,7 @@ __device__ __forceinline__ f32x16 cross_attention_head_x2(const float* __restric
 template <int X> __device__ __forceinline__ void st_op(float* p, int lane, const f32x16& v) {
     if constexpr (X == 1) x3_store(p, lane, x3_split(v));
     else if constexpr (X == 2) x2_store(p, lane, x2_split(v));
+    else if constexpr (X == 3) x1_store(p, lane, x1_cvt(v));
     else store_block(p, lane, v);
 }
 struct W2 { WTile t[2]; };
@@ -455,16 +581,64 @@ __device__ __forceinline__ f32x16 lin2_C(const W2H& w, const X2 (&x)[2]) {
     return h3_mma_aw_main(x[1], w.t[1], h3_mma_aw_main(x[0], w.t[0], h3_mma_aw_small(x[1], w.t[1], h3_mma_aw_small(x[0], w.t[0], zero16()))));
 }
 
+// XA == 3: weights as the two leading fp16 planes (hi, mid: 22 bits) of two H3 tiles (32 VGPRs), activations as X1
+struct G2 { f16x8 hi[2], mid[2]; };      // [k-step]
+struct W2G { G2 t[2]; };
+__device__ __forceinline__ G2 g2_load(const float* __restrict__ tile, int lane) {
+    const f16x8* q = reinterpret_cast<const f16x8*>(tile) + lane;
+    G2 o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { o.hi[s] = q[s * 64]; o.mid[s] = q[(2 + s) * 64]; }
+    return o;
+}
+__device__ __forceinline__ W2G ldw2g(const float* __restrict__ Wx, int i0, int i1, int lane) {
+    W2G w;
+    w.t[0] = g2_load(Wx + (size_t)i0 * kTileX3, lane);
+    w.t[1] = g2_load(Wx + (size_t)i1 * kTileX3, lane);
+    return w;
+}
+__device__ __forceinline__ f32x16 g2_mma_wa(const G2& W, const X1& a, f32x16 acc) {      // acc += W . a, the small plane first
+    acc = GATOR_MFMA_F16(W.mid[0], a.p[0], acc);
+    acc = GATOR_MFMA_F16(W.mid[1], a.p[1], acc);
+    acc = GATOR_MFMA_F16(W.hi[0], a.p[0], acc);
+    return GATOR_MFMA_F16(W.hi[1], a.p[1], acc);
+}
+__device__ __forceinline__ f32x16 lin2_T(const W2G& w, const X1 (&x)[2], f32x16 init) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) init = GATOR_MFMA_F16(w.t[t].mid[s], x[t].p[s], init);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) init = GATOR_MFMA_F16(w.t[t].hi[s], x[t].p[s], init);
+    return init;
+}
+__device__ __forceinline__ f32x16 lin2_C(const W2G& w, const X1 (&x)[2]) {
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc = GATOR_MFMA_F16(x[t].p[s], w.t[t].mid[s], acc);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc = GATOR_MFMA_F16(x[t].p[s], w.t[t].hi[s], acc);
+    return acc;
+}
+
 template <int XA> struct TokOp;
 template <> struct TokOp<0> { typedef W2 W; typedef f32x16 A; };
 template <> struct TokOp<1> { typedef W2X W; typedef X3 A; };
 template <> struct TokOp<2> { typedef W2H W; typedef X2 A; };
+template <> struct TokOp<3> { typedef W2G W; typedef X1 A; };
 template <int XA> __device__ __forceinline__ typename TokOp<XA>::W ldw(const float* __restrict__ Wp, int i0, int i1, int lane) {
-    if constexpr (XA == 2) return ldw2h(Wp, i0, i1, lane); else if constexpr (XA == 1) return ldw2x(Wp, i0, i1, lane); else return ldw2(Wp, i0, i1, lane);
+    i0 = MDR_WIDX(i0); i1 = MDR_WIDX(i1);
+    if constexpr (XA == 3) return ldw2g(Wp, i0, i1, lane); else if constexpr (XA == 2) return ldw2h(Wp, i0, i1, lane); else if constexpr (XA == 1) return ldw2x(Wp, i0, i1, lane); else return ldw2(Wp, i0, i1, lane);
 }
 // operand form of an accumulator tile holding `pre` x its value (pre = 1, or 1 / lin_s when it is a 4-product linear's raw output)
 template <int XA> __device__ __forceinline__ typename TokOp<XA>::A mk(const f32x16& v, float pre = 1.0f) {
-    if constexpr (XA == 2) return x2_split(v * (kActScale * pre)); else if constexpr (XA == 1) return x3_split(v); else return v;
+    if constexpr (XA == 3) return x1_cvt(v * (kActScale * pre)); else if constexpr (XA == 2) return x2_split(v * (kActScale * pre)); else if constexpr (XA == 1) return x3_split(v); else return v;
 }
 
 // MODE 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
@@ -492,10 +666,10 @@ __device__ __forceinline__ void mdr_stage_vectors(const MdrArgs& a, float* VT) {
         if (src) {
             f32x4 v = *reinterpret_cast<const f32x4*>(src);
             // 4-product linears return lin_s x their value: the biases that start or join their accumulators carry the factor too
-            if (XA == 2 && (off < VO_N1W || (off >= VO_PROJB && off < VO_N2W) || (off >= VO_FC2B && off < VO_A2) || (off >= VO_SA0B && off < VO_TOKW3)))
+            if (XA >= 2 && (off < VO_N1W || (off >= VO_PROJB && off < VO_N2W) || (off >= VO_FC2B && off < VO_A2) || (off >= VO_SA0B && off < VO_TOKW3)))
                 v = v * a.lin_s;
             // norm1 / norm2 only feed 4-product linears: their affine part carries the operand scale, so LayerNorm's FMA delivers 16 x value
-            if (XA == 2 && ((off >= VO_N1W && off < VO_PROJB) || (off >= VO_N2W && off < VO_FC2B))) v = v * kActScale;
+            if (XA >= 2 && ((off >= VO_N1W && off < VO_PROJB) || (off >= VO_N2W && off < VO_FC2B))) v = v * kActScale;
             reinterpret_cast<f32x4*>(VT)[e] = v;
         }
     }
@@ -505,7 +679,7 @@ __device__ __forceinline__ void mdr_stage_vectors(const MdrArgs& a, float* VT) {
 template <int MODE, int XA>
 __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const float* VT, f32x4* park) {
     constexpr bool X = XA != 0;
-    constexpr int TQ = XA == 1 ? kTileX3 : kTile;
+    constexpr int TQ = XA == 1 ? kTileX3 : (XA == 3 ? kTileX1 : kTile);
     auto park_vf = [&](const f32x16 (&v)[2]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -542,7 +716,7 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
 #else
 #define MDR_STAMP(i)
 #endif
-    constexpr bool H = XA == 2;                 // 4-product linears: their raw outputs carry the factor a.lin_s
+    constexpr bool H = XA >= 2;                 // 4-product (XA 2) / 2-product (XA 3) linears: their raw outputs carry the factor a.lin_s
     const float inv = H ? a.lin_inv : 1.0f;
     const int b = id / kVT, t = id % kVT;
     const size_t tile = ((size_t)b * kVT + t) * 2;          // index of this wave's first block in vf/q/k/v
@@ -574,7 +748,12 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         }
     } else {
         f32x16 att[2];
-        if constexpr (XA == 2) {
+        if constexpr (XA == 3) {
+            att[0] = self_attention_head_x1<true>(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
+                                    a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
+            att[1] = self_attention_head_x1<true>(a.q_in + (tile + 1) * TQ, a.k_in + ((size_t)b * kVT * 2 + 1) * TQ,
+                                    a.v_in + ((size_t)b * kVT * 2 + 1) * TQ, lane);
+        } else if constexpr (XA == 2) {
             att[0] = self_attention_head_x2<true>(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
                                     a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
             att[1] = self_attention_head_x2<true>(a.q_in + (tile + 1) * TQ, a.k_in + ((size_t)b * kVT * 2 + 1) * TQ,
@@ -598,7 +777,8 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         MDR_STAMP(0)
         // linears[-1] + residual (vanilla_transformer_encoder.py:94, MDR.py:143)
         Act attx[2];
-        if constexpr (XA == 2) { attx[0] = x2_split(att[0]); attx[1] = x2_split(att[1]); }      // the heads come out at 16 x value already
+        if constexpr (XA == 3) { attx[0] = x1_cvt(att[0]); attx[1] = x1_cvt(att[1]); }
+        else if constexpr (XA == 2) { attx[0] = x2_split(att[0]); attx[1] = x2_split(att[1]); }      // the heads come out at 16 x value already
         else { attx[0] = mk<XA>(att[0]); attx[1] = mk<XA>(att[1]); }
         const f32x16 y0 = lin2_T(A, attx, chanvec_lds(VT, VO_SA3B, h));
         if (MODE == 1) A = ldw<XA>(w.wq, 0, 1, lane); else A = ldw<XA>(a.head_w, 0, 1, lane);
@@ -643,7 +823,8 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         {
             f32x16 fzf[2];
             layernorm64_L(vf, VT + VO_N1W, VT + VO_N1B, h, fzf);
-            if constexpr (XA == 2) { fz[0] = x2_split(fzf[0]); fz[1] = x2_split(fzf[1]); }      // already 16 x value (staged 16 w, 16 b)
+            if constexpr (XA == 3) { fz[0] = x1_cvt(fzf[0]); fz[1] = x1_cvt(fzf[1]); }
+            else if constexpr (XA == 2) { fz[0] = x2_split(fzf[0]); fz[1] = x2_split(fzf[1]); }      // already 16 x value (staged 16 w, 16 b)
             else { fz[0] = mk<XA>(fzf[0]); fz[1] = mk<XA>(fzf[1]); }
         }
         const float* jb = a.jkv + (((size_t)b * 3 + a.layer) * 4) * kTile;       // [k/v][head] tiles
@@ -655,11 +836,13 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         MDR_PIN();
 #pragma unroll
         for (int hd = 0; hd < 2; ++hd) {
-            if constexpr (XA == 2) o[hd] = cross_attention_head_x2(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], 16.0f * inv, a.J, lane);
+            if constexpr (XA == 3) o[hd] = cross_attention_head_x1(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], 16.0f * inv, a.J, lane);
+            else if constexpr (XA == 2) o[hd] = cross_attention_head_x2(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], 16.0f * inv, a.J, lane);
             else o[hd] = cross_attention_head(jb + hd * kTile, jb + (2 + hd) * kTile, q[hd], a.J, lane);
         }
         Act ox[2];
-        if constexpr (XA == 2) { ox[0] = x2_split(o[0]); ox[1] = x2_split(o[1]); }      // cross_attention_head_x2 returns 16 x value
+        if constexpr (XA == 3) { ox[0] = x1_cvt(o[0]); ox[1] = x1_cvt(o[1]); }
+        else if constexpr (XA == 2) { ox[0] = x2_split(o[0]); ox[1] = x2_split(o[1]); }      // cross_attention_head_x2 returns 16 x value
         else { ox[0] = mk<XA>(o[0]); ox[1] = mk<XA>(o[1]); }
         const f32x16 y0 = lin2_T(A, ox, chanvec_lds(VT, VO_PROJB, h));
         A = ldw<XA>(w.fc1, 0, 1, lane);                                            // MLP chunk 0: fc1 rows 0..31
@@ -677,7 +860,8 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         {
             f32x16 y2f[2];
             layernorm64_L(vf, VT + VO_N2W, VT + VO_N2B, h, y2f);
-            if constexpr (XA == 2) { y2[0] = x2_split(y2f[0]); y2[1] = x2_split(y2f[1]); }
+            if constexpr (XA == 3) { y2[0] = x1_cvt(y2f[0]); y2[1] = x1_cvt(y2f[1]); }
+            else if constexpr (XA == 2) { y2[0] = x2_split(y2f[0]); y2[1] = x2_split(y2f[1]); }
             else { y2[0] = mk<XA>(y2f[0]); y2[1] = mk<XA>(y2f[1]); }
         }
         if constexpr (X) {      // the residual stream waits in LDS while the MLP needs the registers
@@ -701,7 +885,11 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
                 MDR_PIN();
             }
             if constexpr (H) gelu_tile_scaled(hdn, inv); else gelu_tile(hdn);
-            if constexpr (H) {
+            if constexpr (XA == 3) {
+                const X1 hx = mk<XA>(hdn, inv);
+                acc2[0][0] = g2_mma_wa(B.t[0], hx, acc2[0][0]);
+                acc2[1][0] = g2_mma_wa(B.t[1], hx, acc2[1][0]);
+            } else if constexpr (H) {
                 const X2 hx = mk<XA>(hdn, inv);
                 acc2[0][0] = h3_mma_wa(B.t[0], hx, acc2[0][0]);
                 acc2[1][0] = h3_mma_wa(B.t[1], hx, acc2[1][0]);
@@ -742,7 +930,7 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         B = ldw<XA>(w.sa1, 2, 3, lane);
         MDR_PIN();
         if constexpr (X) {      // the consumer's softmax works in the exp2 domain: fold log2(e) / sqrt(d_k) into Q once, here
-            const float qs = kLog2e * 0.17677669529663688110f * (XA == 2 ? kX2QK : 1.0f) * inv;
+            const float qs = kLog2e * 0.17677669529663688110f * (XA >= 2 ? kX2QK : 1.0f) * inv;
             y0 = y0 * qs;
             y1 = y1 * qs;
         }
@@ -756,7 +944,7 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         const float bv0 = w.sa2_b[lane & 31], bv1 = w.sa2_b[32 + (lane & 31)];
         MDR_PIN();
         if (token >= kV) { y0 = zero16(); y1 = zero16(); }                   // pad keys: finite (they are masked anyway)
-        if constexpr (XA == 2) { y0 = y0 * (kX2QK * inv); y1 = y1 * (kX2QK * inv); }
+        if constexpr (XA >= 2) { y0 = y0 * (kX2QK * inv); y1 = y1 * (kX2QK * inv); }
         st_op<XA>(a.k_out + (tile + 0) * TQ, lane, y0);
         st_op<XA>(a.k_out + (tile + 1) * TQ, lane, y1);
         y0 = lin2_C(A, vfx);                                                  // V in C-layout: channel on the lane
@@ -767,7 +955,7 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
             y0[r] = ok ? (H ? __builtin_fmaf(y0[r], inv, bv0) : y0[r] + bv0) : 0.f;
             y1[r] = ok ? (H ? __builtin_fmaf(y1[r], inv, bv1) : y1[r] + bv1) : 0.f;
         }
-        if constexpr (XA == 2) { y0 = y0 * kX2V; y1 = y1 * kX2V; }
+        if constexpr (XA >= 2) { y0 = y0 * kX2V; y1 = y1 * kX2V; }
         st_op<XA>(a.v_out + (tile + 0) * TQ, lane, y0);
         st_op<XA>(a.v_out + (tile + 1) * TQ, lane, y1);
     }
@@ -843,6 +1031,9 @@ struct MdrChunkPlan {
         return (size_t)ch * kCtrDone + 4 * ((size_t)big * (base + 1) + (size_t)(ch - big) * base);
     }
 };
+// (Round 5, measured and dropped: the one-plane form XA = 3 built for 168 registers and launched with THREE workgroups per CU -- a SIMD
+// issues the vector instructions of three waves faster than of two, tools/microbench/valu_rate.hip -- spills 164 B per lane even with
+// one weight pair alive at a time, and runs in the same time: 3.25 ms per forward of 2 048 samples either way.)
 template <int XA>
 __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) {
     __shared__ f32x4 park[XA != 0 ? kParkF4 : 1];
@@ -1158,8 +1349,11 @@ LayerW make_layer(const FusedState* f, const gator_ctx* c, int li) {
 }  // namespace
 
 // pc [B,J,133] (reference layout) -> f->vc [B,431,3] (vert431) ; taps: f->lbf
-int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream, const float* x_out, const float* pose2d) {
+int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream, const float* x_out, const float* pose2d, bool half16) {
     (void)pose2d;
+    // half16 (BASELINE config 3): the layers on ONE fp16 activation plane (XA = 3); needs the default weight / joint-tile forms (GATOR_MDR_X3=2)
+    if (half16 && f->mdr_x3 != 2) return fail(GATOR_EUNSUPPORTED, "16-bit MDR layers need GATOR_MDR_X3=2 (the default)");
+    const int xa = half16 ? 3 : f->mdr_x3;
     hipStream_t st = (hipStream_t)stream;
     const Weights& w = c->w;
     JointArgs ja;
@@ -1173,7 +1367,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         k_mdr_joint<<<B, 128, 0, st>>>(ja);
     }    // else: done by k_gat's epilogue / k_gat_joint
     const size_t per = (size_t)f->cap * kVT * 2 * kTile;      // one [B][14][2] tile set
-    const size_t perq = (size_t)f->cap * kVT * 2 * (f->mdr_x3 == 1 ? kTileX3 : kTile);      // q/k/v tile sets: X3 tiles are 1.5x, fp32 and X2 tiles 4 KiB
+    const size_t perq = (size_t)f->cap * kVT * 2 * (f->mdr_x3 == 1 ? kTileX3 : kTile);      // q/k/v tile sets: X3 tiles are 1.5x, fp32 and X2 tiles 4 KiB (X1 tiles 2 KiB: half of a set is used)
     float* set[3][4] = {{f->vf, f->q, f->k, f->v}, {f->vf + per, f->q + perq, f->k + perq, f->v + perq},
                         {f->vf + 2 * per, f->q + 2 * perq, f->k + 2 * perq, f->v + 2 * perq}};
     MdrArgs a{};
@@ -1183,6 +1377,12 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     a.lin_inv = 1.0f / a.lin_s;
     const int nwg = (B * kVT + 3) / 4;
 #ifdef GATOR_DIAG
+    {
+        static const int cut = getenv("GATOR_MDR_CUT") ? atoi(getenv("GATOR_MDR_CUT")) : 0;
+        static const int wm = (cut & 1) ? 0 : -1, kvm = (cut & 2) ? 0 : -1;
+        GATOR_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_mdr_wmask), &wm, sizeof(int), 0, hipMemcpyHostToDevice, st));
+        GATOR_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_mdr_kvmask), &kvm, sizeof(int), 0, hipMemcpyHostToDevice, st));
+    }
     static const bool want_stamps = getenv("GATOR_MDR_STAMPS") != nullptr;
     static const size_t solo = getenv("GATOR_MDR_SOLO") ? 60 * 1024 : 0;      // 1 workgroup per CU (1 wave/SIMD)
     unsigned long long* d_st = nullptr;
@@ -1224,7 +1424,11 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         if (li < 3) a.cur = make_layer(f, c, li);
         if (persist) { pa.st[li] = a; continue; }
         StageTimer tm(c, li == 0 ? "mdr_layer0" : (li < 3 ? "mdr_layer" : "mdr_attn_head"), stream);
-        if (f->mdr_x3 == 2) {
+        if (xa == 3) {
+            if (li == 0) k_mdr_layer<0, 3><<<nwg, 256, solo, st>>>(a, nwg);
+            else if (li < 3) k_mdr_layer<1, 3><<<nwg, 256, solo, st>>>(a, nwg);
+            else k_mdr_layer<2, 3><<<nwg, 256, 0, st>>>(a, nwg);
+        } else if (f->mdr_x3 == 2) {
             if (li == 0) k_mdr_layer<0, 2><<<nwg, 256, solo, st>>>(a, nwg);
             else if (li < 3) k_mdr_layer<1, 2><<<nwg, 256, solo, st>>>(a, nwg);
             else k_mdr_layer<2, 2><<<nwg, 256, 0, st>>>(a, nwg);
@@ -1257,7 +1461,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         int nch = f->mdr_persist_chunk > 0 ? (B + f->mdr_persist_chunk - 1) / f->mdr_persist_chunk : B / 256;
         if (nch < 1) nch = 1;
         if (nch > kMdrCtrChunks) nch = kMdrCtrChunks;
-        const size_t tq = f->mdr_x3 == 1 ? kTileX3 : kTile;
+        const size_t tq = f->mdr_x3 == 1 ? kTileX3 : (xa == 3 ? kTileX1 : kTile);
         plan = MdrChunkPlan{nch, B / nch, B % nch};
         for (int ch = 0, b0 = 0; ch < nch; ++ch) {
             const int n = B / nch + (ch < B % nch ? 1 : 0);
@@ -1275,7 +1479,8 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
                 if (s.lbf) s.lbf += (size_t)b0 * kV * kE;
             }
             pc_.ctr = f->mdr_ctr + plan.block(ch);
-            if (f->mdr_x3 == 2) k_mdr_persist<2><<<grid, 256, 0, st>>>(pc_);
+            if (xa == 3) k_mdr_persist<3><<<grid, 256, 0, st>>>(pc_);
+            else if (f->mdr_x3 == 2) k_mdr_persist<2><<<grid, 256, 0, st>>>(pc_);
             else if (f->mdr_x3 == 1) k_mdr_persist<1><<<grid, 256, 0, st>>>(pc_);
             else k_mdr_persist<0><<<grid, 256, 0, st>>>(pc_);
             b0 += n;

@@ -180,7 +180,7 @@ class ShardedForward:
         self._pin_encoder(min(B, self.micro or B), pose2d_shard.device)
         self._throttle(pose2d_shard.device)
         gv, gp = self._buffers(B, J, pose2d_shard.device)
-        side, chunks = None, []
+        side, chunks, deferred = None, [], None
         in_place = bool(getattr(self.model, 'supports_out', False))
         for i, (s, e) in enumerate(self._plan(B)):
             if in_place:                        # the forward writes this rank's slot of the collective's receive buffer
@@ -188,7 +188,15 @@ class ShardedForward:
                 free = self._stage_free.pop(key, None)
                 if free is not None:            # a staging slot is re-used: its last collective + copy-out must be done first
                     torch.cuda.current_stream(pose2d_shard.device).wait_event(free)
-                verts, pose3d = self.model(pose2d_shard[s:e], out=(mv, mp))
+                try:
+                    verts, pose3d = self.model(pose2d_shard[s:e], out=(mv, mp))
+                except RuntimeError as ex:
+                    # An EARLIER forward's device status (GATOR_EDEVICE, api.hip: finish_fwd) rides on a call that was queued normally:
+                    # this rank's rows are being written, so it still joins the collective -- the other ranks are already in it -- and
+                    # the report is raised once every collective of the step is issued.
+                    if 'THIS call was queued normally' not in str(ex):
+                        raise
+                    deferred, verts, pose3d = ex, mv, mp
             else:
                 verts, pose3d = self.model(pose2d_shard[s:e])
                 verts, pose3d = verts.contiguous(), pose3d.contiguous()
@@ -198,6 +206,8 @@ class ShardedForward:
         # the compute stream does NOT wait: the next step overlaps this gather
         self.last_event = side.record_event() if side is not None else None
         self._issued(self.last_event)
+        if deferred is not None:
+            raise deferred
         return gv, gp
 
     # ---- mode 'eval' -----------------------------------------------------------------------------------------------------
@@ -269,8 +279,13 @@ class ShardedForward:
         if kind == 'gather':
             chunks, B, gv, gp = t
             for verts, pose3d, s, e, i in chunks:
-                if not (s == 0 and e == B) and verts.data_ptr() == self._landing(s, e, B, pose3d.shape[1], gv, gp, i)[2].data_ptr():
-                    # in-place micro-batch: a later chunk has re-used the staging slot; put this rank's rows back first
+                land = self._landing(s, e, B, pose3d.shape[1], gv, gp, i)
+                if not (s == 0 and e == B) and verts.data_ptr() == land[2].data_ptr():
+                    # in-place micro-batch: a later chunk has re-used the staging slot; put this rank's rows back first -- behind the
+                    # last collective + copy-out that used the slot (as step() does before it lets a forward write there)
+                    free = self._stage_free.pop(land[4], None)
+                    if free is not None:
+                        torch.cuda.current_stream(verts.device).wait_event(free)
                     verts.copy_(gv.view(self.world, B, 6890, 3)[self.rank, s:e])
                     pose3d.copy_(gp.view(self.world, B, -1, 3)[self.rank, s:e])
                 side = self._gather_chunk(verts, pose3d, s, e, B, gv, gp, i)

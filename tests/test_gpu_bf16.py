@@ -1,6 +1,9 @@
-"""BASELINE config 3: GATOR forward with the vertex regressor on bf16 MFMA (gator_forward_bf16).  Parity is MPJPE-level by
-construction (bf16 rounding of the 431x3 coarse vertices and of upsample_conv.weight, fp32 accumulation): vertices within a
-few mm (rms ~0.6 mm at these synthetic scales), regressed joints within 3 mm and MPJPE within 0.25 mm of the fp64 oracle; the fp32 stages are untouched."""
+"""BASELINE config 3: the GATOR forward in 16-bit operand mode (gator_forward_bf16).  Round 5: the three MDR layers and the head
+features run on ONE fp16 activation plane (mdr_fused.hip, XA = 3: weights on two planes, fp32 accumulate / softmax / norms / GELU /
+residual stream); the encoder and the vertex regressor keep the fp32 configuration's two-plane operands (a single 16-bit plane THERE is
+what costs millimetres: tools/emulate_16bit.py, profiles/r05_emulate_16bit.txt).  Bar (round-4 review): vertices within 1 mm max /
+0.2 mm rms of the fp64 oracle, |delta MPJPE| <= 0.05 mm.  The round-4 form (bf16 vertex regressor only, 8 mm / 1 mm) stays reachable
+through GATOR_C3_MDR=0 GATOR_C3_UPSAMPLE_BF16=1 and through the stage entry point tested at the bottom."""
 import numpy as np
 import pytest
 import torch
@@ -26,18 +29,18 @@ def test_bf16_forward_mpjpe_parity(name, B):
     err = np.abs(verts.cpu().numpy().astype(np.float64) - ref.numpy()) * 1e3
     print('\n[%s bf16 B=%d] vertex err vs fp64: max %.3f mm  rms %.3f mm ; fp32 path max %.2e mm'
           % (name, B, err.max(), np.sqrt((err ** 2).mean()), np.abs(v32.cpu().numpy() - ref.numpy()).max() * 1e3))
-    assert err.max() < 8.0 and np.sqrt((err ** 2).mean()) < 1.0      # bf16 operand rounding: ~2^-9 relative per product
+    assert err.max() < 1.0 and np.sqrt((err ** 2).mean()) < 0.2      # one fp16 activation plane in the MDR layers: 2^-12 relative per operand element
     assert np.abs(pose3d.cpu().numpy() - rp.numpy()).max() <= 1e-3          # GAT stays fp32
     jr = synthetic.load_j_regressors()['h36m']
     reg = geval.JointRegressor(jr, 'cuda')
     j_bf = reg(verts * 1000).cpu().numpy()
     j_ref = go.regress_joints(jr, ref * 1000).numpy()
-    assert np.abs(j_bf - j_ref).max() < 3.0                                  # joints average ~6 vertices each
+    assert np.abs(j_bf - j_ref).max() < 1.0                                  # joints average ~6 vertices each
     gt = j_ref + np.random.RandomState(0).randn(*j_ref.shape) * 30.0
     e_bf = go.mpjpe(j_bf, gt, list(geval.H36M_EVAL_JOINTS))
     e_ref = go.mpjpe(j_ref, gt, list(geval.H36M_EVAL_JOINTS))
     print('[%s bf16] joints max %.3f mm, MPJPE %.4f vs %.4f mm' % (name, np.abs(j_bf - j_ref).max(), e_bf, e_ref))
-    assert abs(e_bf - e_ref) < 0.25
+    assert abs(e_bf - e_ref) < 0.05
 
 
 def test_bf16_upsample_stage():
@@ -53,3 +56,43 @@ def test_bf16_upsample_stage():
     assert err.max() < 8.0
     v2 = mdr.upsample(taps['vert431'].float().cuda(), precision='f32')
     assert np.abs(v2.cpu().numpy() - ref.numpy()).max() * 1e3 <= 1e-3
+
+
+@pytest.mark.timeout(1500)
+def test_config3_2048_samples_every_coordinate():
+    """BASELINE config 3 at its own size (B = 2048, J = 19), every coordinate of every sample against the fp64 oracle: max <= 1 mm,
+    rms <= 0.2 mm, |delta MPJPE| <= 0.05 mm (the round-4 review's bar for "config 3 is real"); deterministic; pose3d is the fp32 path's."""
+    from oracle import gator_oracle as go
+    B, J = 2048, 19
+    z, m = build_model('coco19_alpha', 'fused')
+    zz, c, sd = oracle_setup('coco19_alpha')
+    x = torch.from_numpy(synthetic.synthetic_pose2d(B, J, seed=77))
+    m.precision = 'bf16'
+    v, p = m(x.cuda())
+    v2, _ = m(x.cuda())
+    assert torch.equal(v, v2)
+    m.precision = 'f32'
+    vf, pf = m(x.cuda())
+    assert torch.equal(p, pf)                                       # the encoder is untouched by the mode
+    m.device_status()
+    jr = synthetic.load_j_regressors()['h36m']
+    worst, sq, n, jd = 0.0, 0.0, 0, []
+    gt_rs = np.random.RandomState(0)
+    e16, e64 = [], []
+    for s in range(0, B, 256):
+        ref, _ = go.gator_forward(sd, c, x[s:s + 256], torch.float64)
+        e = np.abs(v[s:s + 256].cpu().numpy().astype(np.float64) - ref.numpy()) * 1e3
+        worst = max(worst, float(e.max()))
+        sq += float((e ** 2).sum())
+        n += e.size
+        j16 = go.regress_joints(jr, v[s:s + 256].cpu().double() * 1000).numpy()
+        j64 = go.regress_joints(jr, ref * 1000).numpy()
+        gt = j64 + gt_rs.randn(*j64.shape) * 30.0
+        e16.append(go.mpjpe(j16, gt, list(geval.H36M_EVAL_JOINTS)))
+        e64.append(go.mpjpe(j64, gt, list(geval.H36M_EVAL_JOINTS)))
+    rms = float(np.sqrt(sq / n))
+    dm = abs(float(np.mean(e16)) - float(np.mean(e64)))
+    d32 = float((v - vf).abs().max()) * 1e3
+    print('\n[config 3, B=2048 J=19, %d coordinates] vs fp64 oracle: max %.3f mm  rms %.4f mm  |dMPJPE| %.5f mm ; vs the fp32 path max %.3f mm'
+          % (n, worst, rms, dm, d32))
+    assert worst <= 1.0 and rms <= 0.2 and dm <= 0.05

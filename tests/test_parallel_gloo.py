@@ -32,7 +32,12 @@ class _FakeModel:                           # the module surface ShardedForward 
         out[0].copy_(v)
         out[1].copy_(p)
         self.out_ptrs.append(out[0].data_ptr())
+        if self.report_next:                 # like gator_forward_f32 after an earlier bad forward: the work is queued, THEN the report is raised
+            self.report_next = False
+            raise RuntimeError('gator_forward_f32 failed (-6): an earlier forward on this ctx produced non-finite ... THIS call was queued normally; ...')
         return out
+
+    report_next = False
 
     def set_encoder(self, mode):
         self.encoder_calls.append(mode)
@@ -58,7 +63,23 @@ def _worker(rank, world, port, micro, mode, q, in_place=True):
     from gator_amd.parallel import ShardedForward
     n = 6
     ok = True
-    if mode == 'gather':
+    if mode == 'deferred':                   # one rank's forward reports an earlier call's device status: nobody may hang in the collective
+        model = _FakeModel(True)
+        run = ShardedForward(model, world, rank, dist, micro_batch=micro)
+        for step in range(3):
+            torch.manual_seed(step)
+            full = torch.randn(world * n, 17, 2)
+            model.report_next = rank == 1 and step == 1
+            raised = False
+            try:
+                gv, gp = run.step(full[rank * n:(rank + 1) * n])
+            except RuntimeError as ex:
+                raised = 'THIS call was queued normally' in str(ex)
+                gv, gp = run._last[1][2], run._last[1][3]
+            rv, rp = _fake_forward(full)
+            ok = ok and raised == (rank == 1 and step == 1)
+            ok = ok and bool(torch.equal(gv, rv)) and bool(torch.equal(gp, rp))     # every rank, incl. the reporting one, holds the full gather
+    elif mode == 'gather':
         model = _FakeModel(in_place)
         run = ShardedForward(model, world, rank, dist, micro_batch=micro)
         kept = []
@@ -116,6 +137,11 @@ def test_allgather_full_batch():
 
 def test_allgather_microbatched_ragged():
     _run(4)                                  # 6 samples per rank in chunks of 4 + 2
+
+
+def test_deferred_device_status_does_not_strand_the_other_ranks():
+    _run(None, 'deferred')
+    _run(4, 'deferred')
 
 
 def test_allgather_model_without_out_argument():
