@@ -781,7 +781,7 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         else if constexpr (XA == 2) { attx[0] = x2_split(att[0]); attx[1] = x2_split(att[1]); }      // the heads come out at 16 x value already
         else { attx[0] = mk<XA>(att[0]); attx[1] = mk<XA>(att[1]); }
         const f32x16 y0 = lin2_T(A, attx, chanvec_lds(VT, VO_SA3B, h));
-        if (MODE == 1) A = ldw<XA>(w.wq, 0, 1, lane); else A = ldw<XA>(a.head_w, 0, 1, lane);
+        if (MODE == 1) A = ldw<XA>(w.wq, 0, 1, lane); else if (XA != 3) A = ldw<XA>(a.head_w, 0, 1, lane);
         MDR_PIN();
         const f32x16 y1 = lin2_T(B, attx, chanvec_lds(VT, VO_SA3B + 32, h));
         if (MODE == 1) B = ldw<XA>(w.wq, 2, 3, lane);
@@ -801,8 +801,17 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
                     *reinterpret_cast<f32x4*>(a.lbf + ((size_t)b * kV + token) * kE + 32 * nb + 8 * g + 4 * h) = v4;
                 }
         }
-        const Act vfx[2] = {mk<XA>(vf[0]), mk<XA>(vf[1])};
-        f32x16 acc = lin2_T(A, vfx, chanvec_lds(VT, VO_HEADB, h));
+        f32x16 acc;
+        if constexpr (XA == 3) {
+            // the head features (mat_A | bias_linear | scale_linear | mat_C, MDR.py:156-162) keep the fp32 configuration's operands even in
+            // 16-bit mode: mat_C goes straight into the coarse vertices, and this is 8 MFMAs of a tile's ~350 (profiles/r05_emulate_16bit.txt, C3d)
+            const X2 vfx2[2] = {x2_split(vf[0] * kActScale), x2_split(vf[1] * kActScale)};
+            const W2H Ah = ldw2h(a.head_w, MDR_WIDX(0), MDR_WIDX(1), lane);
+            acc = lin2_T(Ah, vfx2, chanvec_lds(VT, VO_HEADB, h));
+        } else {
+            const Act vfx[2] = {mk<XA>(vf[0]), mk<XA>(vf[1])};
+            acc = lin2_T(A, vfx, chanvec_lds(VT, VO_HEADB, h));
+        }
         if constexpr (H) acc = acc * inv;
         if (token < kV) {
 #pragma unroll

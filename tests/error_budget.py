@@ -37,6 +37,7 @@ CONFIGS = {
     'all_exact/sample': ({'GATOR_GAT8_H4': '0', 'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1'}, 'sample'),
     'all_exact/tiled': ({'GATOR_GAT_TILED_H4': '0', 'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1'}, 'tiled'),
     'fp32_mfma/sample': ({'GATOR_GAT_X3': '0', 'GATOR_MDR_X3': '0', 'GATOR_UPSAMPLE_X3': '0'}, 'auto'),
+    'config3_f16/sample': ({'_precision': 'bf16'}, 'sample'),      # gator_forward_bf16: MDR layers on one fp16 activation plane (round 5); HIST_MAX clips its histogram, max / rms are exact
 }
 SWITCHES = ('GATOR_GAT8_H4', 'GATOR_GAT_TILED_H4', 'GATOR_MDR_X3', 'GATOR_UPSAMPLE_X3', 'GATOR_GAT_X3', 'GATOR_GAT8', 'GATOR_GAT_TILED')
 HIST_BINS, HIST_MAX = 4000, 4e-3         # mm; 1e-6 mm bins
@@ -97,10 +98,13 @@ def device_outputs(name, wseed, pose, cfg, chunk):
     import torch
     from tests.helpers import build_model
     env, pin = CONFIGS[cfg]
+    env = dict(env)
+    prec = env.pop('_precision', 'f32')
     saved = {k: os.environ.pop(k, None) for k in SWITCHES}
     os.environ.update(env)
     try:
         z, m = build_model(name, 'fused', seed=wseed)
+        m.precision = prec
         if pin != 'auto':
             m.set_encoder(pin)
         out = torch.empty(pose.shape[0], 6890, 3, device='cuda')
@@ -133,17 +137,23 @@ def run_cell(name, wseed, N, configs, pool, nworkers, threads, slice_n, chunk, l
         outs[cfg] = device_outputs(name, wseed, pose, cfg, chunk)
         log('  [%s seed %d] device %-18s done (%.0f s)' % (name, wseed, cfg, time.time() - t0))
     stats = {cfg: Stat(N, 'cuda') for cfg in list(configs) + ['ref32']}
+    vs32 = {cfg: Stat(N, 'cuda') for cfg in configs}          # |ours - ref32|: north_star's literal wording ("within 1e-3 mm of the reference forward")
     done = 0
     for lo, r64, r32 in pending:
         ref = torch.from_numpy(r64).cuda()
         b = ref.shape[0]
+        r32d = torch.from_numpy(r32).cuda().double()
         for cfg in configs:
             stats[cfg].add(lo, (outs[cfg][lo:lo + b].double() - ref).abs() * 1e3)
-        stats['ref32'].add(lo, (torch.from_numpy(r32).cuda().double() - ref).abs() * 1e3)
+            vs32[cfg].add(lo, (outs[cfg][lo:lo + b].double() - r32d).abs() * 1e3)
+        stats['ref32'].add(lo, (r32d - ref).abs() * 1e3)
         done += b
         if done % (8 * slice_n) == 0 or done == N:
             log('  [%s seed %d] oracle %d / %d samples (%.0f s)' % (name, wseed, done, N, time.time() - t0))
     res = {cfg: s.summary() for cfg, s in stats.items()}
+    for cfg in configs:
+        v = vs32[cfg].summary()
+        res[cfg]['vs_ref32_max_mm'], res[cfg]['vs_ref32_p99_999_mm'] = v['max_mm'], v['p99_999_mm']
     # which samples are the worst under the shipped arithmetic, and what the reference's own arithmetic does on them
     first = configs[0]
     worst = torch.topk(stats[first].per_sample, min(5, N)).indices.tolist()
@@ -152,14 +162,16 @@ def run_cell(name, wseed, N, configs, pool, nworkers, threads, slice_n, chunk, l
 
 
 def table(results):
-    lines = ['| variant / weight seed | configuration | max mm | p99.999 mm | rms mm | samples > 0.85e-3 | > 1e-3 | max / ref32 max |', '|---|---|---|---|---|---|---|---|']
+    lines = ['| variant / weight seed | configuration | max mm | p99.999 mm | rms mm | samples > 0.85e-3 | > 1e-3 | max / ref32 max | max abs(ours - ref32) mm | p99.999 abs(ours - ref32) mm |',
+             '|---|---|---|---|---|---|---|---|---|---|']
     for cell, res in results.items():
         ref = res['ref32']['max_mm']
         for cfg, s in res.items():
             if cfg.startswith('_'):
                 continue
-            lines.append('| %s | %s | %.2e | %.2e | %.2e | %d | %d | %.2f |' % (cell, cfg, s['max_mm'], s['p99_999_mm'], s['rms_mm'], s['samples_over_0.85e-3'],
-                                                                              s['samples_over_1e-3'], s['max_mm'] / ref))
+            d32 = ('%.2e | %.2e' % (s['vs_ref32_max_mm'], s['vs_ref32_p99_999_mm'])) if 'vs_ref32_max_mm' in s else '- | -'
+            lines.append('| %s | %s | %.2e | %.2e | %.2e | %d | %d | %.2f | %s |' % (cell, cfg, s['max_mm'], s['p99_999_mm'], s['rms_mm'], s['samples_over_0.85e-3'],
+                                                                                   s['samples_over_1e-3'], s['max_mm'] / ref, d32))
     return '\n'.join(lines)
 
 

@@ -1,0 +1,23 @@
+"""Bit-identity of the fp32 forward against recorded digests (tests/golden/fp32_digests.json, written by tools/ab_digest.py on a GPU box).
+Round 4 made several changes that were meant to be schedules only and checked them by hand with tools/ab_digest.py; this is that check
+as a test: per-sample kernel and sample-tiled kernel, persistent and four-launch MDR forms (B = 5 / 256 / 700), both golden variants.
+A change that is meant to move bits re-records the file (and re-runs the error budget); any other change must leave it green."""
+import json
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fp32_digests.json')
+
+
+def test_fp32_forward_digests_match_the_recorded_build():
+    if not os.path.exists(PATH):
+        pytest.skip('no recorded digests (tools/ab_digest.py --write tests/golden/fp32_digests.json on a GPU box)')
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.ab_digest import digests
+    want = json.load(open(PATH))['digests']
+    got = digests()
+    bad = {k: (got.get(k), h) for k, h in want.items() if got.get(k) != h}
+    assert not bad, 'outputs moved bits against tests/golden/fp32_digests.json: %s' % bad

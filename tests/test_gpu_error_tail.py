@@ -1,0 +1,55 @@
+"""The relative parity criterion on the two heavy-tailed weight draws (round-4 review, item 4a).
+
+profiles/r04_error_budget.md: with two of the six (variant, weight seed) cells -- h36m17_bn seed 1, coco19_alpha seed 2 -- individual poses
+drive the alpha head / the attention logits up, and over 16 384 samples neither the reference's own fp32 arithmetic (478 / 120 samples
+above 1e-3 mm) nor ours (22 - 74 / 26 - 45) meets the absolute 1e-3 mm bar.  What CAN be held there, and what a regression of the
+shipped arithmetic would break first, is the relative criterion: on the same samples, against the fp64 oracle, ours is not noisier than
+the reference's arithmetic (the oracle in fp32) -- rms, max and the number of samples above 1e-3 mm -- under BOTH encoder kernels.
+1 024 samples per cell (the first 1 024 poses of the budget's own stream)."""
+import numpy as np
+import pytest
+import torch
+
+from gator_amd import synthetic
+from tests.helpers import build_model, oracle_setup
+
+pytestmark = pytest.mark.gpu
+N = 1024
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize('name,wseed', [('h36m17_bn', 1), ('coco19_alpha', 2)])
+def test_not_noisier_than_the_reference_arithmetic_on_heavy_tailed_draws(name, wseed):
+    from oracle import gator_oracle as go
+    z, m = build_model(name, 'fused', seed=wseed)
+    zz, c, sd = oracle_setup(name, seed=wseed)
+    x = torch.from_numpy(synthetic.synthetic_pose2d(N, c.J, seed=1000 + 17 * wseed))
+    outs = {}
+    for pin in ('sample', 'tiled'):
+        m.set_encoder(pin)
+        outs[pin] = m(x.cuda())[0].cpu().numpy().astype(np.float64)
+    m.set_encoder('auto')
+    m.device_status()
+    torch.set_num_threads(min(32, torch.get_num_threads() * 2 or 16))
+    st = {k: dict(mx=0.0, sq=0.0, n=0, over=0, d32=0.0) for k in ('ref32', 'sample', 'tiled')}
+    for lo in range(0, N, 128):
+        r64 = go.gator_forward(sd, c, x[lo:lo + 128], torch.float64)[0].numpy()
+        r32 = go.gator_forward(sd, c, x[lo:lo + 128], torch.float32)[0].numpy().astype(np.float64)
+        for k, v in (('ref32', r32), ('sample', outs['sample'][lo:lo + 128]), ('tiled', outs['tiled'][lo:lo + 128])):
+            e = np.abs(v - r64) * 1e3
+            s = st[k]
+            s['mx'] = max(s['mx'], float(e.max()))
+            s['sq'] += float((e ** 2).sum())
+            s['n'] += e.size
+            s['over'] += int((e.reshape(e.shape[0], -1).max(1) > 1e-3).sum())
+            s['d32'] = max(s['d32'], float(np.abs(v - r32).max()) * 1e3)      # north_star's literal wording: |ours - reference forward|
+    rms = {k: (s['sq'] / s['n']) ** 0.5 for k, s in st.items()}
+    print('\n[%s seed %d, %d samples] vs fp64: ' % (name, wseed, N) + ' ; '.join(
+        '%s max %.3e rms %.3e over-1e-3 %d' % (k, st[k]['mx'], rms[k], st[k]['over']) for k in st)
+        + ' ; max |ours - ref32| sample %.3e tiled %.3e mm' % (st['sample']['d32'], st['tiled']['d32']))
+    for pin in ('sample', 'tiled'):
+        assert rms[pin] <= rms['ref32'], (pin, rms)
+        assert st[pin]['mx'] <= st['ref32']['mx'], (pin, st)
+        assert st[pin]['over'] <= st['ref32']['over'], (pin, st)
+        # both are within their own noise of fp64, so they are within the sum of the two of each other
+        assert st[pin]['d32'] <= st[pin]['mx'] + st['ref32']['mx']

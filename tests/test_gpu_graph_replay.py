@@ -57,13 +57,24 @@ def test_graph_replay_slots_eviction_and_switching_off():
             torch.cuda.synchronize()
             assert torch.equal(v, want[0]) and torch.equal(p, want[1]), (rnd, B)
     assert m.graph_launches() == 2 * len(cases)
-    for B in range(10, 19):                                # nine more keys than the eight slots hold: the oldest captures are dropped
+    for B in range(10, 19):                                # eighteen more keys (fresh output tensors each call) than the eight slots hold: keys that were
+                                                           # never captured are evicted first (no device-wide wait), the six captured forwards stay
         xs = _x(B, 17, B)
         for it in range(2):
             v, p = m(xs, out=(torch.empty(B, 6890, 3, device='cuda'), torch.empty(B, 17, 3, device='cuda')))
     x, out, want = cases[256]
     n = m.graph_launches()
-    for it in range(3):                                    # seen again: direct, capture + launch, replay
+    for it in range(3):                                    # seen again: its capture survived, three replays
+        v, p = m(x, out=out)
+        torch.cuda.synchronize()
+        assert torch.equal(v, want[0]) and torch.equal(p, want[1])
+    assert m.graph_launches() == n + 3
+    for B in range(20, 29):                                # nine more CAPTURED keys: now the oldest captures are dropped
+        xs, outs = _x(B, 17, B), (torch.empty(B, 6890, 3, device='cuda'), torch.empty(B, 17, 3, device='cuda'))
+        for it in range(2):
+            m(xs, out=outs)
+    n = m.graph_launches()
+    for it in range(3):                                    # direct, capture + launch, replay
         v, p = m(x, out=out)
         torch.cuda.synchronize()
         assert torch.equal(v, want[0]) and torch.equal(p, want[1])
