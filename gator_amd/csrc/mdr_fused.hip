@@ -353,6 +353,105 @@ __device__ __forceinline__ f32x16 self_attention_head_x2(const float* __restrict
 }
 
 
+// ---- the same loop, software-pipelined by one key tile inside the wave (round 5; MDR_ATTN_PIPE=1, tools/microbench/attn_pipe.hip) ------
+//     block A:  lo plane of P[kt-1] (deferred), O += V[kt-1] P[kt-1] (hi.hi first: it needs no lo plane)  ||  row maximum of S[kt]
+//     rescale (rare, wave-uniform)
+//     block B:  S[kt+1] = K[kt+1] Q  ||  exp2, row sum, hi plane of P[kt]
+// so that every MFMA is followed IN THE WAVE'S OWN STREAM by independent vector work.  Same arithmetic, same order of every
+// accumulation: bitwise the results of self_attention_head_x2.  Alone the loop takes 16 % fewer cycles (776 -> 649 per key tile
+// and SIMD) -- and the chip gives most of it back as clock on real data (profiles/r05_microbench_attn_pipe.txt).
+#ifndef MDR_ATTN_PIPE
+#define MDR_ATTN_PIPE 0
+#endif
+template <bool kActScale16>
+__device__ __forceinline__ f32x16 self_attention_head_x2_pipe(const float* __restrict__ qt, const float* __restrict__ kbase,
+                                                              const float* __restrict__ vbase, int lane) {
+    const int h = lane >> 5;
+    const X2 qx = x2_load(qt, lane);
+    f32x16 O = zero16(), O2 = zero16();
+    float m = -1e30f, l = 0.f;
+    X2 kb0 = x2_load(kbase, lane), kb1 = x2_load(kbase + (size_t)MDR_KVIDX(1) * 2 * kTile, lane);
+    X2 vb0 = x2_load(vbase, lane), vb1 = x2_load(vbase + (size_t)MDR_KVIDX(1) * 2 * kTile, lane);
+    f32x16 S0 = x2_mma(kb0, qx, zero16()), S1 = zero16();          // S[0]; "P[-1]" = 0 in fp32 and in its hi plane
+    kb0 = x2_load(kbase + (size_t)MDR_KVIDX(2) * 2 * kTile, lane);
+    f16x8 ph[2] = {f16x8(0), f16x8(0)};
+    auto step = [&](auto last_, const int kt, f32x16& Sc, f32x16& Sp, X2& Vp, X2& Kn) {
+        constexpr bool LAST = decltype(last_)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LAST) {                                      // keys 431..447 do not exist
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (kap(r) + 4 * h >= kV - 32 * (kVT - 1)) Sc[r] = -1e30f;
+        }
+        f16x8 plo[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) plo[s][j] = (_Float16)(Sp[8 * s + j] - (float)ph[s][j]);
+        O = GATOR_MFMA_F16(Vp.p[0][0], ph[0], O);
+        O = GATOR_MFMA_F16(Vp.p[0][1], ph[1], O);
+        O2 = GATOR_MFMA_F16(Vp.p[1][0], ph[0], O2);
+        O2 = GATOR_MFMA_F16(Vp.p[0][0], plo[0], O2);
+        O2 = GATOR_MFMA_F16(Vp.p[1][1], ph[1], O2);
+        O2 = GATOR_MFMA_F16(Vp.p[0][1], plo[1], O2);
+        float bm = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bm = fmaxf(bm, Sc[r]);
+        bm = fmaxf(bm, xhalf(bm));
+        const bool calm = __all(bm <= m + 2048.0f);
+        __builtin_amdgcn_sched_barrier(0);
+        Vp = x2_load(vbase + (size_t)MDR_KVIDX(kt + 1 < kVT ? kt + 1 : kVT - 1) * 2 * kTile, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!calm) {
+            const float mn = fmaxf(m, bm);
+            const float al = __builtin_amdgcn_exp2f((m - mn) * 0.00390625f);
+            O = O * al;
+            O2 = O2 * al;
+            l *= al;
+            m = mn;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Sp = x2_mma(Kn, qx, zero16());
+        const float off = 6.0f - m * 0.00390625f;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pe = __builtin_amdgcn_exp2f(fmaf(Sc[r], 0.00390625f, off));
+            Sc[r] = pe;
+            ps += pe;
+        }
+        l += ps;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ph[s][j] = (_Float16)Sc[8 * s + j];
+        __builtin_amdgcn_sched_barrier(0);
+        Kn = x2_load(kbase + (size_t)MDR_KVIDX(kt + 3 < kVT ? kt + 3 : kVT - 1) * 2 * kTile, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int kt = 0; kt < kVT - 2; kt += 2) {
+        step(std::false_type(), kt, S0, S1, vb1, kb1);
+        step(std::false_type(), kt + 1, S1, S0, vb0, kb0);
+    }
+    step(std::false_type(), kVT - 2, S0, S1, vb1, kb1);
+    step(std::true_type(), kVT - 1, S1, S0, vb0, kb0);
+    {   // P[13] V[13]: fp32 probabilities in S1, V[13] in vb1
+        f16x8 plo[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) plo[s][j] = (_Float16)(S1[8 * s + j] - (float)ph[s][j]);
+        O = GATOR_MFMA_F16(vb1.p[0][0], ph[0], O);
+        O = GATOR_MFMA_F16(vb1.p[0][1], ph[1], O);
+        O2 = GATOR_MFMA_F16(vb1.p[1][0], ph[0], O2);
+        O2 = GATOR_MFMA_F16(vb1.p[0][0], plo[0], O2);
+        O2 = GATOR_MFMA_F16(vb1.p[1][1], ph[1], O2);
+        O2 = GATOR_MFMA_F16(vb1.p[0][1], plo[1], O2);
+    }
+    l += xhalf(l);
+    return (O + O2) * (((kActScale16 ? 16.0f : 1.0f) / kX2V) / l);
+}
+
 // ---- ONE fp16 plane ("X1", BASELINE config 3: the MDR layers in 16-bit operand mode, XA == 3) --------------------------------------------
 // Activations, Q, K, V and the probabilities are ONE fp16 plane of 16 x value (64 x for P): no split, 2 KiB tiles, 2 MFMAs per 32-deep
 // product in the attention cores (against 6) and 4 per token-wise product (weights on their two leading fp16 planes, 22 bits: against
@@ -384,30 +483,45 @@ __device__ __forceinline__ f32x16 x1_mma(const X1& A, const X1& B, f32x16 acc) {
     return GATOR_MFMA_F16(A.p[1], B.p[1], acc);
 }
 constexpr int kTileX1 = kTile / 2;
+// One key tile.  The VALU work per tile is what bounds this form (4 MFMAs against ~50 vector instructions), so the softmax is cut to
+// exp2 + row sum + one conversion per pair:
+//   * Q arrives scaled by log2(e) / sqrt(d_k) and K unscaled, so the MFMA delivers the score in the exp2 domain, and the running
+//     reference rides on the accumulator's initial value (Ci = 6 - m in every register: the 2^6 keeps P's fp16 image normal), so the
+//     exponent is S itself -- no scale / offset instruction per value;
+//   * no row maximum: the probabilities are non-negative, so "the lane's row sum < 2^15" proves every one of them is inside fp16's range;
+//     where that fails (first tile, a tile whose scores jump by 2^9, anything non-finite) the tile is redone the long way: raw scores,
+//     maximum, rescale of O and l, new reference.  Wave-uniform and rare.
 #define ATTN_TILE_X1(KT, KB, VB)                                                                            \
     {                                                                                                       \
-        f32x16 S = x1_mma(KB, qx, zero16());  /* 256 x S^T[key][query] */                                   \
-        float bm = -1e30f;                                                                                  \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
-            float sc = S[r];                                                                                \
-            if ((KT) == kVT - 1 && kap(r) + 4 * h >= kV - 32 * (kVT - 1)) sc = -1e30f;                      \
-            S[r] = sc;                                                                                      \
-            bm = fmaxf(bm, sc);                                                                             \
+        f32x16 S = x1_mma(KB, qx, Ci);        /* S^T[key][query] - m + 6, exp2 domain */                    \
+        if ((KT) == kVT - 1) {                                                                              \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                  \
+                if (kap(r) + 4 * h >= kV - 32 * (kVT - 1)) S[r] = -1e30f;   /* keys 431..447 do not exist */ \
         }                                                                                                   \
-        bm = fmaxf(bm, xhalf(bm));                                                                          \
-        if (!__all(bm <= m + 2048.0f)) {      /* lazy rescale: P stays <= 2^8 (x 2^6 below) */               \
+        float ps = 0.f;                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+            S[r] = __builtin_amdgcn_exp2f(S[r]);                                                            \
+            ps += S[r];                                                                                     \
+        }                                                                                                   \
+        if (!__all(ps < 32768.0f)) {                                                                        \
+            f32x16 R = x1_mma(KB, qx, zero16());                                                            \
+            float bm = -1e30f;                                                                              \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                \
+                if ((KT) == kVT - 1 && kap(r) + 4 * h >= kV - 32 * (kVT - 1)) R[r] = -1e30f;                \
+                bm = fmaxf(bm, R[r]);                                                                       \
+            }                                                                                               \
+            bm = fmaxf(bm, xhalf(bm));                                                                      \
             const float mn = fmaxf(m, bm);                                                                  \
-            const float al = __builtin_amdgcn_exp2f((m - mn) * 0.00390625f);                                \
+            const float al = __builtin_amdgcn_exp2f(m - mn);                                                \
             O = O * al;                                                                                     \
             l *= al;                                                                                        \
             m = mn;                                                                                         \
-        }                                                                                                   \
-        const float off = 6.0f - m * 0.00390625f;                                                           \
-        float ps = 0.f;                                                                                     \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
-            const float pe = __builtin_amdgcn_exp2f(fmaf(S[r], 0.00390625f, off));                          \
-            S[r] = pe;                                                                                      \
-            ps += pe;                                                                                       \
+            Ci = f32x16(6.0f - m);                                                                          \
+            ps = 0.f;                                                                                       \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                \
+                S[r] = __builtin_amdgcn_exp2f(R[r] + Ci[r]);                                                \
+                ps += S[r];                                                                                 \
+            }                                                                                               \
         }                                                                                                   \
         l += ps;                                                                                            \
         O = x1_mma(VB, x1_cvt(S), O);                                                                       \
@@ -419,6 +533,7 @@ __device__ __forceinline__ f32x16 self_attention_head_x1(const float* __restrict
     const X1 qx = x1_load(qt, lane);
     f32x16 O = zero16();
     float m = -1e30f, l = 0.f;
+    f32x16 Ci = f32x16(1e30f);                 // "6 - m" of an empty history: the first tile overflows its row sums and takes the long way
     X1 kb = x1_load(kbase, lane), vb = x1_load(vbase, lane);
 #pragma unroll 1
     for (int kt = 0; kt < kVT - 2; kt += 2) {
@@ -641,6 +756,37 @@ template <int XA> __device__ __forceinline__ typename TokOp<XA>::A mk(const f32x
     if constexpr (XA == 3) return x1_cvt(v * (kActScale * pre)); else if constexpr (XA == 2) return x2_split(v * (kActScale * pre)); else if constexpr (XA == 1) return x3_split(v); else return v;
 }
 
+// ---- GELU by table (XA == 3 only).  The exact GELU is a quarter of the one-plane tile's vector work (one degree-8 polynomial + exp2 per
+// value, in packed fp32 that the SIMD issues at half rate); its result is rounded to ONE fp16 plane right afterwards, so Phi(x) is read
+// from an LDS table instead: 3 072 (value, forward difference) pairs on [-6, 6) in steps of 1 / 256, linear interpolation -- error of Phi
+// below 4.6e-7 (h^2 / 8 max|Phi''|), against 2.4e-4 |x| for the fp16 rounding that follows; |x| >= 6 clamps to Phi = 0 / 1 (exact to 1e-9).
+// Seven vector instructions and one ds_read_b64 per value instead of ~14 issue slots.  The fp32 configuration keeps the polynomial.
+#ifndef MDR_X1_GELU_TABLE
+#define MDR_X1_GELU_TABLE 1
+#endif
+constexpr bool kX1GeluTable = MDR_X1_GELU_TABLE != 0;
+constexpr int kGeluTab = 3072;
+__device__ __forceinline__ void gelu_table_fill(float* GT) {      // cooperative (256 threads); the caller puts a barrier behind it
+    for (int e = threadIdx.x; e < kGeluTab; e += 256) {
+        const float x0 = (float)(e - kGeluTab / 2) * (1.0f / 256.0f), x1 = x0 + (1.0f / 256.0f);
+        const float p0 = 0.5f * (1.0f + erf_fast(x0 * 0.70710678118654752440f)), p1 = 0.5f * (1.0f + erf_fast(x1 * 0.70710678118654752440f));
+        GT[2 * e] = p0;
+        GT[2 * e + 1] = e + 1 < kGeluTab ? p1 - p0 : 0.f;
+    }
+}
+// v holds S x value (k = 1 / S): returns S x GELU(value)
+__device__ __forceinline__ void gelu_tile_table(f32x16& v, float k, const float* GT) {
+    const float ks = k * 256.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float t = __builtin_fmaf(v[r], ks, (float)(kGeluTab / 2));
+        t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)kGeluTab - 0.0005f);
+        const float fl = __builtin_floorf(t);
+        const f32x2 e = *reinterpret_cast<const f32x2*>(GT + 2 * (int)fl);
+        v[r] = v[r] * __builtin_fmaf(t - fl, e[1], e[0]);
+    }
+}
+
 // MODE 0: tokenise + tokenwise(0) ; 1: attention + tokenwise ; 2: attention + head features
 // XA   0: everything on the fp32-input MFMA ; 1: split precision (exact bf16 x 3, six partial products) everywhere ; 2 (the default):
 //         token-wise linears on four partial products (weights exact on three fp16 planes, activations on two: x3_common.h), the
@@ -677,7 +823,7 @@ __device__ __forceinline__ void mdr_stage_vectors(const MdrArgs& a, float* VT) {
 
 // one wave, one 32-token tile `id` = sample * 14 + tile of the sample
 template <int MODE, int XA>
-__device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const float* VT, f32x4* park) {
+__device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const float* VT, f32x4* park, const float* GT = nullptr) {
     constexpr bool X = XA != 0;
     constexpr int TQ = XA == 1 ? kTileX3 : (XA == 3 ? kTileX1 : kTile);
     auto park_vf = [&](const f32x16 (&v)[2]) {
@@ -754,10 +900,17 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
             att[1] = self_attention_head_x1<true>(a.q_in + (tile + 1) * TQ, a.k_in + ((size_t)b * kVT * 2 + 1) * TQ,
                                     a.v_in + ((size_t)b * kVT * 2 + 1) * TQ, lane);
         } else if constexpr (XA == 2) {
+#if MDR_ATTN_PIPE
+            att[0] = self_attention_head_x2_pipe<true>(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
+                                    a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
+            att[1] = self_attention_head_x2_pipe<true>(a.q_in + (tile + 1) * TQ, a.k_in + ((size_t)b * kVT * 2 + 1) * TQ,
+                                    a.v_in + ((size_t)b * kVT * 2 + 1) * TQ, lane);
+#else
             att[0] = self_attention_head_x2<true>(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
                                     a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
             att[1] = self_attention_head_x2<true>(a.q_in + (tile + 1) * TQ, a.k_in + ((size_t)b * kVT * 2 + 1) * TQ,
                                     a.v_in + ((size_t)b * kVT * 2 + 1) * TQ, lane);
+#endif
         } else if constexpr (XA == 1) {
             att[0] = self_attention_head_x3(a.q_in + (tile + 0) * TQ, a.k_in + ((size_t)b * kVT * 2 + 0) * TQ,
                                             a.v_in + ((size_t)b * kVT * 2 + 0) * TQ, lane);
@@ -893,7 +1046,7 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
                 if (c < 7) A = ldw<XA>(w.fc1, 2 * (c + 1), 2 * (c + 1) + 1, lane); else A = ldw<XA>(w.sa0, 0, 1, lane);
                 MDR_PIN();
             }
-            if constexpr (H) gelu_tile_scaled(hdn, inv); else gelu_tile(hdn);
+            if constexpr (XA == 3 && kX1GeluTable) gelu_tile_table(hdn, inv, GT); else if constexpr (H) gelu_tile_scaled(hdn, inv); else gelu_tile(hdn);
             if constexpr (XA == 3) {
                 const X1 hx = mk<XA>(hdn, inv);
                 acc2[0][0] = g2_mma_wa(B.t[0], hx, acc2[0][0]);
@@ -939,7 +1092,7 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         B = ldw<XA>(w.sa1, 2, 3, lane);
         MDR_PIN();
         if constexpr (X) {      // the consumer's softmax works in the exp2 domain: fold log2(e) / sqrt(d_k) into Q once, here
-            const float qs = kLog2e * 0.17677669529663688110f * (XA >= 2 ? kX2QK : 1.0f) * inv;
+            const float qs = kLog2e * 0.17677669529663688110f * (XA == 2 ? kX2QK : 1.0f) * inv;      // (XA 3: Q . K is the exp2-domain score itself)
             y0 = y0 * qs;
             y1 = y1 * qs;
         }
@@ -953,7 +1106,8 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         const float bv0 = w.sa2_b[lane & 31], bv1 = w.sa2_b[32 + (lane & 31)];
         MDR_PIN();
         if (token >= kV) { y0 = zero16(); y1 = zero16(); }                   // pad keys: finite (they are masked anyway)
-        if constexpr (XA >= 2) { y0 = y0 * (kX2QK * inv); y1 = y1 * (kX2QK * inv); }
+        if constexpr (XA == 2) { y0 = y0 * (kX2QK * inv); y1 = y1 * (kX2QK * inv); }
+        if constexpr (XA == 3) { y0 = y0 * inv; y1 = y1 * inv; }
         st_op<XA>(a.k_out + (tile + 0) * TQ, lane, y0);
         st_op<XA>(a.k_out + (tile + 1) * TQ, lane, y1);
         y0 = lin2_C(A, vfx);                                                  // V in C-layout: channel on the lane
@@ -989,9 +1143,11 @@ template <int MODE, int XA>
 __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) {
     __shared__ f32x4 park[XA != 0 ? kParkF4 : 1];
     __shared__ __attribute__((aligned(16))) float VT[VO_TOTAL];
+    __shared__ __attribute__((aligned(16))) float GT[XA == 3 && MODE < 2 && kX1GeluTable ? 2 * kGeluTab : 2];
+    if constexpr (XA == 3 && MODE < 2 && kX1GeluTable) gelu_table_fill(GT);
     mdr_stage_vectors<MODE, XA>(a, VT);
     __syncthreads();
-    mdr_tile<MODE, XA>(a, xcd_remap(blockIdx.x, nwg) * 4 + (threadIdx.x >> 6), VT, park);
+    mdr_tile<MODE, XA>(a, xcd_remap(blockIdx.x, nwg) * 4 + (threadIdx.x >> 6), VT, park, GT);
 }
 
 // ---- all four stages in ONE persistent launch -------------------------------------------------------------------------------
@@ -1047,7 +1203,9 @@ template <int XA>
 __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) {
     __shared__ f32x4 park[XA != 0 ? kParkF4 : 1];
     __shared__ __attribute__((aligned(16))) float VT[VO_TOTAL];
+    __shared__ __attribute__((aligned(16))) float GT[XA == 3 && kX1GeluTable ? 2 * kGeluTab : 2];
     __shared__ int s_unit;
+    if constexpr (XA == 3 && kX1GeluTable) gelu_table_fill(GT);      // published by the first ticket's barriers
     const int B = p.st[0].B, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned xcc;                                                // the XCD this workgroup REALLY runs on picks its queue
@@ -1105,7 +1263,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) 
             // alone +30 us.)  The compiler barrier keeps the tile's loads behind the poll.
             asm volatile("" ::: "memory");
         }
-        mdr_tile<MODE, XA>(a, id, VT, park);
+        mdr_tile<MODE, XA>(a, id, VT, park, GT);
         // Release to the same L2: the L1 is write-through, so once the stores are acknowledged (vmcnt 0) every CU of the XCD
         // sees them; then the count goes up (an atomic executed in that L2).  The last stage counts too (for k_mdr_head, see above).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1467,7 +1625,9 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         // chunk-local sample keeps its XCD and a launch starts with an empty L1 -- changes nothing: the tiles are written before they are read.
         // Odd chunks on a second, low-priority stream so that a chunk's workgroups move into the slots the previous chunk's tail frees:
         // nothing either, B = 512 .. 2048, two repetitions.)
-        int nch = f->mdr_persist_chunk > 0 ? (B + f->mdr_persist_chunk - 1) / f->mdr_persist_chunk : B / 256;
+        // (the one-plane form's Q / K / V tiles are half the size: chunks of 342 - 512 samples measure 6 % faster than 256 at B = 2 048 -- 3.25
+        // against 3.45 ms per forward, two repetitions, one box -- so it runs ceil(B / 384) launches)
+        int nch = f->mdr_persist_chunk > 0 ? (B + f->mdr_persist_chunk - 1) / f->mdr_persist_chunk : (xa == 3 ? (B + 383) / 384 : B / 256);
         if (nch < 1) nch = 1;
         if (nch > kMdrCtrChunks) nch = kMdrCtrChunks;
         const size_t tq = f->mdr_x3 == 1 ? kTileX3 : (xa == 3 ? kTileX1 : kTile);
