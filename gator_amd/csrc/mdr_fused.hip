@@ -29,6 +29,9 @@ namespace gator {
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
+#ifndef MDR_X1_PIPE
+#define MDR_X1_PIPE 1      // the one-plane form's attention and Mlp loops software-pipelined inside the wave (0: the plain loops, A/B)
+#endif
 
 // Diagnostic library only (GATOR_MDR_CUT, time-only experiments: results are meaningless): bit 0 = every weight load of a matrix reads its
 // tile 0, bit 1 = every K / V load of the 431-key attention reads key tile 0 -- the loads stay, their L2 -> L1 traffic goes (L1 hits).
@@ -533,7 +536,66 @@ __device__ __forceinline__ f32x16 self_attention_head_x1(const float* __restrict
     const X1 qx = x1_load(qt, lane);
     f32x16 O = zero16();
     float m = -1e30f, l = 0.f;
+#if !MDR_X1_PIPE
     f32x16 Ci = f32x16(1e30f);                 // "6 - m" of an empty history: the first tile overflows its row sums and takes the long way
+#endif
+#if MDR_X1_PIPE
+    // Software-pipelined by one key tile (unrolled by two: fixed register names): the RAW scores of tile kt + 1 are issued before the
+    // exponentials of tile kt, so the MFMAs run under the vector work of the same wave.  (Here the reference is added per value -- one
+    // v_add more than the accumulator-initial-value form below, which needs a 16-register tile per head on top of the two score tiles
+    // and spills; this form is bound by latency, not by its vector instruction count.)
+    X1 kA = x1_load(kbase, lane), vA = x1_load(vbase, lane);
+    X1 kB = x1_load(kbase + (size_t)MDR_KVIDX(1) * 2 * kTileX1, lane), vB = x1_load(vbase + (size_t)MDR_KVIDX(1) * 2 * kTileX1, lane);
+    f32x16 SA = x1_mma(kA, qx, zero16()), SB;
+    float ci = 1e30f;                           // 6 - m; an empty history overflows the first tile's row sums: it takes the long way
+    auto step = [&](auto last_, const int kt, f32x16& Sc, f32x16& Sn, X1& Kc, const X1& Kn, X1& Vc) {
+        constexpr int KT = decltype(last_)::value;      // kVT - 1 for the last tile (compile-time mask), else 0
+        if (KT != kVT - 1) Sn = x1_mma(Kn, qx, zero16());     // raw scores of tile kt + 1: independent of everything below
+        if (KT == kVT - 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (kap(r) + 4 * h >= kV - 32 * (kVT - 1)) Sc[r] = -1e30f;     // keys 431..447 do not exist
+        }
+        float ps = 0.f;
+        if (__all(ci < 1e29f)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float pe = __builtin_amdgcn_exp2f(Sc[r] + ci); ps += pe; Sc[r] = pe; }
+        } else ps = 1e30f;
+        if (!__all(ps < 32768.0f)) {            // (the raw scores are gone where the fast way ran: back from K)
+            f32x16 R = x1_mma(Kc, qx, zero16());
+            float bm = -1e30f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (KT == kVT - 1 && kap(r) + 4 * h >= kV - 32 * (kVT - 1)) R[r] = -1e30f;
+                bm = fmaxf(bm, R[r]);
+            }
+            bm = fmaxf(bm, xhalf(bm));
+            const float mn = fmaxf(m, bm);
+            const float al = __builtin_amdgcn_exp2f(m - mn);
+            O = O * al;
+            l *= al;
+            m = mn;
+            ci = 6.0f - m;
+            ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { Sc[r] = __builtin_amdgcn_exp2f(R[r] + ci); ps += Sc[r]; }
+        }
+        l += ps;
+        O = x1_mma(Vc, x1_cvt(Sc), O);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < kVT) {                             // tile kt + 2 into the buffers tile kt has just left
+            Kc = x1_load(kbase + (size_t)MDR_KVIDX(kt + 2) * 2 * kTileX1, lane);
+            Vc = x1_load(vbase + (size_t)MDR_KVIDX(kt + 2) * 2 * kTileX1, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int kt = 0; kt < kVT - 2; kt += 2) {
+        step(std::integral_constant<int, 0>(), kt, SA, SB, kA, kB, vA);
+        step(std::integral_constant<int, 0>(), kt + 1, SB, SA, kB, kA, vB);
+    }
+    step(std::integral_constant<int, 0>(), kVT - 2, SA, SB, kA, kB, vA);
+    step(std::integral_constant<int, kVT - 1>(), kVT - 1, SB, SA, kB, kA, vB);
+#else
     X1 kb = x1_load(kbase, lane), vb = x1_load(vbase, lane);
 #pragma unroll 1
     for (int kt = 0; kt < kVT - 2; kt += 2) {
@@ -548,6 +610,7 @@ __device__ __forceinline__ f32x16 self_attention_head_x1(const float* __restrict
         ATTN_TILE_X1(kVT - 2, kb, vb)
         ATTN_TILE_X1(kVT - 1, kn, vn)
     }
+#endif
     l += xhalf(l);
     return O * (((kActScale16 ? 16.0f : 1.0f) / kX2V) / l);
 }
@@ -1033,6 +1096,37 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
         acc2[1][0] = chanvec_lds(VT, VO_FC2B + 32, h);
         acc2[0][1] = zero16();
         acc2[1][1] = zero16();
+        // XA 3 is a latency-bound kernel (waves parked or issue-stalled 64 % of their time, profiles/r05_pmc_config3_B256.txt): its loop is
+        // software-pipelined by one chunk inside the wave -- fc1 of chunk c + 1 is issued BEFORE the bias + GELU + conversion of chunk c, so
+        // the eight dependent MFMAs run under that vector work instead of in front of it, and fc2's two chains are interleaved.
+        if constexpr (XA == 3 && MDR_X1_PIPE) {
+            f32x16 hn = lin2_T(A, y2, zero16());                                        // fc1, chunk 0
+            A = ldw<XA>(w.fc1, 2, 3, lane);
+            MDR_PIN();
+#pragma unroll 1
+            for (int c = 0; c < 8; ++c) {
+                f32x16 hdn = hn;
+                if (c < 7) hn = lin2_T(A, y2, zero16());                               // fc1, chunk c + 1: independent of everything below
+                hdn += chanvec_lds(VT, VO_FC1B + 32 * c, h);
+                if constexpr (kX1GeluTable) gelu_tile_table(hdn, inv, GT); else gelu_tile_scaled(hdn, inv);
+                const X1 hx = mk<XA>(hdn, inv);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c < 6) A = ldw<XA>(w.fc1, 2 * (c + 2), 2 * (c + 2) + 1, lane); else if (c == 6) A = ldw<XA>(w.sa0, 0, 1, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {                                          // fc2: two independent chains, small planes first
+                    acc2[0][0] = GATOR_MFMA_F16(B.t[0].mid[s], hx.p[s], acc2[0][0]);
+                    acc2[1][0] = GATOR_MFMA_F16(B.t[1].mid[s], hx.p[s], acc2[1][0]);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    acc2[0][0] = GATOR_MFMA_F16(B.t[0].hi[s], hx.p[s], acc2[0][0]);
+                    acc2[1][0] = GATOR_MFMA_F16(B.t[1].hi[s], hx.p[s], acc2[1][0]);
+                }
+                if (c < 7) B = ldw<XA>(w.fc2, c + 1, 8 + c + 1, lane); else B = ldw<XA>(w.sa0, 2, 3, lane);
+                MDR_PIN();
+            }
+        } else
 #pragma unroll 1
         for (int c = 0; c < 8; ++c) {           // 256 hidden units in 8 chunks of 32: fc1 -> GELU -> fc2 partial
             f32x16 hdn;
