@@ -13,12 +13,21 @@ namespace {
 // shift, which cancels in the per-axis standardisation that follows it (checked on the demo input to 5e-8):
 // out = (xy - mean) / std over the joints of the sample, population std (np.std).  COCO inputs first get pelvis = (L_Hip+R_Hip)/2
 // and neck = (L_Shoulder+R_Shoulder)/2 appended (joints 11,12 and 5,6).
+// element j of this thread's column of a [n][threads] LDS image
+template <class T> struct ColT {
+    T* base; int tid, stride;
+    __device__ __forceinline__ T& operator[](int j) const { return base[j * stride + tid]; }
+};
+typedef ColT<double> Col;
+typedef ColT<float> ColF;
 __global__ void k_preprocess(const float* __restrict__ in, int B, int jin, int comps, int add_pn, float* __restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int jout = jin + (add_pn ? 2 : 0);
     const float* p = in + (size_t)b * jin * comps;
-    double x[32], y[32];
+    // the joints of a sample as one COLUMN of a [32][blockDim] LDS image (run-time indexed private arrays would live in scratch)
+    __shared__ double xs_[32 * 64], ys_[32 * 64];
+    const Col x{xs_, (int)threadIdx.x, (int)blockDim.x}, y{ys_, (int)threadIdx.x, (int)blockDim.x};
     for (int j = 0; j < jin; ++j) { x[j] = p[j * comps]; y[j] = p[j * comps + 1]; }
     if (add_pn) {
         x[jin] = (x[11] + x[12]) * 0.5;     y[jin] = (y[11] + y[12]) * 0.5;          // pelvis
@@ -223,7 +232,10 @@ __global__ void k_preprocess_chain(const float* __restrict__ in, int B, int jin,
     if (b >= B) return;
     const int J = jin + (add_pn ? 2 : 0);
     const float* p = in + (size_t)b * jin * comps;
-    double x[32], y[32];
+    __shared__ double xs_[32 * 64], ys_[32 * 64];          // one column per thread (48 KB with the float32 images below: 64-thread blocks)
+    __shared__ float fxs_[32 * 64], fys_[32 * 64];
+    const Col x{xs_, (int)threadIdx.x, (int)blockDim.x}, y{ys_, (int)threadIdx.x, (int)blockDim.x};
+    const ColF fxn{fxs_, (int)threadIdx.x, (int)blockDim.x}, fyn{fys_, (int)threadIdx.x, (int)blockDim.x};
     for (int j = 0; j < jin; ++j) { x[j] = p[j * comps]; y[j] = p[j * comps + 1]; }
     if (add_pn) {
         x[jin] = (x[11] + x[12]) * 0.5;     y[jin] = (y[11] + y[12]) * 0.5;
@@ -286,7 +298,6 @@ __global__ void k_preprocess_chain(const float* __restrict__ in, int B, int jin,
             if (u < J && v < J) { const double tx = x[u], ty = y[u]; x[u] = x[v]; y[u] = y[v]; x[v] = tx; y[v] = ty; }
         }
     }
-    float fxn[32], fyn[32];
     for (int j = 0; j < J; ++j) { fxn[j] = (float)x[j] / (float)res_w; fyn[j] = (float)y[j] / (float)res_h; }   // astype(float32); /= [W,H]
     double mx = 0.0, my = 0.0;
     for (int j = 0; j < J; ++j) { mx += fxn[j]; my += fyn[j]; }
@@ -318,7 +329,7 @@ extern "C" int gator_preprocess_pose2d_f32(const float* joints, int32_t batch, i
     if (!joints || !pose2d || batch <= 0 || num_joint_in <= 0 || num_joint_in + (add_pelvis_neck ? 2 : 0) > 32 || comps < 2)
         return fail(GATOR_EINVAL, "gator_preprocess_pose2d_f32: bad arguments");
     if (add_pelvis_neck && num_joint_in < 13) return fail(GATOR_EINVAL, "gator_preprocess_pose2d_f32: pelvis/neck need the COCO joint order (>= 13 joints)");
-    k_preprocess<<<(batch + 127) / 128, 128, 0, (hipStream_t)stream>>>(joints, batch, num_joint_in, comps, add_pelvis_neck, pose2d);
+    k_preprocess<<<(batch + 63) / 64, 64, 0, (hipStream_t)stream>>>(joints, batch, num_joint_in, comps, add_pelvis_neck, pose2d);      // 64-thread blocks: the kernel's LDS images have 64 columns
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;
 }
