@@ -136,3 +136,20 @@ def test_config3_attention_long_way_under_large_logits(gain):
     v2, _ = m(x.cuda())
     vs, _ = m(x[5:9].cuda())
     assert torch.equal(v, v2) and torch.equal(vs, v[5:9])
+
+
+def test_config3_persistent_launch_equals_four_launches_bitwise(monkeypatch):
+    """The 16-bit MDR layers as persistent launches (chunks of <= 384 samples) and as four per-stage launches run the same tile body on the
+    same tiles: bitwise the same vertices, whatever the batch (ragged last chunk, a batch below the persistent threshold)."""
+    monkeypatch.setenv('GATOR_MDR_PERSIST', '1')
+    z, m1 = build_model('coco19_alpha', 'fused')
+    monkeypatch.setenv('GATOR_MDR_PERSIST', '0')
+    z, m0 = build_model('coco19_alpha', 'fused')
+    m1.precision = m0.precision = 'bf16'
+    for B in (7, 300, 801):
+        x = torch.from_numpy(synthetic.synthetic_pose2d(B, 19, seed=B)).cuda()
+        a, b = m1(x), m0(x)
+        assert torch.isfinite(a[0]).all()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), B
+    m1.device_status()
+    m0.device_status()
