@@ -239,6 +239,8 @@ int fused_create(gator_ctx* c, void* stream) {
     // profiles/r05_emulate_16bit.txt).  GATOR_C3_MDR=0 / GATOR_C3_UPSAMPLE_BF16=1 restore round 4's form (bf16 regressor only).
     if (const char* e = getenv("GATOR_C3_MDR")) f->c3_mdr = atoi(e) != 0;
     if (const char* e = getenv("GATOR_C3_UPSAMPLE_BF16")) f->c3_up_bf16 = atoi(e) != 0;
+    if (const char* e = getenv("GATOR_C3_ENCODER")) f->c3_encoder = atoi(e) != 0;
+    if (const char* e = getenv("GATOR_C3_UPSAMPLE_W1")) f->c3_up_w1 = atoi(e) != 0;
     if (f->mdr_x3 != 2) f->c3_mdr = false;
     if (!(f->x3 && f->up_x2)) f->c3_up_bf16 = true;
     if (const char* e = getenv("GATOR_GRAPH")) f->graph_replay = atoi(e) != 0;      // hipGraph replay of repeated forwards (gator_set_graph_replay)
@@ -404,9 +406,9 @@ void fused_destroy(gator_ctx* c) {
     c->fused = nullptr;
 }
 
-int launch_upsample_any(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints) {
+int launch_upsample_any(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints, bool w1) {
     if (!f->x3) return launch_upsample(f, c, B, verts, stream);
-    return f->up_x2 ? launch_upsample_x2(f, c, B, verts, stream, with_joints) : launch_upsample_x3(f, c, B, verts, stream, with_joints);
+    return f->up_x2 ? launch_upsample_x2(f, c, B, verts, stream, with_joints, w1) : launch_upsample_x3(f, c, B, verts, stream, with_joints);
 }
 
 int fused_gat_forward(gator_ctx* c, const float* pose2d, int B, float* x_out, float* feat, void* stream) {
@@ -620,10 +622,11 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
     const bool tiled = n_tiled > 0;
     {   // x_out [B,3J] IS pose3d [B,J,3]: the tail writes the caller's buffer and produces the MDR joint K/V
         StageTimer tm(c, "gat", stream);
-        if (n_tiled > 0) rc = launch_gat_tiled(c, f, pose2d, n_tiled, f->feat, stream, B);
+        const bool enc16 = bf16 && f->c3_encoder && f->gat_x3 && f->gat8 && f->gat8_h4 && f->gat_tiled_h4 && f->g8stream != nullptr;
+        if (n_tiled > 0) rc = launch_gat_tiled(c, f, pose2d, n_tiled, f->feat, stream, B, enc16);
         if (rc == GATOR_OK && n_tiled < B) {
             const size_t o = (size_t)n_tiled * c->J;
-            rc = launch_gat(c, f, pose2d + o * 2, B - n_tiled, pose3d + o * 3, f->feat + o * kC, stream, true, B, n_tiled);
+            rc = launch_gat(c, f, pose2d + o * 2, B - n_tiled, pose3d + o * 3, f->feat + o * kC, stream, true, B, n_tiled, enc16);
         }
     }
     if (rc) return rc;
@@ -649,7 +652,7 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
     }
     if (bf16 && f->c3_up_bf16) return fused_upsample_bf16_in(c, f->vc, B, verts, stream);
     StageTimer tm(c, "upsample", stream);
-    return launch_upsample_any(f, c, B, verts, stream);
+    return launch_upsample_any(f, c, B, verts, stream, false, bf16 && f->c3_up_w1);
 }
 
 // Register a sparse [nj, 6890] joint regressor (COO, host or device pointers are both read through hipMemcpy) for the fused epilogue

@@ -75,6 +75,8 @@ struct FusedState : FusedWs {
     int mdr_wshift = 0;                 // GATOR_MDR_X3=2: wxbuf holds three fp16 planes of 2^mdr_wshift * w
     int mdr_x3 = 2;                     // GATOR_MDR_X3: 0 fp32-input MFMA; 1 exact bf16 x 3 split everywhere; 2 (default) that + the 431x431 attention on two fp16 planes
     bool c3_mdr = true;                 // gator_forward_bf16 (BASELINE config 3): the MDR layers on one fp16 activation plane (GATOR_C3_MDR=0: fp32 form)
+    bool c3_encoder = true;             // ... the encoder's token-wise products on one fp16 activation plane as well (GATOR_C3_ENCODER=0: the fp32 configuration's)
+    bool c3_up_w1 = true;               // ... the vertex regressor's weights on ONE fp16 plane, coarse vertices on two (GATOR_C3_UPSAMPLE_W1=0: weights on two)
     bool c3_up_bf16 = false;            // ... and the vertex regressor on one bf16 plane (GATOR_C3_UPSAMPLE_BF16=1; default: its two fp16 planes)
     bool x3 = true;                     // split-precision vertex regressor (GATOR_UPSAMPLE_X3=0: fp32-input MFMA kernel)
     bool up_x2 = true;                  // ... on two fp16 planes (default; GATOR_UPSAMPLE_X3=1: the exact three bf16 planes)
@@ -130,15 +132,15 @@ int launch_upsample(const FusedState* f, const gator_ctx* c, int B, float* verts
 int gat_prepare_device();
 int gat_ensure_blk_tap(gator_ctx* c, FusedState* f, int B);
 int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue = false,
-               int B_total = 0, int tap_row0 = 0);
+               int B_total = 0, int tap_row0 = 0, bool half16 = false);      // half16: the one-plane form of the two-role kernel (config 3); other forms ignore it
 // gat_roles.hip
 int gat8_prepare_device();
 int gat8_build_stream(FusedState* f, void* stream);
-int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total = 0, int tap_row0 = 0);
+int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total = 0, int tap_row0 = 0, bool half16 = false);
 // gat_tiled.hip
 int gat_tiled_prepare_device();
 int gat_tiled_samples_per_wg(int J);
-int launch_gat_tiled(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total = 0);
+int launch_gat_tiled(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total = 0, bool half16 = false);
 // gat_tail.hip
 size_t gat_tail_part_floats(int B, int J);
 int launch_gat_tail(gator_ctx* c, FusedState* f, const float* pose2d, const float* feat, int B, float* x_out, void* stream, bool joint);
@@ -160,9 +162,9 @@ size_t upsample_x2_vcp_elems(int B);
 int upsample_x2_prepare_device();
 int pack_upsample_x2(const float* up_w, void* dst, float* unscale, void* stream);
 int launch_pack_vc_x2(const float* vc, int B, void* vcp2, void* stream);
-int launch_upsample_x2(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints = false);
+int launch_upsample_x2(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints = false, bool w1 = false);
 // the vertex regressor the ctx was created with (fp32-input MFMA | bf16 x 3 | fp16 x 2)
-int launch_upsample_any(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints = false);
+int launch_upsample_any(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints = false, bool w1 = false);
 // mdr_fused.hip
 int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream, const float* x_out = nullptr, const float* pose2d = nullptr, bool half16 = false);
 

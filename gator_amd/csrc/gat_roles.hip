@@ -432,6 +432,27 @@ __device__ __forceinline__ void tile_mma_refill(H3& w, const X2& b, f32x16& acc,
     }
 #undef GAT8_MM
 }
+// The one-plane form (BASELINE config 3, the 16-bit operand mode: DESIGN.md 4e): activations on their hi plane only, weights on their hi and mid
+// planes -- w_mid a_hi | w_hi a_hi, four MFMAs per tile, and the lo plane of the weight stream (a third of its bytes) is never loaded.
+// Same tile geometry, same stream; a type of its own so that the overloads below pick the form.
+struct H3P2 { f16x8 p[2][2]; };      // [plane hi/mid][k-step]: 16 VGPRs
+template <bool CL>
+__device__ __forceinline__ void tile_mma_refill(H3P2& w, const X2& b, f32x16& acc, f32x16& acs, const float* __restrict__ wp, int lane) {
+    const f16x8* q = reinterpret_cast<const f16x8*>(wp) + lane;
+#define GAT8_MM(wpl, s, AC) AC = CL ? GATOR_MFMA_F16(b.p[0][s], w.p[wpl][s], AC) : GATOR_MFMA_F16(w.p[wpl][s], b.p[0][s], AC)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        GAT8_MM(1, s, acs);                                // w mid * a hi
+        __builtin_amdgcn_sched_barrier(0);
+        w.p[1][s] = q[(1 * 2 + s) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        GAT8_MM(0, s, acc);                                // w hi  * a hi
+        __builtin_amdgcn_sched_barrier(0);
+        w.p[0][s] = q[(0 * 2 + s) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef GAT8_MM
+}
 // one k-step of the two-plane product (x3_common.h: x2_mma does both): lo*hi | hi*lo | hi*hi
 __device__ __forceinline__ f32x16 x2_mma_step(const X2& A, const X2& B, int s, f32x16 acc) {
     acc = GATOR_MFMA_F16(A.p[1][s], B.p[0][s], acc);
@@ -442,6 +463,13 @@ __device__ __forceinline__ f32x16 x2_mma_step(const X2& A, const X2& B, int s, f
 __device__ __forceinline__ void ld_tile(X3& o, const float* p, int lane) { o = x3_load(p, lane); }
 __device__ __forceinline__ void ld_tile(X2& o, const float* p, int lane) { o = x2_load(p, lane); }
 __device__ __forceinline__ void ld_tile(H3& o, const float* p, int lane) { o = h3_load(p, lane); }
+__device__ __forceinline__ void ld_tile(H3P2& o, const float* p, int lane) {
+    const f16x8* q = reinterpret_cast<const f16x8*>(p) + lane;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) o.p[pl][s2] = q[(pl * 2 + s2) * 64];
+}
 template <bool SWZ> __device__ __forceinline__ void ld_opnd(X3& o, const float* p, int lane) { o = x3_load(p, lane); }
 template <bool SWZ> __device__ __forceinline__ void ld_opnd(X2& o, const float* p, int lane) { o = SWZ ? x2_load_swz(p, lane) : x2_load(p, lane); }
 
@@ -464,7 +492,7 @@ __device__ __forceinline__ void unit4(WT (&W)[kNT], const float* __restrict__& w
         wp += kTileX3;
         b = bn;
     }
-    if constexpr (std::is_same<WT, H3>::value) acc = acc + acs;
+    if constexpr (!std::is_same<WT, X3>::value) acc = acc + acs;
     store_block(raw, lane, acc);
 }
 // one tile: partial hop-2 linear (linears[1], 128 -> 16) over k block `w` of SB; C-layout
@@ -475,7 +503,7 @@ __device__ __forceinline__ void unit1(WT (&W)[kNT], const float* __restrict__& w
     ld_tile(b, o0, lane);
     tile_mma_refill<true>(W[S0 % kNT], b, acc, acs, wp, lane);
     wp += kTileX3;
-    if constexpr (std::is_same<WT, H3>::value) acc = acc + acs;
+    if constexpr (!std::is_same<WT, X3>::value) acc = acc + acs;
     store_block(raw, lane, acc);
 }
 
@@ -490,9 +518,10 @@ __device__ __forceinline__ void skip_pad(WT (&W)[kNT], const float* __restrict__
 }
 
 // H4: the token-wise products on four partial products (weights H3, operands X2; raw tiles carry 1 / a.lin_inv) instead of six
-template <bool H4, int LR>
+template <bool H4, int LR, bool H2 = false>
 __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
-    typedef typename std::conditional<H4, H3, X3>::type WT;
+    static_assert(H4 || !H2, "the one-plane form is a variant of the four-product form");
+    typedef typename std::conditional<H2, H3P2, typename std::conditional<H4, H3, X3>::type>::type WT;
     typedef typename std::conditional<H4, X2, X3>::type OT;
     const float inv = H4 ? a.lin_inv : 1.0f;
     // operand tile of a true-scale register tile; pick-up of a raw product tile with what is added to it
@@ -1024,6 +1053,8 @@ int gat8_prepare_device() {
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     return GATOR_OK;
 }
 
@@ -1078,7 +1109,8 @@ int gat8_build_stream(FusedState* f, void* stream) {
 }
 
 // feat only (the lifter and the MDR joint tokens are the batched launches of gat_tail.hip)
-int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total, int tap_row0) {
+int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total, int tap_row0, bool half16) {
+    if (half16 && !f->gat8_h4) return fail(GATOR_EUNSUPPORTED, "the 16-bit encoder needs the four-product weight stream (GATOR_GAT8_H4=1, the default)");
     Gat8Args a;
     const Weights& w = c->w;
     a.B = B; a.J = c->J; a.pose2d = pose2d;
@@ -1117,6 +1149,8 @@ int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* 
     a.lin_inv = std::ldexp(1.0f, -(4 + f->gat8_wshift));
     // token rows that exist sit in registers r < LR of a row-over-token tile: token t <-> r = (t & 3) + 4 (t >> 3), so J <= 18 / 20 -> 10 / 12
     if (!f->gat8_h4) k_gat8<false, 16><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else if (half16 && c->J <= 18) k_gat8<true, 10, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else if (half16 && c->J <= 20) k_gat8<true, 12, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else if (c->J <= 18) k_gat8<true, 10><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else if (c->J <= 20) k_gat8<true, 12><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else return fail(GATOR_EUNSUPPORTED, "k_gat8: more than 20 joints (gator_create admits 17 and 19)");

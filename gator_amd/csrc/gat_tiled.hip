@@ -178,6 +178,7 @@ __device__ __forceinline__ void glds16(const float* gsrc, const float* lds_dst) 
 // (unfenced, hipcc hoists all of a group's LDS reads to its top: 5 x 24 registers on top of the 300 the state needs -> scratch).
 __device__ __forceinline__ void ld_wtile(X3& o, const float* p, int lane) { o = x3_load(p, lane); }
 __device__ __forceinline__ void ld_wtile(H3& o, const float* p, int lane) { o = h3_load(p, lane); }
+__device__ __forceinline__ void ld_wtile(G2& o, const float* p, int lane) { o = g2_load(p, lane); }      // the hi and mid planes of an H3 tile
 template <int N, class WT, class F>
 __device__ __forceinline__ void for_tiles(const float* slot, int lane, F&& f) {
     WT cur;
@@ -225,16 +226,20 @@ __device__ __forceinline__ int group_tiles(const TiledBlk& w, int g, const float
 // H4: token-wise products on four partial products (weights H3 in the ring, operands X2 in registers): every accumulator of such a
 // product - and every exchange image, bias and aggregate made from one - carries the factor a.lin_s; the residual stream, the
 // LayerNorms and the GELU's result do not.
-template <int J, bool H4>
+// H2 (with H4; BASELINE config 3, the 16-bit operand mode: DESIGN.md 4e): activations as ONE fp16 plane, weights as the hi and mid planes
+// of the same ring tiles (the lo plane is not even copied): two MFMAs per k-step instead of four; the J x J operators stay fp32 on the VALU.
+template <int J, bool H4, bool H2 = false>
 __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
-    typedef typename std::conditional<H4, H3, X3>::type WT;
-    typedef typename std::conditional<H4, X2, X3>::type OT;
+    static_assert(H4 || !H2, "the one-plane form shares the four-product form's scales");
+    typedef typename std::conditional<H2, G2, typename std::conditional<H4, H3, X3>::type>::type WT;
+    typedef typename std::conditional<H2, X1, typename std::conditional<H4, X2, X3>::type>::type OT;
+    constexpr int NP = H2 ? 4 : 6;                          // 1 KiB pieces of a ring tile that are copied
     const float inv = H4 ? a.lin_inv : 1.0f;
     auto sp = [&](const f32x16& v, float pre) -> OT {       // operand form of a register tile that holds 1 / pre x its value
-        if constexpr (H4) return x2_split(v * (16.0f * pre)); else return x3_split(v);
+        if constexpr (H2) return x1_cvt(v * (16.0f * pre)); else if constexpr (H4) return x2_split(v * (16.0f * pre)); else return x3_split(v);
     };
     auto mm = [&](const WT& wt, const OT& x, const f32x16& acc) -> f32x16 {
-        if constexpr (H4) return h3_mma_wa(wt, x, acc); else return x3_mma(wt, x, acc);
+        if constexpr (H2) return g2_mma_wa(wt, x, acc); else if constexpr (H4) return h3_mma_wa(wt, x, acc); else return x3_mma(wt, x, acc);
     };
     // the block's vector table: biases that start an accumulator carry lin_s
     auto stage_vecs = [&](const float* vecs, float* Vd, int tid_) {
@@ -274,12 +279,12 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
 #pragma unroll
             for (int p0 = 0; p0 < 2; ++p0) {
                 const int p = ((wave - 2 * i) & 3) + 4 * p0;
-                if (p < 6) glds16(tl[i] + p * 256 + lane * 4, slot + (i * 6 + p) * 256);
+                if (p < NP) glds16(tl[i] + p * 256 + lane * 4, slot + (i * 6 + p) * 256);
             }
     };
     auto begin_group = [&]() -> const float* {      // -> ring slot holding the group that begins now
         // vmcnt retires in order: all but this wave's 6 youngest copies (group gk+1) done  =>  its pieces of group gk have landed
-        if (gk + 1 < kDepth * kGroupsPerBlock) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (gk + 1 < kDepth * kGroupsPerBlock) { if constexpr (NP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                            // ... and so have everybody's; slot (gk+2) % 3 (group gk-1) is free
         issue(gk + 2);
@@ -587,11 +592,14 @@ int gat_tiled_prepare_device() {
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat_tiled<19, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat_tiled<17, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat_tiled<19, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat_tiled<17, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat_tiled<19, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
     return GATOR_OK;
 }
 
 // pose2d [B,J,2] -> feat [B,J,128]; requires the split-precision weight images (FusedState::gxbuf)
-int launch_gat_tiled(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total) {
+int launch_gat_tiled(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total, bool half16) {
+    if (half16 && !f->gat_tiled_h4) return fail(GATOR_EUNSUPPORTED, "the 16-bit encoder needs the four-product weight image (GATOR_GAT_TILED_H4=1, the default)");
     if (!f->gat_x3) return fail(GATOR_EUNSUPPORTED, "the sample-tiled GAT kernel needs the split-precision weights (GATOR_GAT_X3=1)");
     const Weights& w = c->w;
     TiledArgs a;
@@ -621,7 +629,10 @@ int launch_gat_tiled(gator_ctx* c, FusedState* f, const float* pose2d, int B, fl
     const size_t ldsb = kTiledLdsFloats * sizeof(float);
     a.lin_s = f->gat_tiled_h4 ? std::ldexp(16.0f, f->gat_tiled_wshift) : 1.0f;
     a.lin_inv = 1.0f / a.lin_s;
-    if (f->gat_tiled_h4) {
+    if (half16) {
+        if (c->J == 17) k_gat_tiled<17, true, true><<<nwg, 256, ldsb, (hipStream_t)stream>>>(a);
+        else k_gat_tiled<19, true, true><<<nwg, 256, ldsb, (hipStream_t)stream>>>(a);
+    } else if (f->gat_tiled_h4) {
         if (c->J == 17) k_gat_tiled<17, true><<<nwg, 256, ldsb, (hipStream_t)stream>>>(a);
         else k_gat_tiled<19, true><<<nwg, 256, ldsb, (hipStream_t)stream>>>(a);
     } else {

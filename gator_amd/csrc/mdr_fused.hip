@@ -460,31 +460,6 @@ __device__ __forceinline__ f32x16 self_attention_head_x2_pipe(const float* __res
 // product in the attention cores (against 6) and 4 per token-wise product (weights on their two leading fp16 planes, 22 bits: against
 // 8); accumulation, softmax, norms, GELU and the residual stream stay fp32.  What that costs in accuracy is the activation rounding
 // (2^-12 relative per operand element): tools/emulate_16bit.py, profiles/r05_emulate_16bit.txt (sub-millimetre vertices).
-struct X1 { f16x8 p[2]; };          // [k-step]: 8 VGPRs
-__device__ __forceinline__ X1 x1_cvt(const f32x16& v) {
-    X1 o;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.p[s][j] = (_Float16)v[8 * s + j];
-    return o;
-}
-__device__ __forceinline__ X1 x1_load(const float* __restrict__ tile, int lane) {      // also: the hi plane of an X2 tile
-    const f16x8* q = reinterpret_cast<const f16x8*>(tile) + lane;
-    X1 o;
-    o.p[0] = q[0];
-    o.p[1] = q[64];
-    return o;
-}
-__device__ __forceinline__ void x1_store(float* __restrict__ tile, int lane, const X1& v) {
-    f16x8* q = reinterpret_cast<f16x8*>(tile) + lane;
-    q[0] = v.p[0];
-    q[64] = v.p[1];
-}
-__device__ __forceinline__ f32x16 x1_mma(const X1& A, const X1& B, f32x16 acc) {
-    acc = GATOR_MFMA_F16(A.p[0], B.p[0], acc);
-    return GATOR_MFMA_F16(A.p[1], B.p[1], acc);
-}
 constexpr int kTileX1 = kTile / 2;
 // One key tile.  The VALU work per tile is what bounds this form (4 MFMAs against ~50 vector instructions), so the softmax is cut to
 // exp2 + row sum + one conversion per pair:
@@ -760,26 +735,12 @@ __device__ __forceinline__ f32x16 lin2_C(const W2H& w, const X2 (&x)[2]) {
 }
 
 // XA == 3: weights as the two leading fp16 planes (hi, mid: 22 bits) of two H3 tiles (32 VGPRs), activations as X1
-struct G2 { f16x8 hi[2], mid[2]; };      // [k-step]
 struct W2G { G2 t[2]; };
-__device__ __forceinline__ G2 g2_load(const float* __restrict__ tile, int lane) {
-    const f16x8* q = reinterpret_cast<const f16x8*>(tile) + lane;
-    G2 o;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) { o.hi[s] = q[s * 64]; o.mid[s] = q[(2 + s) * 64]; }
-    return o;
-}
 __device__ __forceinline__ W2G ldw2g(const float* __restrict__ Wx, int i0, int i1, int lane) {
     W2G w;
     w.t[0] = g2_load(Wx + (size_t)i0 * kTileX3, lane);
     w.t[1] = g2_load(Wx + (size_t)i1 * kTileX3, lane);
     return w;
-}
-__device__ __forceinline__ f32x16 g2_mma_wa(const G2& W, const X1& a, f32x16 acc) {      // acc += W . a, the small plane first
-    acc = GATOR_MFMA_F16(W.mid[0], a.p[0], acc);
-    acc = GATOR_MFMA_F16(W.mid[1], a.p[1], acc);
-    acc = GATOR_MFMA_F16(W.hi[0], a.p[0], acc);
-    return GATOR_MFMA_F16(W.hi[1], a.p[1], acc);
 }
 __device__ __forceinline__ f32x16 lin2_T(const W2G& w, const X1 (&x)[2], f32x16 init) {
 #pragma unroll

@@ -106,6 +106,9 @@ struct JregEpi2 {
     int nnz;
 };
 
+// WLO = false (BASELINE config 3, the 16-bit operand mode): the weights' lo plane is not used -- weights on ONE fp16 plane, coarse vertices on two:
+// two MFMAs per product instead of three (0.35 mm max / 0.06 mm rms by the emulation: profiles/r05_emulate_16bit.txt)
+template <bool WLO = true>
 __global__ __launch_bounds__(512, 1) void k_upsample_x2(const _Float16* __restrict__ ap, const _Float16* __restrict__ wp,
                                                         const float* __restrict__ bias, const float* __restrict__ tpl,
                                                         float* __restrict__ out, int B, int MT, int MG, int nwg, float unscale,
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void k_upsample_x2(const _Float16* __restri
                     const int l = lp + 1 - k;
                     if (l < 0 || l > 2) continue;
                     big[l] = GATOR_MFMA_F16(a[lp][0], w[k][0], big[l]);      // hi*hi
-                    sm[l] = GATOR_MFMA_F16(a[lp][0], w[k][1], sm[l]);        // hi*lo
+                    if constexpr (WLO) sm[l] = GATOR_MFMA_F16(a[lp][0], w[k][1], sm[l]);        // hi*lo
                     sm[l] = GATOR_MFMA_F16(a[lp][1], w[k][0], sm[l]);        // lo*hi
                 }
             // every 7 k-steps the hi*hi chain moves into a running total and restarts from zero: its partial sums stay small, only
@@ -232,7 +235,8 @@ size_t upsample_x2_weight_elems() { return (size_t)(kOB / 2) * kS16 * 12 * 512; 
 size_t upsample_x2_vcp_elems(int B) { return (size_t)((B + 127) / 128) * kS16 * 24 * 512; }           // fp16 elements
 
 int upsample_x2_prepare_device() {
-    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_upsample_x2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX2Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_upsample_x2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX2Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_upsample_x2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX2Lds));
     return GATOR_OK;
 }
 
@@ -274,13 +278,15 @@ int launch_pack_vc_x2(const float* vc, int B, void* vcp2, void* stream) {
 }
 
 // verts == nullptr: vertices are not stored (joint regression only); with_joints: also fill f->jr_P for launch_jreg_reduce
-int launch_upsample_x2(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints) {
+int launch_upsample_x2(const FusedState* f, const gator_ctx* c, int B, float* verts, void* stream, bool with_joints, bool w1) {
     const int MT = (B + 31) / 32, MG = (MT + 3) / 4;
     JregEpi2 jr{};
     if (with_joints) { jr.blk = (const int2*)f->jr_blk; jr.ent = (const int2*)f->jr_ent; jr.w = f->jr_w; jr.P = f->jr_P; jr.nnz = f->jr_nnz; }
     const int nwg = (kOB / 2) * MG;
-    k_upsample_x2<<<nwg, 512, kX2Lds, (hipStream_t)stream>>>((const _Float16*)f->vcp3, (const _Float16*)f->up_w2, c->w.up_b, c->w.v6890,
-                                                            verts, B, MT, MG, nwg, f->up_w2_unscale, jr);
+    if (w1) k_upsample_x2<false><<<nwg, 512, kX2Lds, (hipStream_t)stream>>>((const _Float16*)f->vcp3, (const _Float16*)f->up_w2, c->w.up_b, c->w.v6890,
+                                                                           verts, B, MT, MG, nwg, f->up_w2_unscale, jr);
+    else k_upsample_x2<true><<<nwg, 512, kX2Lds, (hipStream_t)stream>>>((const _Float16*)f->vcp3, (const _Float16*)f->up_w2, c->w.up_b, c->w.v6890,
+                                                                       verts, B, MT, MG, nwg, f->up_w2_unscale, jr);
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;
 }

@@ -189,6 +189,50 @@ __device__ __forceinline__ f32x16 h3_mma_aw_main(const X2& a, const H3& W, f32x1
 }
 __device__ __forceinline__ f32x16 h3_mma_aw(const X2& a, const H3& W, f32x16 acc) { return h3_mma_aw_main(a, W, h3_mma_aw_small(a, W, acc)); }
 
+
+// ---- ONE fp16 plane ("X1"; BASELINE config 3, the 16-bit operand mode: DESIGN.md 4e) -------------------------------------------------
+// Activations (and the attention operands of the MDR layers) as one fp16 plane of 16 x value: no split, 2 KiB tiles; weights as the two
+// leading planes (hi, mid: 22 bits) of the same H3 tiles the fp32 configuration packs ("G2") -- two MFMAs per k-step instead of four.
+struct X1 { f16x8 p[2]; };          // [k-step]: 8 VGPRs
+__device__ __forceinline__ X1 x1_cvt(const f32x16& v) {
+    X1 o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.p[s][j] = (_Float16)v[8 * s + j];
+    return o;
+}
+__device__ __forceinline__ X1 x1_load(const float* __restrict__ tile, int lane) {      // also: the hi plane of an X2 tile
+    const f16x8* q = reinterpret_cast<const f16x8*>(tile) + lane;
+    X1 o;
+    o.p[0] = q[0];
+    o.p[1] = q[64];
+    return o;
+}
+__device__ __forceinline__ void x1_store(float* __restrict__ tile, int lane, const X1& v) {
+    f16x8* q = reinterpret_cast<f16x8*>(tile) + lane;
+    q[0] = v.p[0];
+    q[64] = v.p[1];
+}
+__device__ __forceinline__ f32x16 x1_mma(const X1& A, const X1& B, f32x16 acc) {
+    acc = GATOR_MFMA_F16(A.p[0], B.p[0], acc);
+    return GATOR_MFMA_F16(A.p[1], B.p[1], acc);
+}
+struct G2 { f16x8 hi[2], mid[2]; };      // [k-step]
+__device__ __forceinline__ G2 g2_load(const float* __restrict__ tile, int lane) {
+    const f16x8* q = reinterpret_cast<const f16x8*>(tile) + lane;
+    G2 o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { o.hi[s] = q[s * 64]; o.mid[s] = q[(2 + s) * 64]; }
+    return o;
+}
+__device__ __forceinline__ f32x16 g2_mma_wa(const G2& W, const X1& a, f32x16 acc) {      // acc += W . a, the small plane first
+    acc = GATOR_MFMA_F16(W.mid[0], a.p[0], acc);
+    acc = GATOR_MFMA_F16(W.mid[1], a.p[1], acc);
+    acc = GATOR_MFMA_F16(W.hi[0], a.p[0], acc);
+    return GATOR_MFMA_F16(W.hi[1], a.p[1], acc);
+}
+
 // fused_pack.hip: fp32 packed tiles [g][lane][4] -> X3 tiles, same tile indices
 int fused_repack_x3(const float* src_tiles, float* dst_tiles, int64_t ntiles, void* stream);
 // ... -> H3 tiles (three fp16 planes of 2^shift * w); *shift is chosen from max|w| over the tiles with (tile % period) < live (the

@@ -30,7 +30,7 @@ def test_bf16_forward_mpjpe_parity(name, B):
     print('\n[%s bf16 B=%d] vertex err vs fp64: max %.3f mm  rms %.3f mm ; fp32 path max %.2e mm'
           % (name, B, err.max(), np.sqrt((err ** 2).mean()), np.abs(v32.cpu().numpy() - ref.numpy()).max() * 1e3))
     assert err.max() < 1.0 and np.sqrt((err ** 2).mean()) < 0.2      # one fp16 activation plane in the MDR layers: 2^-12 relative per operand element
-    assert np.abs(pose3d.cpu().numpy() - rp.numpy()).max() <= 1e-3          # GAT stays fp32
+    assert np.abs(pose3d.cpu().numpy() - rp.numpy()).max() <= 1.0           # pose3d in mm: the encoder's linears run on one activation plane too
     jr = synthetic.load_j_regressors()['h36m']
     reg = geval.JointRegressor(jr, 'cuda')
     j_bf = reg(verts * 1000).cpu().numpy()
@@ -73,7 +73,7 @@ def test_config3_2048_samples_every_coordinate():
     assert torch.equal(v, v2)
     m.precision = 'f32'
     vf, pf = m(x.cuda())
-    assert torch.equal(p, pf)                                       # the encoder is untouched by the mode
+    assert float((p - pf).abs().max()) <= 1.0                       # pose3d (mm) of the 16-bit encoder against the fp32 path's
     m.device_status()
     jr = synthetic.load_j_regressors()['h36m']
     worst, sq, n, jd = 0.0, 0.0, 0, []
