@@ -177,6 +177,8 @@ STAGE_PRODUCTS = {'mdr_layer0': [(_CA, 3), (48.7 - _CA, 4)],
 # product, token-wise linears two (weights on two planes) -- encoder and vertex regressor as in the fp32 configuration
 STAGE_PRODUCTS_C3 = {'mdr_layer0': [(_CA, 1), (48.7 - _CA, 2)], 'mdr_layer': [(_SA + _CA, 1), (99.2 - _SA - _CA, 2)],
                      'mdr_attn_head': [(_SA, 1), (51.4 - _SA, 2)], 'mdr_layers': [(3 * _SA + 3 * _CA, 1), (298.5 - 3 * _SA - 3 * _CA, 2)]}
+STAGE_PRODUCTS_C3['upsample'] = [(53.45, 2)]                                   # weights one plane, coarse vertices two
+STAGE_PRODUCTS_C3['gat'] = [(54.4, 2), (0.89, 3), (0.50, 2), (56.66 - 54.4 - 0.89 - 0.50, 16)]      # k_gat8's token-wise linears on two products
 PEAK_X2_TFLOPS = round(PEAK_BF16_TFLOPS / 3, 1)
 
 
@@ -496,7 +498,7 @@ def main():
             roof = {'bound': 'mfma', 'kernel': 'whole forward', 'achieved': round(per_gpu_tf, 2), 'peak': PEAK_F32_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(per_gpu_tf / PEAK_F32_TFLOPS, 4), 'traffic': None}
         jset = {17: 'Human3.6M 17-joint', 19: 'COCO 19-joint'}.get(J, '%d-joint' % J)
-        prec = 'fp32' if a.precision == 'f32' else '16-bit operand mode (MDR layers on one fp16 activation plane; encoder and vertex regressor on two)'
+        prec = 'fp32' if a.precision == 'f32' else '16-bit operand mode (activations of the encoder and MDR layers on one fp16 plane, weights on two; vertex regressor weights on one)'
         tail = ''
         if world > 1:
             tail = (', RCCL all-gather of [%d,6890,3] vertices' % (B * world)) if a.mode == 'gather' else \
@@ -509,9 +511,9 @@ def main():
                 # build with no rounded operand is the `exact_split` entry of `variants`; parity of both: tests/test_gpu_x3.py.
                 'arithmetic': ('fp32 values, split-precision 16-bit MFMA products: weights exact (3 planes), activations / attention / vertex-regressor operands rounded to 22 bits (2 planes); measured error of this run: `parity`'
                                if a.precision == 'f32' else
-                               'gator_forward_bf16 (BASELINE config 3): fp32 in / out / accumulate / softmax / norms / GELU / residual stream; the three MDR layers and the head features take their '
-                               'activations, Q, K, V and probabilities as ONE fp16 plane (weights on two), the encoder and the vertex regressor keep two-plane operands (one plane there costs '
-                               'millimetres: profiles/r05_emulate_16bit.txt); measured error of this run: `parity` (bar: 1 mm max, 0.2 mm rms)'),
+                               'gator_forward_bf16 (BASELINE config 3): fp32 in / out / accumulate / softmax / norms / GELU / residual stream; the token-wise linears of the encoder and of the three MDR layers take their '
+                               'activations - and the MDR attention cores their Q, K, V and probabilities - as ONE fp16 plane (weights on two); the vertex regressor takes its weights as one plane and the coarse '
+                               'vertices as two; head features, J x J attention of the encoder, lifter and tokenisers keep two planes / fp32 (profiles/r05_emulate_16bit.txt); measured error of this run: `parity` (bar: 1 mm max, 0.2 mm rms)'),
                 'config': {'workload': 'B=%d synthetic %s poses per GPU, GAT+MDR forward %s%s' % (B, jset, prec, tail),
                            'baseline_config': baseline_config_of(a, world),
                            'batch_per_gpu': B, 'global_batch': B * world, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world,
@@ -545,7 +547,9 @@ def main():
             if a.precision != 'f32':      # config 3: what the 16-bit mode buys -- the fp32 build at the same shape, same box, same process
                 vlist = (vlist[0],
                          ('fp32 build at this shape (gator_forward_f32)', {'_precision': 'f32'}),
-                         ('round 4 form of config 3: bf16 vertex regressor only (GATOR_C3_MDR=0 GATOR_C3_UPSAMPLE_BF16=1)', {'GATOR_C3_MDR': '0', 'GATOR_C3_UPSAMPLE_BF16': '1'}),
+                         ('16-bit MDR layers only (GATOR_C3_ENCODER=0 GATOR_C3_UPSAMPLE_W1=0)', {'GATOR_C3_ENCODER': '0', 'GATOR_C3_UPSAMPLE_W1': '0'}),
+                         ('round 4 form of config 3: bf16 vertex regressor only (GATOR_C3_MDR=0 GATOR_C3_ENCODER=0 GATOR_C3_UPSAMPLE_BF16=1)',
+                          {'GATOR_C3_MDR': '0', 'GATOR_C3_ENCODER': '0', 'GATOR_C3_UPSAMPLE_BF16': '1'}),
                          ('four MDR launches instead of the persistent one (GATOR_MDR_PERSIST=0)', {'GATOR_MDR_PERSIST': '0'}))
             for vname, env in vlist:
                 env = dict(env)

@@ -45,11 +45,12 @@ class Policy:
     up_a / up_w     the vertex regressor (upsample_conv): coarse vertices / weights
     """
     KEYS = ('lin_a', 'lin_w', 'qk', 'pv_p', 'pv_v', 'adj', 'head', 'up_a', 'up_w',
-            'gat_a', 'mdr_a', 'hd_a', 'mlp_a')     # optional overrides of lin_a by site: encoder / MDR layers / head + lifter + tokenisers / MLP hidden (fc2 input)
+            'gat_a', 'mdr_a', 'hd_a', 'mlp_a',     # optional overrides of lin_a by site: encoder / MDR layers / head + lifter + tokenisers / MLP hidden (fc2 input)
+            'gat_core')                             # optional override of qk / pv_p / pv_v for the encoder's J x J attention (head dim 16)
 
     def __init__(self, name, **kw):
         self.name = name
-        self.b = {k: kw.get(k, 'x' if k in ('gat_a', 'mdr_a', 'hd_a', 'mlp_a') else None) for k in self.KEYS}
+        self.b = {k: kw.get(k, 'x' if k in ('gat_a', 'mdr_a', 'hd_a', 'mlp_a', 'gat_core') else None) for k in self.KEYS}
 
 
 class Emu(TorchFunctionMode):
@@ -79,9 +80,10 @@ class Emu(TorchFunctionMode):
         if func in (torch.matmul, torch.Tensor.matmul, torch.Tensor.__matmul__, torch.bmm, torch.Tensor.bmm):
             a, b = args[0], args[1]
             if a.dim() == 4 and b.dim() == 4:                 # attention cores [B,H,N,d] @ [B,H,d,M] / [B,H,N,M] @ [B,H,M,d]
+                gat = a.shape[1] == 8 and p.get('gat_core', 'x') != 'x'      # the encoder has 8 heads, the MDR layers 2
                 if a.shape[-1] in (16, 32) and b.shape[-2] == a.shape[-1] and b.shape[-1] != a.shape[-1]:
-                    return func(rnd(a, p['qk']), rnd(b, p['qk']))
-                return func(rnd(a, p['pv_p']), rnd(b, p['pv_v']))
+                    return func(rnd(a, p['gat_core'] if gat else p['qk']), rnd(b, p['gat_core'] if gat else p['qk']))
+                return func(rnd(a, p['gat_core'] if gat else p['pv_p']), rnd(b, p['gat_core'] if gat else p['pv_v']))
             if a.dim() == 3 and b.dim() == 3 and a.shape[-1] == 20:      # head: softmax(mat_A) @ mat_B
                 return func(rnd(a, p['head']), rnd(b, p['head']))
             if a.dim() <= 3 and a.shape[-1] == a.shape[-2] and a.shape[-1] in (17, 19):   # adjacency / hop masks [J,J] @ [B,J,C]
@@ -101,7 +103,7 @@ class Emu(TorchFunctionMode):
 
 def policies():
     F16, BF, X2 = 11, 8, 22
-    allk = lambda b: {k: b for k in Policy.KEYS if not k.endswith('_a') or k in ('lin_a', 'up_a')}
+    allk = lambda b: {k: b for k in Policy.KEYS if (not k.endswith('_a') or k in ('lin_a', 'up_a')) and k != 'gat_core'}
     P = [
         Policy('shipped fp32 config: every operand 22 bits (weights of linears exact)', **dict(allk(X2), lin_w=None)),
         Policy('ALL operands one fp16 plane (11 bits)', **allk(F16)),
@@ -131,6 +133,9 @@ def policies():
         Policy('C3f: only MLP hidden fp16 + cores fp16, rest 22', **dict(allk(X2), mlp_a=F16, qk=F16, pv_p=F16, pv_v=F16)),
         Policy('C3g: = C3a + regressor weights fp16 (a 22)', **dict(allk(X2), lin_a=F16, qk=F16, pv_p=F16, pv_v=F16, up_w=F16)),
         Policy('C3h: = C3a with bf16 instead of fp16', **dict(allk(X2), lin_a=BF, qk=BF, pv_p=BF, pv_v=BF)),
+        # what round 5 ships as gator_forward_bf16: encoder and MDR-layer linears on one activation plane, MDR attention cores on one plane, head
+        # features / lifter / tokenisers and the encoder's J x J attention on two (or exact), weights 22 bits, regressor: weights one plane, coarse vertices two
+        Policy('C3 shipped: linears (encoder + MDR) acts fp16, MDR cores fp16, head 22, regressor w fp16 | a 22', **dict(allk(X2), lin_a=F16, hd_a=X2, qk=F16, pv_p=F16, pv_v=F16, gat_core=X2, up_w=F16)),
     ]
     return P
 
