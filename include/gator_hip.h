@@ -101,15 +101,20 @@ int gator_device_status(gator_ctx* ctx, int32_t sync);
  * (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 GATOR_GAT_TILED_H4=0) or the fp32-input MFMA (=0). */
 int gator_forward_f32(gator_ctx* ctx, const float* pose2d, int32_t batch, float* verts, float* pose3d, void* stream);
 
-/* BASELINE config 3 ("full GATOR forward bf16"): the same forward in 16-bit operand mode.  Round 5: the three MDR layers
- * (lib/models/MDR.py:140-153, vanilla_transformer_encoder.py:82-94) take their activations, Q, K, V and probabilities as ONE fp16 plane
- * (weights on two planes; fp32 accumulate / softmax / norms / GELU / residual stream / output); the encoder, the head features and the
- * vertex regressor keep gator_forward_f32's two-plane operands, because a single 16-bit plane THERE is what costs millimetres
- * (tools/emulate_16bit.py).  Against the fp64 evaluation of the reference: 0.42 mm max, 0.07 mm rms, |delta MPJPE| < 1e-3 mm over 2048
- * samples (tests/test_gpu_bf16.py; bar 1 mm / 0.2 mm / 0.05 mm); 1.35 - 1.42 x the fp32 forward at B = 2048.  pose3d is bit for bit
- * gator_forward_f32's.  Needs the default operand forms (GATOR_MDR_X3=2, GATOR_UPSAMPLE_X3=2).  GATOR_C3_MDR=0 GATOR_C3_UPSAMPLE_BF16=1
- * (read at gator_create) restore round 4's form: fp32 MDR layers + vertex regressor on one bf16 plane (8 mm max / 1 mm rms).
- * gator_upsample_bf16: the stage entry point of that bf16 vertex regressor (upsample_conv, MDR.py:122,167-168). */
+/* BASELINE config 3 ("full GATOR forward bf16"): the same forward in 16-bit operand mode (round 5).  Activations travel as ONE fp16 plane
+ * into every token-wise linear of the encoder (lib/models/GAT.py:33-43, backbones/modules.py:121-196) and of the three MDR layers
+ * (lib/models/MDR.py:140-153, vanilla_transformer_encoder.py:82-94), whose attention cores take Q, K, V and the probabilities as one plane
+ * too; weights stay on two planes (22 bits) - except upsample_conv's (MDR.py:122,167-168), which go on one while the coarse vertices stay on
+ * two.  fp32 accumulate / softmax / norms / GELU / residual stream / output; the head features, the encoder's J x J operators, the lifter
+ * and the tokenisers keep gator_forward_f32's operands.  Which operand may be one plane was decided with the fp64 oracle under operand
+ * rounding (tools/emulate_16bit.py): a single 16-bit plane for the WEIGHTS of the linears, or bf16 anywhere, is what costs millimetres.
+ * Against the fp64 evaluation of the reference over 2048 samples x every coordinate: 0.76 mm max, 0.10 mm rms, |delta MPJPE| < 1e-3 mm
+ * (tests/test_gpu_bf16.py; bar 1 mm / 0.2 mm / 0.05 mm); 1.6 x the fp32 forward at B = 2048.  Not for weights that drive the attention
+ * logits to hundreds (near one-hot softmaxes): there one plane moves a score by 2^-12 of its magnitude.  Needs the default operand forms
+ * (GATOR_MDR_X3=2, GATOR_UPSAMPLE_X3=2, GATOR_GAT8_H4=1, GATOR_GAT_TILED_H4=1).  Read at gator_create: GATOR_C3_ENCODER=0 (encoder as in
+ * gator_forward_f32), GATOR_C3_UPSAMPLE_W1=0 (regressor weights on two planes), GATOR_C3_MDR=0 (MDR layers as in gator_forward_f32),
+ * GATOR_C3_UPSAMPLE_BF16=1 (round 4's form of the regressor: both operands one bf16 plane, 8 mm max / 1 mm rms).
+ * gator_upsample_bf16: the stage entry point of that bf16 vertex regressor. */
 int gator_forward_bf16(gator_ctx* ctx, const float* pose2d, int32_t batch, float* verts, float* pose3d, void* stream);
 int gator_upsample_bf16(gator_ctx* ctx, const float* vert431, int32_t batch, float* verts, void* stream);
 
