@@ -395,6 +395,7 @@ void fused_destroy(gator_ctx* c) {
     if (c->fused->gxbuf) (void)hipFree(c->fused->gxbuf);
     if (c->fused->gxbuf_h3) (void)hipFree(c->fused->gxbuf_h3);
     if (c->fused->g8stream) (void)hipFree(c->fused->g8stream);
+    if (c->fused->g8stream_b) (void)hipFree(c->fused->g8stream_b);
     if (c->fused->wxbuf) (void)hipFree(c->fused->wxbuf);
     if (c->fused->up_w16) (void)hipFree(c->fused->up_w16);
     if (c->fused->blk_tap) (void)hipFree(c->fused->blk_tap);

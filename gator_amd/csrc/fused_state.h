@@ -67,6 +67,8 @@ struct FusedState : FusedWs {
     float* g8stream = nullptr;          // the same tiles as four per-wave streams in consumption order (gat_roles.hip)
     bool gat8 = true;                   // one-sample-per-workgroup encoder: the two-role kernel k_gat8 (GATOR_GAT8=0: k_gat)
     bool gat8_h4 = true;                // ... with its token-wise products on four partial products (x3_common.h; GATOR_GAT8_H4=0: the exact six)
+    float* g8stream_b = nullptr;        // ... and its byte-lo image (H3B tiles, 5 KiB: gat_roles.hip), what k_gat8<true, LR, false, true> streams
+    bool gat8_lobyte = false;           // set when every weight's lo plane survives the byte round trip (always, for finite weights; GATOR_GAT8_LOBYTE=0: off)
     int gat8_wshift = 0;                // its weight stream holds three fp16 planes of 2^gat8_wshift * w
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
     int mdr_persist = -1;               // the four MDR stages as ONE persistent launch (k_mdr_persist): -1 by batch size (launch_mdr), GATOR_MDR_PERSIST=0 never, =1 always

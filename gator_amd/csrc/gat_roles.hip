@@ -61,6 +61,8 @@ constexpr int kBlkTiles = kUseTiles + kPadTiles;
 enum { OFF_Q = 0, OFF_K = 4, OFF_V = 8, OFF_H0 = 12, OFF_H1 = 16, OFF_PROJ = 20, OFF_LIN0 = 24, OFF_LIN1 = 28, OFF_BACK = 29, OFF_FC1 = 33, OFF_FC2 = 49 };
 constexpr int kWaveTiles = kBlkTiles * kDepth;          // per product wave
 constexpr int kStreamFloats = (4 * kWaveTiles + kNT) * kTileX3;
+constexpr int kTileH3B = 2 * 512 + 256;                // floats of a byte-lo tile: hi and mid planes as in H3 (1 KiB per k-step each), lo as one byte per weight
+constexpr int kStreamFloatsB = (4 * kWaveTiles + kNT) * kTileH3B;
 
 // offsets into a block's vector table (fused_api.hip packs them in this order, 2048 floats per block)
 enum { V_N1W = 0, V_N1B = 128, V_QKVB = 256, V_PROJB = 640, V_GCNB = 768, V_LIN0B = 896, V_BACKB = 1024, V_N2W = 1152,
@@ -453,6 +455,53 @@ __device__ __forceinline__ void tile_mma_refill(H3P2& w, const X2& b, f32x16& ac
     }
 #undef GAT8_MM
 }
+// The byte-lo form of the four-product stream (round 5; default, GATOR_GAT8_LOBYTE=0 keeps H3): the same three fp16 planes, but the lo
+// plane travels as ONE BYTE per weight.  lo = fp16(w - hi - mid) is zero or a single power of two between 2^-24 and 2^-10 (the
+// residual of two 11-bit roundings of a 24-bit significand is at most one unit of w's last place), so the top byte of
+// fp16(2^24 lo) -- sign, five exponent bits, two mantissa bits -- holds it exactly; the product wave rebuilds the fp16 value with
+// two v_perm_b32 and two v_pk_mul_f16 (x 2^-24, exact: fp16 denormals are on) per four weights in the shadow of the MFMA before,
+// and multiplies the SAME bits in the SAME order: results are bit for bit those of the H3 stream (tests/test_gpu_digest.py), a
+// sixth of the stream's bytes never crosses the L2 -> CU path that bounds this kernel.  gat8_build_stream checks
+// on the device, with this very expansion, that every weight's lo survives the round trip, and keeps the H3 stream if one does not.
+struct H3B { f16x8 p[2][2]; uint4 lo; };     // [plane hi/mid][k-step] + 16 lo bytes (k-step 0: x y, k-step 1: z w): 20 VGPRs
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x8 lo_expand(unsigned d0, unsigned d1) {
+    const f16x2_t sc = {(_Float16)5.9604644775390625e-08f, (_Float16)5.9604644775390625e-08f};      // 2^-24
+    union { unsigned u[4]; f16x2_t h[4]; f16x8 v; } o;
+    o.u[0] = __builtin_amdgcn_perm(d0, d0, 0x010c000cu);      // (byte 0, byte 1) -> the high bytes of two halves
+    o.u[1] = __builtin_amdgcn_perm(d0, d0, 0x030c020cu);
+    o.u[2] = __builtin_amdgcn_perm(d1, d1, 0x010c000cu);
+    o.u[3] = __builtin_amdgcn_perm(d1, d1, 0x030c020cu);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.h[i] = o.h[i] * sc;
+    return o.v;
+}
+template <bool CL>
+__device__ __forceinline__ void tile_mma_refill(H3B& w, const X2& b, f32x16& acc, f32x16& acs, const float* __restrict__ wp, int lane) {
+    const f16x8* q = reinterpret_cast<const f16x8*>(wp) + lane;
+#define GAT8_MM(wv, bpl, s, AC) AC = CL ? GATOR_MFMA_F16(b.p[bpl][s], (wv), AC) : GATOR_MFMA_F16((wv), b.p[bpl][s], AC)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        GAT8_MM(w.p[0][s], 1, s, acs);                     // w hi  * a lo
+        const f16x8 lo = lo_expand(s == 0 ? w.lo.x : w.lo.z, s == 0 ? w.lo.y : w.lo.w);
+        GAT8_MM(lo, 0, s, acs);                            // w lo  * a hi
+        __builtin_amdgcn_sched_barrier(0);
+        if (s == 1) w.lo = reinterpret_cast<const uint4*>(wp + 1024)[lane];
+        __builtin_amdgcn_sched_barrier(0);
+        GAT8_MM(w.p[1][s], 0, s, acs);                     // w mid * a hi
+        __builtin_amdgcn_sched_barrier(0);
+        w.p[1][s] = q[(1 * 2 + s) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        GAT8_MM(w.p[0][s], 0, s, acc);                     // w hi  * a hi
+        __builtin_amdgcn_sched_barrier(0);
+        w.p[0][s] = q[(0 * 2 + s) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef GAT8_MM
+}
+// floats from one tile of a wave's stream to the next
+template <class WT> struct WTile { static constexpr int floats = kTileX3; };
+template <> struct WTile<H3B> { static constexpr int floats = kTileH3B; };
 // one k-step of the two-plane product (x3_common.h: x2_mma does both): lo*hi | hi*lo | hi*hi
 __device__ __forceinline__ f32x16 x2_mma_step(const X2& A, const X2& B, int s, f32x16 acc) {
     acc = GATOR_MFMA_F16(A.p[1][s], B.p[0][s], acc);
@@ -469,6 +518,14 @@ __device__ __forceinline__ void ld_tile(H3P2& o, const float* p, int lane) {
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) o.p[pl][s2] = q[(pl * 2 + s2) * 64];
+}
+__device__ __forceinline__ void ld_tile(H3B& o, const float* p, int lane) {
+    const f16x8* q = reinterpret_cast<const f16x8*>(p) + lane;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) o.p[pl][s2] = q[(pl * 2 + s2) * 64];
+    o.lo = reinterpret_cast<const uint4*>(p + 1024)[lane];
 }
 template <bool SWZ> __device__ __forceinline__ void ld_opnd(X3& o, const float* p, int lane) { o = x3_load(p, lane); }
 template <bool SWZ> __device__ __forceinline__ void ld_opnd(X2& o, const float* p, int lane) { o = SWZ ? x2_load_swz(p, lane) : x2_load(p, lane); }
@@ -489,7 +546,7 @@ __device__ __forceinline__ void unit4(WT (&W)[kNT], const float* __restrict__& w
         OT bn = b;
         if (kb < 3) ld_opnd<SWZ>(bn, ops[kb + 1], lane);
         tile_mma_refill<CL>(W[(S0 + kb) % kNT], b, acc, acs, wp, lane);
-        wp += kTileX3;
+        wp += WTile<WT>::floats;
         b = bn;
     }
     if constexpr (!std::is_same<WT, X3>::value) acc = acc + acs;
@@ -502,7 +559,7 @@ __device__ __forceinline__ void unit1(WT (&W)[kNT], const float* __restrict__& w
     OT b;
     ld_tile(b, o0, lane);
     tile_mma_refill<true>(W[S0 % kNT], b, acc, acs, wp, lane);
-    wp += kTileX3;
+    wp += WTile<WT>::floats;
     if constexpr (!std::is_same<WT, X3>::value) acc = acc + acs;
     store_block(raw, lane, acc);
 }
@@ -513,15 +570,17 @@ __device__ __forceinline__ void skip_pad(WT (&W)[kNT], const float* __restrict__
 #pragma unroll
     for (int i = 0; i < kPadTiles; ++i) {
         ld_tile(W[(S0 + i) % kNT], wp, lane);
-        wp += kTileX3;
+        wp += WTile<WT>::floats;
     }
 }
 
 // H4: the token-wise products on four partial products (weights H3, operands X2; raw tiles carry 1 / a.lin_inv) instead of six
-template <bool H4, int LR, bool H2 = false>
+template <bool H4, int LR, bool H2 = false, bool LB = false>
 __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
     static_assert(H4 || !H2, "the one-plane form is a variant of the four-product form");
-    typedef typename std::conditional<H2, H3P2, typename std::conditional<H4, H3, X3>::type>::type WT;
+    static_assert((H4 && !H2) || !LB, "the byte-lo stream is a form of the four-product stream");
+    typedef typename std::conditional<LB, H3B, typename std::conditional<H2, H3P2, typename std::conditional<H4, H3, X3>::type>::type>::type WT;
+    constexpr int kWF = WTile<WT>::floats;                 // floats per tile of the weight stream
     typedef typename std::conditional<H4, X2, X3>::type OT;
     const float inv = H4 ? a.lin_inv : 1.0f;
     // operand tile of a true-scale register tile; pick-up of a raw product tile with what is added to it
@@ -597,9 +656,9 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
     if (is_prod) {
         // =========================================== product waves ===========================================================
         WT W[kNT];                                                          // the head of the weight stream (held back until here: five tiles
-        const float* __restrict__ wp = a.wstream + (size_t)w * kWaveTiles * kTileX3;     // live across the embedding would spill)
+        const float* __restrict__ wp = a.wstream + (size_t)w * kWaveTiles * kWF;         // live across the embedding would spill)
 #pragma unroll
-        for (int s = 0; s < kNT; ++s) { ld_tile(W[s], wp, lane); wp += kTileX3; }
+        for (int s = 0; s < kNT; ++s) { ld_tile(W[s], wp, lane); wp += kWF; }
         asm volatile("" ::: "memory");
 #ifdef GATOR_DIAG
         unsigned long long* st_lds = reinterpret_cast<unsigned long long*>(lds + kGat8LdsFloats);
@@ -691,8 +750,8 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         for (int bi = 0; bi < kDepth; ++bi)
             for (int n = 1; n <= 22; ++n) {
                 if ((n == 2 || n == 19) && bi + 1 < kDepth && a.pf_loads > 0) {
-                    const char* wsrc = reinterpret_cast<const char*>(a.wstream + ((size_t)w * kWaveTiles + (size_t)(bi + 1) * kBlkTiles) * kTileX3);
-                    const int share = a.pf_loads * 8192, first = ((b >> 3) % a.pf_n) * share, lim = kBlkTiles * kTileX3 * 4 - 128;
+                    const char* wsrc = reinterpret_cast<const char*>(a.wstream + ((size_t)w * kWaveTiles + (size_t)(bi + 1) * kBlkTiles) * kWF);
+                    const int share = a.pf_loads * 8192, first = ((b >> 3) % a.pf_n) * share, lim = kBlkTiles * kWF * 4 - 128;
                     const int i0 = n == 2 ? 0 : (a.pf_loads + 1) / 2, i1 = n == 2 ? (a.pf_loads + 1) / 2 : a.pf_loads;
                     for (int i = i0; i < i1; ++i)
                         glds4(reinterpret_cast<const float*>(wsrc + min(first + i * 8192 + lane * 128, lim)), lds + kDummy + w * 256);
@@ -730,8 +789,8 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         const float* dummy = lds + kDummy + w * 256;
         const Gat8Blk& nx = a.blk[bi + 1 < kDepth ? bi + 1 : bi];
         auto warm_weights = [&](int i0, int i1) {
-            const char* wsrc = reinterpret_cast<const char*>(a.wstream + ((size_t)w * kWaveTiles + (size_t)(bi + 1) * kBlkTiles) * kTileX3);
-            const int share = a.pf_loads * 8192, first = ((b >> 3) % a.pf_n) * share, lim = kBlkTiles * kTileX3 * 4 - 128;
+            const char* wsrc = reinterpret_cast<const char*>(a.wstream + ((size_t)w * kWaveTiles + (size_t)(bi + 1) * kBlkTiles) * kWF);
+            const int share = a.pf_loads * 8192, first = ((b >> 3) % a.pf_n) * share, lim = kBlkTiles * kWF * 4 - 128;
             for (int i = i0; i < i1; ++i)
                 glds4(reinterpret_cast<const float*>(wsrc + min(first + i * 8192 + lane * 128, lim)), dummy);
         };
@@ -1044,6 +1103,32 @@ __global__ void k_gather_tiles(const float* __restrict__ src, const int* __restr
     f32x4* d = reinterpret_cast<f32x4*>(dst + (size_t)blockIdx.x * TILE);
     for (int e = threadIdx.x; e < TILE / 4; e += blockDim.x) d[e] = s[e];
 }
+// H3 stream -> byte-lo stream, one wave per tile: hi and mid planes copied, lo packed as the top byte of fp16(2^24 lo); *bad counts
+// the weights whose lo does not come back bit for bit from the product wave's own expansion (lo_expand)
+__global__ void k_h3_to_h3b(const float* __restrict__ src, float* __restrict__ dst, unsigned* __restrict__ bad) {
+    const int lane = threadIdx.x;
+    const f16x8* q = reinterpret_cast<const f16x8*>(src + (size_t)blockIdx.x * kTileX3) + lane;
+    f16x8* d = reinterpret_cast<f16x8*>(dst + (size_t)blockIdx.x * kTileH3B) + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i * 64] = q[i * 64];
+    unsigned pk[4] = {0, 0, 0, 0};
+    unsigned nbad = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const f16x8 lo = q[(4 + s2) * 64];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 up = (_Float16)((float)lo[j] * 16777216.0f);
+            pk[s2 * 2 + (j >> 2)] |= (unsigned)(__builtin_bit_cast(unsigned short, up) >> 8) << (8 * (j & 3));
+        }
+        const f16x8 back = lo_expand(pk[s2 * 2], pk[s2 * 2 + 1]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            nbad += __builtin_bit_cast(unsigned short, (_Float16)back[j]) != __builtin_bit_cast(unsigned short, (_Float16)lo[j]);
+    }
+    reinterpret_cast<uint4*>(dst + (size_t)blockIdx.x * kTileH3B + 1024)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    if (nbad) atomicAdd(bad, nbad);
+}
 
 }  // namespace
 
@@ -1055,6 +1140,8 @@ int gat8_prepare_device() {
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 12, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     return GATOR_OK;
 }
 
@@ -1100,6 +1187,20 @@ int gat8_build_stream(FusedState* f, void* stream) {
         int rc = fused_repack_h3(h3, f->g8stream, (int64_t)idx.size(), &f->gat8_wshift, &left, stream);
         if (rc == GATOR_OK && left > 1e-7f) rc = fail(GATOR_EUNSUPPORTED, "GAT weights span more than fp16 x 3 planes hold exactly: use GATOR_GAT8_H4=0");
         if (rc) return rc;
+        static const bool lobyte = [] { const char* e = getenv("GATOR_GAT8_LOBYTE"); return !(e && atoi(e) == 0); }();     // default on; =0 for A/B
+        if (lobyte) {      // the byte-lo image of the same stream (H3B): used only if every lo value survives the round trip
+            DevFree t_bad;
+            GATOR_HIP_CHECK(hipMalloc(&t_bad.p, sizeof(unsigned)));
+            GATOR_HIP_CHECK(hipMemsetAsync(t_bad.p, 0, sizeof(unsigned), (hipStream_t)stream));
+            GATOR_HIP_CHECK(hipMalloc(&f->g8stream_b, (size_t)kStreamFloatsB * sizeof(float)));
+            k_h3_to_h3b<<<(unsigned)idx.size(), 64, 0, (hipStream_t)stream>>>(f->g8stream, f->g8stream_b, (unsigned*)t_bad.p);
+            GATOR_HIP_CHECK(hipGetLastError());
+            unsigned nbad = 0;
+            GATOR_HIP_CHECK(hipMemcpyAsync(&nbad, t_bad.p, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+            GATOR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+            f->gat8_lobyte = nbad == 0;
+            if (!f->gat8_lobyte) { (void)hipFree(f->g8stream_b); f->g8stream_b = nullptr; }
+        }
     } else {
         k_gather_tiles<kTileX3><<<(unsigned)idx.size(), 128, 0, (hipStream_t)stream>>>(f->gxbuf, d_idx, f->g8stream);
     }
@@ -1134,7 +1235,9 @@ int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* 
     }
     static const bool l2warm = [] { const char* e = getenv("GATOR_GAT_L2WARM"); return !(e && atoi(e) == 0); }();     // default on; =0 for A/B
     a.pf_n = std::min(32, (B + 7) / 8);                  // workgroups b and b + 8 share an XCD (round-robin dispatch; speed only)
-    a.pf_loads = l2warm ? (kBlkTiles * kTileX3 * 4 / a.pf_n + 8191) / 8192 : 0;       // 8 KiB (64 lines) per instruction
+    const bool lob = f->gat8_h4 && f->gat8_lobyte && !half16;                         // the byte-lo stream (the one-plane form reads hi and mid of the H3 stream)
+    if (lob) a.wstream = f->g8stream_b;
+    a.pf_loads = l2warm ? (kBlkTiles * (lob ? kTileH3B : kTileX3) * 4 / a.pf_n + 8191) / 8192 : 0;       // 8 KiB (64 lines) per instruction
     if (a.pf_loads > 6) a.pf_loads = 0;      // fewer than ~8 workgroups per XCD (B < 64): a share is so large that touching it costs more than it hides
 #ifdef GATOR_DIAG
     a.stamps = nullptr;
@@ -1151,6 +1254,8 @@ int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* 
     if (!f->gat8_h4) k_gat8<false, 16><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else if (half16 && c->J <= 18) k_gat8<true, 10, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else if (half16 && c->J <= 20) k_gat8<true, 12, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else if (lob && c->J <= 18) k_gat8<true, 10, false, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else if (lob && c->J <= 20) k_gat8<true, 12, false, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else if (c->J <= 18) k_gat8<true, 10><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else if (c->J <= 20) k_gat8<true, 12><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else return fail(GATOR_EUNSUPPORTED, "k_gat8: more than 20 joints (gator_create admits 17 and 19)");
