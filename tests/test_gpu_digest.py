@@ -21,3 +21,20 @@ def test_fp32_forward_digests_match_the_recorded_build():
     got = digests()
     bad = {k: (got.get(k), h) for k, h in want.items() if got.get(k) != h}
     assert not bad, 'outputs moved bits against tests/golden/fp32_digests.json: %s' % bad
+
+
+def test_byte_lo_weight_stream_equals_the_three_plane_stream_bit_for_bit():
+    """k_gat8 streams its weights with the lo plane as one byte per weight by default (gat_roles.hip: H3B); GATOR_GAT8_LOBYTE=0 keeps
+    the three fp16 planes.  The switch is read once per process, so the other form runs in a child process; the digests (which cover
+    B = 5 / 256 / 700 on k_gat8) must be equal.  (Which kernel ran is visible in profiles/r05_kernel_stats_*: k_gat8<true, 10, false, true>.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for lb in ('1', '0'):
+        env = dict(os.environ, GATOR_GAT8_LOBYTE=lb)
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'ab_digest.py'), 'lobyte' + lb], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[lb] = sorted(ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith('lobyte'))
+        assert len(out[lb]) >= 8
+    assert out['1'] == out['0']
