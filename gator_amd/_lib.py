@@ -27,7 +27,7 @@ class GemmProblem(ctypes.Structure):            # include/gator_train.h: gator_g
 
 class GatorConfig(ctypes.Structure):
     _fields_ = [('num_joint', ctypes.c_int32), ('alpha', ctypes.c_int32), ('impl', ctypes.c_int32),
-                ('max_batch', ctypes.c_int32), ('parts', ctypes.c_int32), ('subbatch_streams', ctypes.c_int32)]
+                ('max_batch', ctypes.c_int32), ('parts', ctypes.c_int32), ('subbatch_streams', ctypes.c_int32), ('arithmetic', ctypes.c_int32)]
 
 
 # every symbol include/gator_hip.h and include/gator_train.h declare: name -> (restype, argtypes)

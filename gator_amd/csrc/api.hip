@@ -202,9 +202,12 @@ extern "C" int gator_create(const gator_tensor* tensors, int32_t n, const gator_
     if (!tensors || n <= 0 || !cfg || !out) return fail(GATOR_EINVAL, "gator_create: null argument");
     if (cfg->num_joint != 17 && cfg->num_joint != 19)
         return fail(GATOR_EUNSUPPORTED, "gator_create: num_joint must be 17 or 19 (reference: lib/models/GAT.py:79-93), got %d", cfg->num_joint);
+    if (cfg->arithmetic != GATOR_ARITH_DEFAULT && cfg->arithmetic != GATOR_ARITH_EXACT_SPLIT)
+        return fail(GATOR_EINVAL, "gator_create: arithmetic must be GATOR_ARITH_DEFAULT (0) or GATOR_ARITH_EXACT_SPLIT (1), got %d", cfg->arithmetic);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(GATOR_EHIP, "gator_create: no HIP device available");
     gator_ctx* c = new gator_ctx();
+    c->arithmetic = cfg->arithmetic;
     c->J = cfg->num_joint;
     c->alpha = cfg->alpha ? 1 : 0;
     c->impl = cfg->impl;
@@ -291,8 +294,8 @@ static int report_device_status(gator_ctx* c, unsigned st, const char* fn, bool 
         return fail(GATOR_EDEVICE, "%s: an earlier forward on this ctx produced non-finite or out-of-range coarse vertices.  Either its input poses "
                                    "were not finite (the reference returns NaN for those too), or the weights drive an activation out of the default "
                                    "arithmetic's range (|vert431| must stay below 4094 m, and every activation that feeds a token-wise linear below "
-                                   "4094: they travel as fp16 planes of 16 x value); GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 "
-                                   "GATOR_GAT_TILED_H4=0 select the bf16 forms without that range limit.%s", fn, tail);
+                                   "4094: they travel as fp16 planes of 16 x value); a ctx created with gator_config.arithmetic = GATOR_ARITH_EXACT_SPLIT "
+                                   "(model.arithmetic = 'exact') runs the bf16 forms without that range limit.%s", fn, tail);
     return GATOR_OK;
 }
 static unsigned take_status_word(gator_ctx* c) { return c->status_host ? __atomic_exchange_n(c->status_host, 0u, __ATOMIC_RELAXED) : 0u; }

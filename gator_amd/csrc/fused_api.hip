@@ -138,8 +138,9 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
             GATOR_HIP_CHECK(hipMalloc(&f->gxbuf, (size_t)ntiles * kTileX3 * sizeof(float)));
             int rc = fused_repack_x3(f->gblk[0].qkv, f->gxbuf, ntiles, stream);
             if (rc) return rc;
+            const bool exact = c->arithmetic == GATOR_ARITH_EXACT_SPLIT;       // gator_config.arithmetic: no two-plane operand anywhere
             const char* th = getenv("GATOR_GAT_TILED_H4");
-            f->gat_tiled_h4 = !(th && atoi(th) == 0);
+            f->gat_tiled_h4 = !exact && !(th && atoi(th) == 0);
             if (f->gat_tiled_h4) {
                 float left = 0.f;
                 GATOR_HIP_CHECK(hipMalloc(&f->gxbuf_h3, (size_t)ntiles * kTileX3 * sizeof(float)));
@@ -151,7 +152,7 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
             const char* g8 = getenv("GATOR_GAT8");
             f->gat8 = !(g8 && atoi(g8) == 0);
             const char* g8h = getenv("GATOR_GAT8_H4");
-            f->gat8_h4 = !(g8h && atoi(g8h) == 0);
+            f->gat8_h4 = !exact && !(g8h && atoi(g8h) == 0);
             if (f->gat8) {
                 rc = gat8_build_stream(f, stream);
                 if (rc) return rc;
@@ -227,12 +228,13 @@ int fused_create(gator_ctx* c, void* stream) {
     if (!(c->parts & GATOR_PART_MDR)) return GATOR_OK;
     // vertex regressor: split-precision bf16 planes by default; GATOR_UPSAMPLE_X3=0 keeps the fp32-input MFMA kernel (A/B runs)
     const char* x3env = getenv("GATOR_UPSAMPLE_X3");
-    const int up_mode = x3env ? atoi(x3env) : 2;
+    const bool exact = c->arithmetic == GATOR_ARITH_EXACT_SPLIT;
+    const int up_mode = exact ? 1 : x3env ? atoi(x3env) : 2;
     if (up_mode < 0 || up_mode > 2) return fail(GATOR_EINVAL, "GATOR_UPSAMPLE_X3 must be 0, 1 or 2");
     f->x3 = up_mode != 0;
     f->up_x2 = up_mode == 2;
     const char* mx3 = getenv("GATOR_MDR_X3");
-    f->mdr_x3 = mx3 ? atoi(mx3) : 2;
+    f->mdr_x3 = exact ? 1 : mx3 ? atoi(mx3) : 2;
     if (f->mdr_x3 < 0 || f->mdr_x3 > 2) return fail(GATOR_EINVAL, "GATOR_MDR_X3 must be 0, 1 or 2");
     // BASELINE config 3 (gator_forward_bf16): which stages run on ONE 16-bit operand plane.  Default: the MDR layers (one fp16 activation
     // plane, mdr_fused.hip XA = 3), the vertex regressor stays on its two fp16 planes (a single bf16 / fp16 plane there costs 4 / 0.5 mm:

@@ -67,7 +67,7 @@ struct ProfRec { const char* name; void* start; void* stop; };
 }  // namespace gator
 
 struct gator_ctx {
-    int J = 0, alpha = 0, impl = 0, device = 0, D = 0, parts = 3, subbatch_streams = 0;
+    int J = 0, alpha = 0, impl = 0, device = 0, D = 0, parts = 3, subbatch_streams = 0, arithmetic = 0;
     std::string prefix_gat, prefix_mdr;
     std::map<std::string, gator::TensorRef> t;
     char* arena = nullptr;

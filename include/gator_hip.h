@@ -57,14 +57,16 @@ typedef struct {
  * Operand range of that default: every value that feeds a token-wise linear and every coarse vertex must stay below 4 094 in
  * magnitude (16 x value must fit an fp16 plane); beyond it the plane overflows, the vertices of that forward come out NaN and the
  * NEXT call on the ctx (or gator_device_status) returns GATOR_EDEVICE -- loud, never silently wrong.  Trained checkpoints are
- * orders of magnitude inside (LayerNorm outputs, GELU hiddens, metres).  Environment variables read by gator_create select the forms
- * without a rounded operand and without that limit (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 GATOR_GAT_TILED_H4=0: exact
+ * orders of magnitude inside (LayerNorm outputs, GELU hiddens, metres).  gator_config.arithmetic = GATOR_ARITH_EXACT_SPLIT (or the environment
+ * variables it stands for, read by gator_create) selects the forms without a rounded operand and without that limit (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 GATOR_GAT_TILED_H4=0: exact
  * three-way bf16 split, six products) or the fp32-input MFMA form of a stage (GATOR_GAT_X3 / GATOR_MDR_X3 / GATOR_UPSAMPLE_X3 = 0);
  * all forms are the same accuracy class and under test (tests/test_gpu_x3.py; statistics: profiles/r04_error_budget.md). */
 typedef enum { GATOR_IMPL_FUSED = 0,   /* MFMA / register-resident fused kernels (default) */
                GATOR_IMPL_BASIC = 1    /* bring-up kernels: one simple HIP kernel per reference op; used as an
                                           on-device cross-check of the fused path */
 } gator_impl;
+
+typedef enum { GATOR_ARITH_DEFAULT = 0, GATOR_ARITH_EXACT_SPLIT = 1 } gator_arith;
 
 typedef enum { GATOR_PART_GAT = 1,    /* pose_lifter.*  (models.GAT.get_model used stand-alone, lib/core/base.py:59) */
                GATOR_PART_MDR = 2     /* pose2mesh.*    (models.MDR.get_model, lib/models/MDR.py:172-174) */
@@ -77,6 +79,10 @@ typedef struct {
     int32_t max_batch;   /* workspace is sized for this many samples up front (0 = grow on demand) */
     int32_t parts;       /* gator_parts bitmask: which sub-modules' weights are present (0 = both) */
     int32_t subbatch_streams; /* 2: run batches >= 128 as two half-batches on two streams (identical results, better tails) */
+    int32_t arithmetic;  /* gator_arith: 0 = default (two-plane activations, operand range |value| < 4 094, see above);
+                            1 = GATOR_ARITH_EXACT_SPLIT: every product on the exact three-way bf16 split (six partial products), no
+                            rounded operand and no operand-range limit -- what a ctx that reported GATOR_EDEVICE for an out-of-range
+                            operand is re-created with.  Same accuracy class, ~1.5 x the time (tests/test_gpu_x3.py) */
 } gator_config;
 
 /* Replaces: models.GATOR.get_model(...) + load_state_dict + .cuda()  (lib/models/GATOR.py:24-27,

@@ -157,6 +157,35 @@ def test_operand_range_violation_is_loud(key, gain):
         m(x)                                                # the forward after a bad one reports it without an explicit query
 
 
+@pytest.mark.parametrize('key,gain', [('pose2mesh.encoder_1.mlp.fc1.weight', 3e4), ('pose_lifter.blocks.2.mlp.fc1.weight', 3e4)])
+def test_exact_split_arithmetic_has_no_operand_range(key, gain):
+    """gator_config.arithmetic = GATOR_ARITH_EXACT_SPLIT (include/gator_hip.h; `model.arithmetic = 'exact'`): every product on the exact
+    three-way bf16 split, so the weights that break the default's operand range above (an MLP hidden beyond 4 094) give finite
+    vertices, a clean device status, and the reference's numbers -- compared with the fp64 oracle on the same scaled weights,
+    relative to the reference arithmetic's own error (the oracle in fp32)."""
+    from oracle import gator_oracle as go
+    z, m = build_model('h36m17_bn', 'fused', device=None)
+    zz, c, sd_o = oracle_setup('h36m17_bn')
+    sd = m.state_dict()
+    sd[key] = sd[key] * gain
+    sd_o[key] = sd_o[key] * gain
+    m.load_state_dict(sd)
+    m.arithmetic = 'exact'
+    m = m.cuda()
+    x = torch.from_numpy(synthetic.synthetic_pose2d(16, 17, seed=5))
+    v, p = m(x.cuda())
+    torch.cuda.synchronize()
+    assert torch.isfinite(v).all() and torch.isfinite(p).all()
+    m.device_status()
+    r64, _ = go.gator_forward(sd_o, c, x, torch.float64)
+    r32, _ = go.gator_forward(sd_o, c, x, torch.float32)
+    scale = float(r64.abs().max())
+    ours = float(np.abs(v.cpu().numpy().astype(np.float64) - r64.numpy()).max()) / scale
+    ref = float(np.abs(r32.numpy().astype(np.float64) - r64.numpy()).max()) / scale
+    print('\n[%s x %g, exact split] |ours - fp64| / max|v| = %.2e, reference arithmetic %.2e' % (key, gain, ours, ref))
+    assert ours <= max(2e-6, 2.0 * ref)
+
+
 def test_device_status_is_clean_after_normal_forwards():
     z, m = build_model('coco19_alpha', 'fused')
     for B in (1, 33, 300):
