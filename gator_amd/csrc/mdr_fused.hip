@@ -37,6 +37,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 // tile 0, bit 1 = every K / V load of the 431-key attention reads key tile 0 -- the loads stay, their L2 -> L1 traffic goes (L1 hits).
 #ifdef GATOR_DIAG
 __device__ int g_mdr_wmask = -1, g_mdr_kvmask = -1;
+__device__ unsigned long long* g_persist_ends = nullptr;      // GATOR_MDR_ENDS=1: [workgroup][start, last ticket taken, end] wall-clock stamps (100 MHz) of k_mdr_persist
 #define MDR_WIDX(i) ((i) & g_mdr_wmask)
 #define MDR_KVIDX(i) ((i) & g_mdr_kvmask)
 #else
@@ -1326,13 +1327,27 @@ __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) 
     };
     // Tickets come in stage order, so a workgroup's stages only ever go up: three plain loops, one tile body each (one loop with a
     // switch keeps all three bodies' state alive at once: 256 VGPRs + 760 B of scratch).
+#ifdef GATOR_DIAG
+    const unsigned long long pe_t0 = wall_clock64();
+    unsigned long long pe_last = pe_t0;
+#define PERSIST_END_MARK() pe_last = wall_clock64()
+#else
+#define PERSIST_END_MARK()
+#endif
     int unit = ticket();
     for (; unit < units; unit = ticket()) run(std::integral_constant<int, 0>(), 0, unit);
     for (; unit < 3 * units; unit = ticket()) {
         const int stage = unit >= 2 * units ? 2 : 1;
         run(std::integral_constant<int, 1>(), stage, unit);
     }
-    for (; unit < 4 * units; unit = ticket()) run(std::integral_constant<int, 2>(), 3, unit);
+    for (; unit < 4 * units; unit = ticket()) { PERSIST_END_MARK(); run(std::integral_constant<int, 2>(), 3, unit); }
+#ifdef GATOR_DIAG
+    if (g_persist_ends && threadIdx.x == 0) {
+        g_persist_ends[3 * blockIdx.x] = pe_t0;
+        g_persist_ends[3 * blockIdx.x + 1] = pe_last;
+        g_persist_ends[3 * blockIdx.x + 2] = wall_clock64();
+    }
+#endif
 }
 
 // Joint tokens: jf = Linear(133->64)(pose_combine) + pos_j (MDR.py:130-134); per layer k = wk(LN1(jf)), v = wv(LN1(jf))
@@ -1664,6 +1679,15 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
             else k_mdr_layer<2, 0><<<nwg, 256, 0, st>>>(a, nwg);
         }
     }
+#ifdef GATOR_DIAG
+    static const bool want_ends = getenv("GATOR_MDR_ENDS") != nullptr;
+    unsigned long long* d_ends = nullptr;
+    if (want_ends && persist) {
+        GATOR_HIP_CHECK(hipMalloc(&d_ends, 3 * 1024 * sizeof(unsigned long long)));
+        GATOR_HIP_CHECK(hipMemset(d_ends, 0, 3 * 1024 * sizeof(unsigned long long)));
+        GATOR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_persist_ends), &d_ends, sizeof(d_ends)));
+    }
+#endif
     if (persist) {      // the four stages as persistent launches (k_mdr_persist): tickets and per-sample completion counts start from zero
         if (!ctr_clean) GATOR_HIP_CHECK(hipMemsetAsync(f->mdr_ctr, 0, mdr_ctr_words(B) * sizeof(unsigned), st));
         StageTimer tm(c, "mdr_layers", stream);
@@ -1711,6 +1735,31 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
         }
     }
 #ifdef GATOR_DIAG
+    if (d_ends) {      // synchronous read-back (diagnostic build only): when did each workgroup of the LAST persistent launch start / take its last ticket / end?
+        std::vector<unsigned long long> he(3 * 1024);
+        GATOR_HIP_CHECK(hipMemcpy(he.data(), d_ends, he.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long* none = nullptr;
+        GATOR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_persist_ends), &none, sizeof(none)));
+        GATOR_HIP_CHECK(hipFree(d_ends));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        int n = 0;
+        for (int i = 0; i < 1024; ++i) if (he[3 * i + 2]) { t0 = std::min(t0, he[3 * i]); t1 = std::max(t1, he[3 * i + 2]); ++n; }
+        if (n) {
+            double idle = 0, lastlen = 0, first_end = 1e30, start_spread = 0;
+            std::vector<double> ends;
+            for (int i = 0; i < 1024; ++i) if (he[3 * i + 2]) {
+                idle += (double)(t1 - he[3 * i + 2]) / 100.0;
+                lastlen += (double)(he[3 * i + 2] - he[3 * i + 1]) / 100.0;
+                first_end = std::min(first_end, (double)(he[3 * i + 2] - t0) / 100.0);
+                start_spread = std::max(start_spread, (double)(he[3 * i] - t0) / 100.0);
+                ends.push_back((double)(he[3 * i + 2] - t0) / 100.0);
+            }
+            std::sort(ends.begin(), ends.end());
+            fprintf(stderr, "[k_mdr_persist ends, B=%d, %d workgroups] span %.1f us; workgroup starts spread over %.1f us; ends: first %.1f, p10 %.1f, median %.1f, p90 %.1f, last %.1f us; "
+                            "mean idle before the last workgroup ends %.1f us; mean length of a workgroup's last stage-3 ticket %.1f us\n",
+                    B, n, (double)(t1 - t0) / 100.0, start_spread, first_end, ends[n / 10], ends[n / 2], ends[n * 9 / 10], ends[n - 1], idle / n, lastlen / n);
+        }
+    }
     if (d_st) {
         unsigned long long hst[512];
         GATOR_HIP_CHECK(hipMemcpy(hst, d_st, sizeof(hst), hipMemcpyDeviceToHost));
