@@ -103,7 +103,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--blocks', type=int, default=11, help='timed blocks of --steps steps each; the median block is reported')
+    ap.add_argument('--blocks', type=int, default=11, help='timed blocks of --steps steps each (a minimum: see --min-timed-s); the median block is reported')
+    ap.add_argument('--min-timed-s', type=float, default=3.0,
+                    help='keep adding timed blocks of --steps steps until the timed region holds at least this many seconds of forwards '
+                         '(N = 1; with ranks the block count must agree, so it is fixed from the first blocks by rank 0 and broadcast); 0 = exactly --blocks')
     ap.add_argument('--config', type=int, default=0, choices=[0, 2, 3, 4, 5],
                     help='BASELINE.json preset (1-based as in VERDICT.md): 2 = B=256 J=17 fp32, 3 = B=2048 J=19 bf16, 4 = 1024 per GPU J=17 + '
                          'all-gather (8 GPUs = B 8192), 5 = evaluation mode J=19 (all-reduce only); --batch/--joints/--precision/--mode override')
@@ -189,10 +192,15 @@ def stage_pipe(stage, impl, precision='f32'):
     mode = os.environ.get(sw, '2' if sw in ('GATOR_MDR_X3', 'GATOR_UPSAMPLE_X3') else '1') if sw else '0'
     if impl == 'fused' and sw is not None and mode != '0':
         parts = STAGE_PRODUCTS.get(stage) if mode == '2' else None
-        if precision == 'bf16' and mode == '2' and stage in STAGE_PRODUCTS_C3 and os.environ.get('GATOR_C3_MDR', '1') != '0':
+        c3 = precision == 'bf16' and mode == '2'
+        # config 3: each stage follows its own switch (fused_api.hip: GATOR_C3_MDR / GATOR_C3_UPSAMPLE_W1 / GATOR_C3_ENCODER, all default on)
+        c3_switch = 'GATOR_C3_UPSAMPLE_W1' if stage == 'upsample' else 'GATOR_C3_MDR'
+        if c3 and stage in STAGE_PRODUCTS_C3 and stage != 'gat' and os.environ.get(c3_switch, '1') != '0':
             parts = STAGE_PRODUCTS_C3[stage]
         if stage == 'gat':      # the four-product form is k_gat8's (GATOR_GAT8_H4, default on); k_gat / k_gat_tiled run six
-            parts = STAGE_PRODUCTS['gat'] if (os.environ.get('GATOR_GAT8', '1') != '0' and os.environ.get('GATOR_GAT8_H4', '1') != '0') else None
+            g8 = os.environ.get('GATOR_GAT8', '1') != '0' and os.environ.get('GATOR_GAT8_H4', '1') != '0'
+            c3e = precision == 'bf16' and os.environ.get('GATOR_C3_ENCODER', '1') != '0'
+            parts = (STAGE_PRODUCTS_C3['gat'] if c3e else STAGE_PRODUCTS['gat']) if g8 else None
         if parts:
             tot = sum(m for m, _ in parts)
             peak = tot / sum(m * k / PEAK_BF16_TFLOPS for m, k in parts)
@@ -229,15 +237,15 @@ def build_model(J, impl, device):
 
 def pmc_digest(B):
     """The committed rocprofv3 PMC digest of this same command at B=256 (tools/profile_round.sh + tools/pmc_digest.py), newest
-    round first; None for other batch sizes."""
+    round first (profiles/rNN_pmc_summary_B256.json, highest NN); None for other batch sizes."""
     if B != 256:
         return None, None
-    for name in ('r04_pmc_summary_B256.json', 'r03_pmc_summary_B256.json', 'r02_pmc_summary_B256.json', 'r01_pmc_summary_B256.json'):
-        path = os.path.join(ROOT, 'profiles', name)
-        if os.path.exists(path):
-            prov = os.path.join(ROOT, 'profiles', name.replace('_pmc_summary_B256.json', '_pmc_provenance.json'))
-            commit = json.load(open(prov)).get('commit') if os.path.exists(prov) else None
-            return json.load(open(path)), (name + (' @ ' + commit if commit else ''))
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_summary_B256.json')), reverse=True):
+        name = os.path.basename(path)
+        prov = os.path.join(ROOT, 'profiles', name.replace('_pmc_summary_B256.json', '_pmc_provenance.json'))
+        commit = json.load(open(prov)).get('commit') if os.path.exists(prov) else None
+        return json.load(open(path)), (name + (' @ ' + commit if commit else ''))
     return None, None
 
 
@@ -437,6 +445,13 @@ def main():
     for _ in range(max(1, a.blocks)):
         dt, out = block(lambda: runner.step(x), a.steps)
         dts.append(dt)
+    # The timed region is made long enough for an outside sampler (the driver's SMI poll) to see a busy GPU: more blocks of EXACTLY
+    # --steps steps, same protocol, until it holds --min-timed-s seconds.  Every rank runs the same count (dts are MAX-reduced, so equal).
+    if a.min_timed_s > 0:
+        more = int(min(20000, max(0.0, a.min_timed_s - sum(dts)) / max(float(np.median(dts)), 1e-6) + 0.999))
+        for _ in range(more):
+            dt, out = block(lambda: runner.step(x), a.steps)
+            dts.append(dt)
     prof = model.profile_read()
     model.profile(0)
     dt = float(np.median(dts))
@@ -519,7 +534,9 @@ def main():
                            'batch_per_gpu': B, 'global_batch': B * world, 'num_joint': J, 'impl': a.impl, 'parallelism': 'dp%d' % world,
                            'mode': a.mode},
                 'timing': {'blocks': len(dts), 'reported': 'median block',
-                           'block_ms': [round(d * 1e3, 3) for d in dts],
+                           'timed_region_s': round(sum(dts), 3),
+                           'block_ms': [round(d * 1e3, 3) for d in dts] if len(dts) <= 32 else None,
+                           'block_ms_quantiles': {q: round(float(np.quantile(dts, float(q))) * 1e3, 3) for q in ('0.0', '0.05', '0.25', '0.5', '0.75', '0.95', '1.0')},
                            'min_ms_per_step': round(min(dts) / a.steps * 1e3, 4), 'max_ms_per_step': round(max(dts) / a.steps * 1e3, 4)},
                 'whole_forward': {'flop_per_mesh': FLOPS_PER_MESH.get(J), 'achieved_tflops_per_gpu': round(per_gpu_tf, 2),
                                   'frac_of_fp32_peak_157.3': round(per_gpu_tf / PEAK_F32_TFLOPS, 4),

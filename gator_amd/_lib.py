@@ -25,8 +25,13 @@ class GemmProblem(ctypes.Structure):            # include/gator_train.h: gator_g
                 ('ws_off', ctypes.c_int64), ('total_wgs', ctypes.c_int32), ('total_fin', ctypes.c_int32), ('bias', ctypes.c_void_p)]
 
 
+ABI_VERSION = 2                                 # include/gator_hip.h: GATOR_ABI_VERSION this binding was written against
+EDEVICE, EDEVICE_DEFERRED = -7, -8
+REASON_PERSIST_INCOMPLETE, REASON_NONFINITE = 1, 2      # gator_status_reason
+
+
 class GatorConfig(ctypes.Structure):
-    _fields_ = [('num_joint', ctypes.c_int32), ('alpha', ctypes.c_int32), ('impl', ctypes.c_int32),
+    _fields_ = [('struct_size', ctypes.c_int32), ('num_joint', ctypes.c_int32), ('alpha', ctypes.c_int32), ('impl', ctypes.c_int32),
                 ('max_batch', ctypes.c_int32), ('parts', ctypes.c_int32), ('subbatch_streams', ctypes.c_int32), ('arithmetic', ctypes.c_int32)]
 
 
@@ -36,6 +41,8 @@ SIGNATURES = {
     'gator_create': (_I, [ctypes.POINTER(GatorTensor), _I, ctypes.POINTER(GatorConfig), ctypes.POINTER(_P)]),
     'gator_destroy': (_I, [_P]),
     'gator_device_status': (_I, [_P, _I]),
+    'gator_status_reason': (_I, [_P]),
+    'gator_abi_version': (_I, []),
     'gator_forward_f32': (_I, [_P, _P, _I, _P, _P, _P]),
     'gator_forward_bf16': (_I, [_P, _P, _I, _P, _P, _P]),
     'gator_upsample_bf16': (_I, [_P, _P, _I, _P, _P]),
@@ -112,10 +119,26 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.gator_abi_version() != ABI_VERSION:
+            raise RuntimeError('%s is ABI %d, this binding is ABI %d: rebuild with `python -m gator_amd.build`' % (LIB_PATH, lib.gator_abi_version(), ABI_VERSION))
         _lib = lib
     return _lib
 
 
+class DeviceStatusError(RuntimeError):
+    """GATOR_EDEVICE: a kernel of an EARLIER call on the ctx flagged its result as invalid (include/gator_hip.h: gator_device_status)."""
+    code = EDEVICE
+    reason = 0          # gator_status_reason, filled in by the caller that knows the ctx
+    outputs = None
+
+
+class DeferredDeviceStatus(DeviceStatusError):
+    """GATOR_EDEVICE_DEFERRED: the same report carried by a forward that was queued normally.  `outputs` holds the tensors that forward
+    is writing (valid unless the next call reports again), so a caller that must stay in step with other ranks can go on with them."""
+    code = EDEVICE_DEFERRED
+
+
 def check(rc, what):
     if rc != 0:
-        raise RuntimeError('%s failed (%d): %s' % (what, rc, load().gator_last_error().decode()))
+        cls = {EDEVICE: DeviceStatusError, EDEVICE_DEFERRED: DeferredDeviceStatus}.get(rc, RuntimeError)
+        raise cls('%s failed (%d): %s' % (what, rc, load().gator_last_error().decode()))

@@ -58,22 +58,29 @@ def build(force=False, verbose=True, diag=False):
                 (['-x', 'hip', '-Rpass-analysis=kernel-resource-usage'] if is_hip else []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            with open(stamp, 'w') as fh:
-                fh.write(want)
-            procs.append((s, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+            for stale in (obj, stamp):       # a failed compile must not leave the other flag set's object behind a matching stamp
+                if os.path.exists(stale):
+                    os.remove(stale)
+            procs.append((s, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True), stamp, want))
     from . import kernel_resources as kr
     remarks = {}
-    for s, obj, p in procs:
+    failed = None
+    for s, obj, p, stamp, want in procs:
         err = p.communicate()[1]
         if p.returncode != 0:
             sys.stderr.write(err)
-            raise RuntimeError('hipcc failed on %s' % s)
+            failed = failed or s
+            continue
+        with open(stamp, 'w') as fh:       # the stamp records the flags of an object that exists
+            fh.write(want)
         noise = ('remark:', '-Rpass-analysis')
         rest = [ln for ln in err.splitlines() if ln.strip() and not any(n in ln for n in noise)]
         rest = [ln for ln in rest if not (ln.lstrip().startswith('|') or ln.lstrip()[:1].isdigit() and ' | ' in ln)]
         if rest and verbose:
             sys.stderr.write('\n'.join(rest) + '\n')
         remarks[s] = (obj, kr.parse(err))
+    if failed:
+        raise RuntimeError('hipcc failed on %s' % failed)
     if not diag:
         try:
             kr.check({s: r for s, (_, r) in remarks.items()})

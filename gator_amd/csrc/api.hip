@@ -183,7 +183,8 @@ size_t dtype_size(int dt) { return dt == GATOR_I64 ? 8 : 4; }
 using namespace gator;
 
 extern "C" const char* gator_last_error(void) { return g_err; }
-extern "C" const char* gator_version(void) { return "gator-amd 0.1 (gfx950)"; }
+extern "C" const char* gator_version(void) { return "gator-amd 0.2 (gfx950)"; }
+extern "C" int gator_abi_version(void) { return GATOR_ABI_VERSION; }
 
 static void prof_clear(gator_ctx* c, bool destroy);
 
@@ -198,8 +199,16 @@ extern "C" int gator_destroy(gator_ctx* c) {
     return GATOR_OK;
 }
 
-extern "C" int gator_create(const gator_tensor* tensors, int32_t n, const gator_config* cfg, gator_ctx** out) {
-    if (!tensors || n <= 0 || !cfg || !out) return fail(GATOR_EINVAL, "gator_create: null argument");
+extern "C" int gator_create(const gator_tensor* tensors, int32_t n, const gator_config* cfg_in, gator_ctx** out) {
+    if (!tensors || n <= 0 || !cfg_in || !out) return fail(GATOR_EINVAL, "gator_create: null argument");
+    // ABI 2: the caller states the size of ITS gator_config; later fields read as 0.  (An ABI-1 caller's first field is num_joint = 17 / 19.)
+    const int32_t csz = cfg_in->struct_size;
+    if (csz < 8 || csz > 1024 || (csz & 3))
+        return fail(GATOR_EINVAL, "gator_create: gator_config.struct_size = %d; set it to sizeof(gator_config) (ABI %d: struct_size is the first field)", csz, GATOR_ABI_VERSION);
+    gator_config cfg_local;
+    memset(&cfg_local, 0, sizeof(cfg_local));
+    memcpy(&cfg_local, cfg_in, std::min((size_t)csz, sizeof(cfg_local)));
+    const gator_config* cfg = &cfg_local;
     if (cfg->num_joint != 17 && cfg->num_joint != 19)
         return fail(GATOR_EUNSUPPORTED, "gator_create: num_joint must be 17 or 19 (reference: lib/models/GAT.py:79-93), got %d", cfg->num_joint);
     if (cfg->arithmetic != GATOR_ARITH_DEFAULT && cfg->arithmetic != GATOR_ARITH_EXACT_SPLIT)
@@ -283,15 +292,17 @@ extern "C" int gator_create(const gator_tensor* tensors, int32_t n, const gator_
 // What a kernel left in the ctx's sticky status word (an EARLIER call's failure: nothing here synchronises).  Reported once, then cleared.
 // `executed`: the report rides on an entry point that has queued its own work normally (finish_fwd): the caller's buffers are being written.
 static int report_device_status(gator_ctx* c, unsigned st, const char* fn, bool executed) {
+    const int code = executed ? GATOR_EDEVICE_DEFERRED : GATOR_EDEVICE;
+    if (st) c->status_reason = (int)st;
     const char* tail = executed ? "  THIS call was queued normally; its outputs are valid unless the next call reports again." : "";
     if (st == DEV_PERSIST_INCOMPLETE) {
         fused_disable_persist(c);        // e.g. an XCD without workgroups (CU mask): its queue is never served.  The four-launch form has no such dependency.
-        return fail(GATOR_EDEVICE, "%s: an earlier forward on this ctx did not complete its persistent MDR launch (a sample's stage tiles were never "
+        return fail(code, "%s: an earlier forward on this ctx did not complete its persistent MDR launch (a sample's stage tiles were never "
                                    "finished: an XCD without workgroups, or the hang guard); the vertices of that forward are NaN.  This ctx now uses the "
                                    "four-launch form of the MDR stages (same results); GATOR_MDR_PERSIST=0 selects it from the start.%s", fn, tail);
     }
     if (st == DEV_NONFINITE)
-        return fail(GATOR_EDEVICE, "%s: an earlier forward on this ctx produced non-finite or out-of-range coarse vertices.  Either its input poses "
+        return fail(code, "%s: an earlier forward on this ctx produced non-finite or out-of-range coarse vertices.  Either its input poses "
                                    "were not finite (the reference returns NaN for those too), or the weights drive an activation out of the default "
                                    "arithmetic's range (|vert431| must stay below 4094 m, and every activation that feeds a token-wise linear below "
                                    "4094: they travel as fp16 planes of 16 x value); a ctx created with gator_config.arithmetic = GATOR_ARITH_EXACT_SPLIT "
@@ -299,6 +310,8 @@ static int report_device_status(gator_ctx* c, unsigned st, const char* fn, bool 
     return GATOR_OK;
 }
 static unsigned take_status_word(gator_ctx* c) { return c->status_host ? __atomic_exchange_n(c->status_host, 0u, __ATOMIC_RELAXED) : 0u; }
+
+extern "C" int gator_status_reason(gator_ctx* c) { return c ? c->status_reason : 0; }
 
 extern "C" int gator_device_status(gator_ctx* c, int32_t sync) {
     if (!c) return fail(GATOR_EINVAL, "gator_device_status: null ctx");
@@ -314,7 +327,7 @@ extern "C" int gator_device_status(gator_ctx* c, int32_t sync) {
 // Entry of every forward.  An earlier call's device status does NOT stop this one (round-4 advice: a NaN input pose, for which the
 // reference just returns NaN, must not make the next unrelated forward a no-op with stale output buffers, nor keep one rank of a
 // sharded run out of its collective): the word is taken here -- the persistent-launch failure already switches the ctx to four
-// launches for THIS call -- the call runs, and finish_fwd returns GATOR_EDEVICE once it is queued.
+// launches for THIS call -- the call runs, and finish_fwd returns GATOR_EDEVICE_DEFERRED once it is queued.
 static int check_fwd(gator_ctx* c, const void* a, const void* b, int B, const char* fn) {
     if (!c || !a || !b || B <= 0) return fail(GATOR_EINVAL, "%s: null pointer or batch <= 0", fn);
     if (const unsigned st = take_status_word(c)) {

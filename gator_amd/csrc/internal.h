@@ -93,6 +93,7 @@ struct gator_ctx {
     gator::FusedState* fused = nullptr;
     unsigned* status_host = nullptr;   // sticky device status (gator::DeviceStatus): pinned host word the kernels write ...
     unsigned* status_dev = nullptr;    // ... through this device pointer
+    int status_reason = 0;             // DeviceStatus of the last report (gator_status_reason)
     unsigned deferred_status = 0;      // an EARLIER call's status, taken by the running entry point and reported when it returns (api.hip: finish_fwd)
     // measurement hook (gator_profile_*): (stage name, start event, stop event) per launch
     bool profiling = false;       // StageTimer records only when set; forwards toggle it from prof_stride

@@ -113,11 +113,10 @@ class GAT(HipModule):
         """pose2d [B, 2J] (or [B,J,2]) -> (x_out [B,3J] mm, feat [B,J,C]);  lib/models/GAT.py:133-152."""
         x = self._prep(pose2d, 'GAT.forward')
         B = x.shape[0]
-        ctx = self._context(x.device)
         x_out = torch.empty((B, 3 * self.num_joint), device=x.device, dtype=torch.float32)
         feat = torch.empty((B, self.num_joint, self.embed_dim), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.load().gator_gat_forward_f32(ctx, x.data_ptr(), B, x_out.data_ptr(), feat.data_ptr(),
-                                                    self._stream(x.device)), 'gator_gat_forward_f32')
+        self._run(x.device, lambda ctx: _lib.load().gator_gat_forward_f32(ctx, x.data_ptr(), B, x_out.data_ptr(), feat.data_ptr(),
+                                                                         self._stream(x.device)), 'gator_gat_forward_f32', outputs=(x_out, feat))
         return x_out, feat
 
 

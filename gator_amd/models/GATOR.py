@@ -34,7 +34,6 @@ class GATOR(HipModule):
         fresh allocations."""
         x = self._prep(pose2d, 'GATOR.forward')
         B = x.shape[0]
-        ctx = self._context(x.device)
         if out is not None:
             verts, pose3d = out
             for t, shp in ((verts, (B, 6890, 3)), (pose3d, (B, self.num_joint, 3))):
@@ -43,8 +42,11 @@ class GATOR(HipModule):
         else:
             verts = torch.empty((B, 6890, 3), device=x.device, dtype=torch.float32)
             pose3d = torch.empty((B, self.num_joint, 3), device=x.device, dtype=torch.float32)
-        fn = _lib.load().gator_forward_bf16 if self.precision == 'bf16' else _lib.load().gator_forward_f32
-        _lib.check(fn(ctx, x.data_ptr(), B, verts.data_ptr(), pose3d.data_ptr(), self._stream(x.device)), 'gator_forward_' + self.precision)
+        def call(ctx):       # the 16-bit mode exists on the default operand forms only: a module healed to 'exact' (HipModule._run) runs fp32
+            lib = _lib.load()
+            fn = lib.gator_forward_bf16 if (self.precision == 'bf16' and self.arithmetic == 'default') else lib.gator_forward_f32
+            return fn(ctx, x.data_ptr(), B, verts.data_ptr(), pose3d.data_ptr(), self._stream(x.device))
+        self._run(x.device, call, 'gator_forward_' + self.precision, outputs=(verts, pose3d))
         return verts, pose3d
 
 
@@ -64,18 +66,21 @@ class GATOR(HipModule):
             raise RuntimeError('call set_joint_regressor() first')
         x = self._prep(pose2d, 'GATOR.forward_joints')
         B = x.shape[0]
-        ctx = self._context(x.device)
         lib = _lib.load()
         r, c, v, nj = self._jreg
-        if getattr(self, '_jreg_ctx', None) != ctx.value:
-            _lib.check(lib.gator_set_joint_regressor(ctx, r.ctypes.data, c.ctypes.data, v.ctypes.data, int(r.size), nj), 'gator_set_joint_regressor')
-            self._jreg_ctx = ctx.value
         joints = torch.empty((B, nj, 3), device=x.device, dtype=torch.float32)
         pose3d = torch.empty((B, self.num_joint, 3), device=x.device, dtype=torch.float32)
         verts = torch.empty((B, 6890, 3), device=x.device, dtype=torch.float32) if with_verts else None
-        _lib.check(lib.gator_forward_joints_f32(ctx, x.data_ptr(), B, joints.data_ptr(), pose3d.data_ptr(),
-                                                verts.data_ptr() if with_verts else None, self._stream(x.device)), 'gator_forward_joints_f32')
-        return (joints, pose3d, verts) if with_verts else (joints, pose3d)
+
+        def call(ctx):       # the regressor belongs to a context: (re-)registered when the context is new (first call, healed arithmetic)
+            if getattr(self, '_jreg_ctx', None) != ctx.value:
+                _lib.check(lib.gator_set_joint_regressor(ctx, r.ctypes.data, c.ctypes.data, v.ctypes.data, int(r.size), nj), 'gator_set_joint_regressor')
+                self._jreg_ctx = ctx.value
+            return lib.gator_forward_joints_f32(ctx, x.data_ptr(), B, joints.data_ptr(), pose3d.data_ptr(),
+                                                verts.data_ptr() if with_verts else None, self._stream(x.device))
+        res = (joints, pose3d, verts) if with_verts else (joints, pose3d)
+        self._run(x.device, call, 'gator_forward_joints_f32', outputs=res)
+        return res
 
 
 def get_model(num_joint, embed_dim, depth, graph_adj, GCN_depth, J_regressor, **kw):

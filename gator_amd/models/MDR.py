@@ -81,20 +81,18 @@ class MDR(HipModule):
         """x = cat(pose2d, pose3d/1000, feat) [B,J,133] -> vertices [B,6890,3] (m);  lib/models/MDR.py:124-170."""
         x = self._prep(x, 'MDR.forward')
         B = x.shape[0]
-        ctx = self._context(x.device)
         verts = torch.empty((B, 6890, 3), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.load().gator_mdr_forward_f32(ctx, x.data_ptr(), B, verts.data_ptr(), self._stream(x.device)),
-                   'gator_mdr_forward_f32')
+        self._run(x.device, lambda ctx: _lib.load().gator_mdr_forward_f32(ctx, x.data_ptr(), B, verts.data_ptr(), self._stream(x.device)),
+                  'gator_mdr_forward_f32', outputs=verts)
         return verts
 
     def upsample(self, vert431, precision='f32'):
         """upsample_conv + template add alone (MDR.py:167-168): [B,431,3] -> [B,6890,3]."""
         x = self._prep(vert431, 'MDR.upsample')
         B = x.shape[0]
-        ctx = self._context(x.device)
         verts = torch.empty((B, 6890, 3), device=x.device, dtype=torch.float32)
         fn = _lib.load().gator_upsample_bf16 if precision == 'bf16' else _lib.load().gator_upsample_f32
-        _lib.check(fn(ctx, x.data_ptr(), B, verts.data_ptr(), self._stream(x.device)), 'gator_upsample_' + precision)
+        self._run(x.device, lambda ctx: fn(ctx, x.data_ptr(), B, verts.data_ptr(), self._stream(x.device)), 'gator_upsample_' + precision, outputs=verts)
         return verts
 
 

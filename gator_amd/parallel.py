@@ -37,6 +37,8 @@ import contextlib
 
 import torch
 
+from ._lib import DeferredDeviceStatus
+
 
 class ShardedForward:
     def __init__(self, model, world_size=1, rank=0, dist=None, micro_batch=None, always_gather=False, mode='gather', depth=2,
@@ -166,6 +168,19 @@ class ShardedForward:
         if self.last_event is not None:
             torch.cuda.current_stream().wait_event(self.last_event)
 
+    @staticmethod
+    def _forward(fn, *a, **k):
+        """-> (outputs, deferred report or None).  A module with on_device_status = 'raise' hands an EARLIER forward's device status to the
+        caller as DeferredDeviceStatus (GATOR_EDEVICE_DEFERRED, include/gator_hip.h) on a call that WAS queued normally: the exception
+        carries that call's outputs, this rank goes on with them -- the other ranks are already in the collective -- and the report
+        is raised once every collective of the step is issued.  (The default, 'heal', never raises: gator_amd/models/_base.py.)"""
+        try:
+            return fn(*a, **k), None
+        except DeferredDeviceStatus as ex:
+            if ex.outputs is None:
+                raise
+            return ex.outputs, ex
+
     # ---- mode 'gather' ---------------------------------------------------------------------------------------------------
     def step(self, pose2d_shard):
         """pose2d_shard [B_local, J, 2] on this rank's GPU.
@@ -188,18 +203,11 @@ class ShardedForward:
                 free = self._stage_free.pop(key, None)
                 if free is not None:            # a staging slot is re-used: its last collective + copy-out must be done first
                     torch.cuda.current_stream(pose2d_shard.device).wait_event(free)
-                try:
-                    verts, pose3d = self.model(pose2d_shard[s:e], out=(mv, mp))
-                except RuntimeError as ex:
-                    # An EARLIER forward's device status (GATOR_EDEVICE, api.hip: finish_fwd) rides on a call that was queued normally:
-                    # this rank's rows are being written, so it still joins the collective -- the other ranks are already in it -- and
-                    # the report is raised once every collective of the step is issued.
-                    if 'THIS call was queued normally' not in str(ex):
-                        raise
-                    deferred, verts, pose3d = ex, mv, mp
+                (verts, pose3d), ex = self._forward(self.model, pose2d_shard[s:e], out=(mv, mp))
             else:
-                verts, pose3d = self.model(pose2d_shard[s:e])
+                (verts, pose3d), ex = self._forward(self.model, pose2d_shard[s:e])
                 verts, pose3d = verts.contiguous(), pose3d.contiguous()
+            deferred = deferred or ex
             side = self._gather_chunk(verts, pose3d, s, e, B, gv, gp, i)
             chunks.append((verts, pose3d, s, e, i))
         self._last = ('gather', (chunks, B, gv, gp))
@@ -250,14 +258,15 @@ class ShardedForward:
         B = pose2d_shard.shape[0]
         self._pin_encoder(min(B, self.micro or B), pose2d_shard.device)
         self._throttle(pose2d_shard.device)
-        acc = None
+        acc, deferred = None, None
         for s, e in self._plan(B):
             if fused:
-                joints, pose3d = self.model.forward_joints(pose2d_shard[s:e])
+                (joints, pose3d), ex = self._forward(self.model.forward_joints, pose2d_shard[s:e])
                 part = self._joint_metrics(joints, self._target, slice(s, e))
             else:
-                verts, pose3d = self.model(pose2d_shard[s:e])
+                (verts, pose3d), ex = self._forward(self.model, pose2d_shard[s:e])
                 part = fn(verts, pose3d, self._target, slice(s, e))
+            deferred = deferred or ex
             acc = part if acc is None else acc + part
         if self.dist is not None and (self.world > 1 or self.always_gather):
             ctx, side = self._side(acc.device)
@@ -268,6 +277,8 @@ class ShardedForward:
                 self.last_event = side.record_event()
             self._issued(self.last_event if side is not None else None)
             self._last = ('reduce', (acc,))
+        if deferred is not None:
+            raise deferred
         return acc
 
     # ---- measurement helper ---------------------------------------------------------------------------------------------

@@ -28,8 +28,14 @@ typedef struct gator_ctx gator_ctx;
 
 typedef enum { GATOR_OK = 0, GATOR_EINVAL = -1, GATOR_EMISSING = -2, GATOR_ESHAPE = -3, GATOR_EHIP = -4,
                GATOR_ENOMEM = -5, GATOR_EUNSUPPORTED = -6,
-               GATOR_EDEVICE = -7     /* a kernel of an EARLIER call flagged its result as invalid (gator_device_status) */
+               GATOR_EDEVICE = -7,    /* a kernel of an EARLIER call flagged its result as invalid (gator_device_status) */
+               GATOR_EDEVICE_DEFERRED = -8   /* the same report, riding on a forward that WAS queued normally: this call's outputs are being
+                                                written and are valid unless the next call reports again (gator_status_reason says why) */
 } gator_status;
+
+/* ABI 2 (round 6): gator_config starts with struct_size; forwards return GATOR_EDEVICE_DEFERRED instead of GATOR_EDEVICE when they carry
+ * an earlier call's report; gator_abi_version / gator_status_reason added.  A binding checks gator_abi_version() == GATOR_ABI_VERSION at load. */
+#define GATOR_ABI_VERSION 2
 
 typedef enum { GATOR_F32 = 0, GATOR_I64 = 1, GATOR_I32 = 2 } gator_dtype;
 
@@ -73,6 +79,9 @@ typedef enum { GATOR_PART_GAT = 1,    /* pose_lifter.*  (models.GAT.get_model us
 } gator_parts;
 
 typedef struct {
+    int32_t struct_size; /* = sizeof(gator_config) of the header the caller was built with.  Fields the caller's header does not have yet
+                            read as 0 (their defaults); a value that is not a multiple of 4 in [8, 1024] is refused (GATOR_EINVAL) -- which is
+                            what a caller built against the ABI-1 header (first field num_joint = 17 / 19) gets instead of a mis-read struct */
     int32_t num_joint;   /* 17 (Human3.6M) or 19 (COCO + pelvis + neck); lib/models/GAT.py:79-93 */
     int32_t alpha;       /* cfg.MODEL.alpha: LayerNorm(3)+scale head instead of BatchNorm1d(431); MDR.py:115-119,162 */
     int32_t impl;        /* gator_impl */
@@ -97,6 +106,10 @@ int gator_destroy(gator_ctx* ctx);
  * host-visible status word and reported by the NEXT entry point called on the ctx, once, as GATOR_EDEVICE (the affected vertices are NaN).  gator_device_status reports it on demand; sync != 0 waits for the device first
  * (the reference raises at the point of use, lib/core/base.py:210-237; this is the asynchronous equivalent). */
 int gator_device_status(gator_ctx* ctx, int32_t sync);
+/* Why the last GATOR_EDEVICE / GATOR_EDEVICE_DEFERRED of this ctx was returned: 1 = a persistent MDR launch did not finish (the ctx has switched to
+ * the four-launch form), 2 = non-finite / out-of-range coarse vertices (input poses not finite, or the default arithmetic's operand range:
+ * re-create the ctx with GATOR_ARITH_EXACT_SPLIT -- gator_amd/models/_base.py does exactly that by itself), 0 = none yet. */
+int gator_status_reason(gator_ctx* ctx);
 
 /* Replaces: GATOR.forward (lib/models/GATOR.py:16-22).
  *   pose2d [B,J,2] f32 device, contiguous  ->  verts [B,6890,3] f32 (metres), pose3d [B,J,3] f32 (mm).
@@ -239,6 +252,7 @@ int gator_verts_joints_relation(const float* joints, int32_t n_joint, const floa
 
 const char* gator_last_error(void);
 const char* gator_version(void);
+int gator_abi_version(void);      /* GATOR_ABI_VERSION of the library that is loaded */
 
 #ifdef __cplusplus
 }

@@ -143,6 +143,7 @@ def test_operand_range_violation_is_loud(key, gain):
     good = sd[key].clone()
     sd[key] = good * gain
     m.load_state_dict(sd)
+    m.on_device_status = 'raise'                            # the C ABI's behaviour (the module's default heals: next test)
     m = m.cuda()
     x = torch.from_numpy(synthetic.synthetic_pose2d(16, 17, seed=5)).cuda()
     v, p = m(x)
@@ -153,8 +154,53 @@ def test_operand_range_violation_is_loud(key, gain):
     m.device_status()                                       # reported once, then clear
     v2, _ = m(x)                                            # the ctx still accepts work
     torch.cuda.synchronize()
-    with pytest.raises(RuntimeError):
-        m(x)                                                # the forward after a bad one reports it without an explicit query
+    from gator_amd._lib import DeferredDeviceStatus
+    with pytest.raises(DeferredDeviceStatus) as ei:
+        m(x)                                                # the forward after a bad one reports it without an explicit query ...
+    assert ei.value.code == -8 and ei.value.reason == 2 and ei.value.outputs is not None      # ... as GATOR_EDEVICE_DEFERRED, its own outputs attached
+
+
+@pytest.mark.parametrize('key,gain', [('pose2mesh.encoder_1.mlp.fc1.weight', 3e4), ('pose_lifter.blocks.2.mlp.fc1.weight', 3e4)])
+def test_operand_range_violation_heals_by_itself(key, gain):
+    """Round-5 review item 4: the reference's forward never raises (lib/models/GATOR.py:16-22), so a drop-in must not either.  The weights
+    that break the default arithmetic's operand range, through the DEFAULT module: the first forward's vertices are NaN (nothing on the
+    host can know in time), the second one notices the report, switches the module to the exact-split arithmetic, re-runs its batch
+    there and returns the reference's numbers (criterion of test_exact_split_arithmetic_has_no_operand_range) -- with a warning, no
+    exception, and for every later call."""
+    import warnings
+    from oracle import gator_oracle as go
+    z, m = build_model('h36m17_bn', 'fused', device=None)
+    zz, c, sd_o = oracle_setup('h36m17_bn')
+    sd = m.state_dict()
+    sd[key] = sd[key] * gain
+    sd_o[key] = sd_o[key] * gain
+    m.load_state_dict(sd)
+    m = m.cuda()
+    assert m.arithmetic == 'default' and m.on_device_status == 'heal'
+    x = torch.from_numpy(synthetic.synthetic_pose2d(16, 17, seed=5))
+    v0, _ = m(x.cuda())
+    torch.cuda.synchronize()
+    assert not torch.isfinite(v0).all()                    # the one forward the device could not warn about in time
+    out = (torch.empty(16, 6890, 3, device='cuda'), torch.empty(16, 17, 3, device='cuda'))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        v, p = m(x.cuda(), out=out)                         # heals: same output tensors, exact arithmetic
+        torch.cuda.synchronize()
+    assert any('exact' in str(i.message) for i in w) and m.arithmetic == 'exact'
+    assert v.data_ptr() == out[0].data_ptr() and torch.isfinite(v).all() and torch.isfinite(p).all()
+    r64, _ = go.gator_forward(sd_o, c, x, torch.float64)
+    r32, _ = go.gator_forward(sd_o, c, x, torch.float32)
+    scale = float(r64.abs().max())
+    ours = float(np.abs(v.cpu().numpy().astype(np.float64) - r64.numpy()).max()) / scale
+    ref = float(np.abs(r32.numpy().astype(np.float64) - r64.numpy()).max()) / scale
+    print('\n[%s x %g, healed] |ours - fp64| / max|v| = %.2e, reference arithmetic %.2e' % (key, gain, ours, ref))
+    assert ours <= max(2e-6, 2.0 * ref)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        v3, _ = m(x.cuda())                                 # and stays healed, silently
+        torch.cuda.synchronize()
+    assert not w and torch.equal(v3, v)
+    m.device_status()
 
 
 @pytest.mark.parametrize('key,gain', [('pose2mesh.encoder_1.mlp.fc1.weight', 3e4), ('pose_lifter.blocks.2.mlp.fc1.weight', 3e4)])

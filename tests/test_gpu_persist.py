@@ -96,6 +96,7 @@ def test_unserved_queue_is_loud_and_the_ctx_falls_back(monkeypatch):
     monkeypatch.setenv('GATOR_MDR_PERSIST', '1')
     monkeypatch.setenv('GATOR_MDR_PERSIST_GRID', '3')
     z, m = build_model('h36m17_bn', 'fused')
+    m.on_device_status = 'raise'
     v, p = m(x)
     torch.cuda.synchronize()
     bad = ~torch.isfinite(v).reshape(40, -1).all(1)

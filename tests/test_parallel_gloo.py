@@ -26,16 +26,19 @@ class _FakeModel:                           # the module surface ShardedForward 
 
     def __call__(self, x, out=None):
         v, p = _fake_forward(x)
-        if out is None:
-            return v, p
-        assert out[0].is_contiguous() and out[1].is_contiguous() and out[0].shape == v.shape and out[1].shape == p.shape
-        out[0].copy_(v)
-        out[1].copy_(p)
-        self.out_ptrs.append(out[0].data_ptr())
-        if self.report_next:                 # like gator_forward_f32 after an earlier bad forward: the work is queued, THEN the report is raised
-            self.report_next = False
-            raise RuntimeError('gator_forward_f32 failed (-6): an earlier forward on this ctx produced non-finite ... THIS call was queued normally; ...')
-        return out
+        if out is not None:
+            assert out[0].is_contiguous() and out[1].is_contiguous() and out[0].shape == v.shape and out[1].shape == p.shape
+            out[0].copy_(v)
+            out[1].copy_(p)
+            self.out_ptrs.append(out[0].data_ptr())
+            v, p = out
+        if self.report_next:                 # like gator_forward_f32 after an earlier bad forward with on_device_status = 'raise': the work is
+            self.report_next = False         # queued, THEN the report is raised with the call's outputs attached (gator_amd/models/_base.py: _run)
+            from gator_amd._lib import DeferredDeviceStatus
+            ex = DeferredDeviceStatus('gator_forward_f32 failed (-8): an earlier forward on this ctx produced non-finite ...')
+            ex.reason, ex.outputs = 2, (v, p)
+            raise ex
+        return v, p
 
     report_next = False
 
@@ -64,7 +67,8 @@ def _worker(rank, world, port, micro, mode, q, in_place=True):
     n = 6
     ok = True
     if mode == 'deferred':                   # one rank's forward reports an earlier call's device status: nobody may hang in the collective
-        model = _FakeModel(True)
+        from gator_amd._lib import DeferredDeviceStatus
+        model = _FakeModel(in_place)
         run = ShardedForward(model, world, rank, dist, micro_batch=micro)
         for step in range(3):
             torch.manual_seed(step)
@@ -73,12 +77,33 @@ def _worker(rank, world, port, micro, mode, q, in_place=True):
             raised = False
             try:
                 gv, gp = run.step(full[rank * n:(rank + 1) * n])
-            except RuntimeError as ex:
-                raised = 'THIS call was queued normally' in str(ex)
+            except DeferredDeviceStatus as ex:
+                raised = ex.code == -8
                 gv, gp = run._last[1][2], run._last[1][3]
             rv, rp = _fake_forward(full)
             ok = ok and raised == (rank == 1 and step == 1)
             ok = ok and bool(torch.equal(gv, rv)) and bool(torch.equal(gp, rp))     # every rank, incl. the reporting one, holds the full gather
+    elif mode == 'deferred_eval':            # the same in evaluation mode: the reporting rank still joins the all-reduce
+        from gator_amd._lib import DeferredDeviceStatus
+        model = _FakeModel(False)
+        torch.manual_seed(0)
+        tgt = torch.randn(world * n, 17, 3)
+        run = ShardedForward(model, world, rank, dist, micro_batch=micro, mode='eval', metrics_fn=_fake_metrics)
+        run.set_eval(None, tgt[rank * n:(rank + 1) * n])
+        for step in range(3):
+            torch.manual_seed(step + 1)
+            full = torch.randn(world * n, 17, 2)
+            model.report_next = rank == 1 and step == 1
+            raised = False
+            try:
+                got = run.step(full[rank * n:(rank + 1) * n])
+            except DeferredDeviceStatus:
+                raised = True
+                got = run._last[1][0]
+            v, p = _fake_forward(full)
+            want = _fake_metrics(v, p, tgt, slice(0, world * n))
+            ok = ok and raised == (rank == 1 and step == 1)
+            ok = ok and bool(torch.allclose(got, want, rtol=1e-12, atol=0))
     elif mode == 'gather':
         model = _FakeModel(in_place)
         run = ShardedForward(model, world, rank, dist, micro_batch=micro)
@@ -142,6 +167,11 @@ def test_allgather_microbatched_ragged():
 def test_deferred_device_status_does_not_strand_the_other_ranks():
     _run(None, 'deferred')
     _run(4, 'deferred')
+
+
+def test_deferred_device_status_model_without_out_argument_and_eval_mode():
+    _run(4, 'deferred', in_place=False)      # every branch of step() keeps the reporting rank in the collective
+    _run(4, 'deferred_eval')
 
 
 def test_allgather_model_without_out_argument():
