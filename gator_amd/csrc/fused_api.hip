@@ -133,6 +133,8 @@ int fused_create_gat(gator_ctx* c, FusedState* f, void* stream) {
         f->gat_x3 = !(e && atoi(e) == 0);
         const char* te = getenv("GATOR_GAT_TAIL");
         f->gat_split_tail = !(te && atoi(te) == 0);
+        const char* t8 = getenv("GATOR_GAT8_TAIL");
+        f->gat8_tail = !(t8 && atoi(t8) == 0);
         if (f->gat_x3) {
             const int64_t ntiles = (p - f->gblk[0].qkv) / kTile;
             GATOR_HIP_CHECK(hipMalloc(&f->gxbuf, (size_t)ntiles * kTileX3 * sizeof(float)));
@@ -338,6 +340,13 @@ int fused_create(gator_ctx* c, void* stream) {
         rc = fused_pack_linear(w.jfeat_w + 5, 133, 1, 64, 128, d128, stream);
         if (rc) return rc;
         f->jfeat128_p = d128;
+        if (f->mdr_x3 == 2) {      // the same eight tiles as three fp16 planes under their own power-of-two scale (k_gat8's fused tail, gat_roles.hip)
+            float left = 0.f;
+            GATOR_HIP_CHECK(hipMalloc(&f->jf128_h3, (size_t)8 * kTileX3 * sizeof(float)));
+            rc = fused_repack_h3(d128, f->jf128_h3, 8, &f->jf128_wshift, &left, stream);
+            if (rc == GATOR_OK && left > 1e-7f) { (void)hipFree(f->jf128_h3); f->jf128_h3 = nullptr; }      // (the two tail launches stay)
+            if (rc) return rc;
+        }
         const std::vector<float> jw = d2h(w.jfeat_w, 64 * 133);
         std::vector<float> j5(5 * 64);
         for (int i = 0; i < 5; ++i)
@@ -399,6 +408,7 @@ void fused_destroy(gator_ctx* c) {
     if (c->fused->g8stream) (void)hipFree(c->fused->g8stream);
     if (c->fused->g8stream_b) (void)hipFree(c->fused->g8stream_b);
     if (c->fused->wxbuf) (void)hipFree(c->fused->wxbuf);
+    if (c->fused->jf128_h3) (void)hipFree(c->fused->jf128_h3);
     if (c->fused->up_w16) (void)hipFree(c->fused->up_w16);
     if (c->fused->blk_tap) (void)hipFree(c->fused->blk_tap);
     for (void* p : {c->fused->jr_blk, c->fused->jr_ent, (void*)c->fused->jr_w, (void*)c->fused->jr_rowptr, (void*)c->fused->jr_P})
@@ -623,19 +633,24 @@ static int fused_forward_one(gator_ctx* c, const float* pose2d, int B, float* ve
     // GATOR_GAT_TILED=0 keeps every batch on k_gat (bitwise batch invariance at any size), =1 forces the tiled kernel.
     const int n_tiled = fused_tiled_samples(c, B);
     const bool tiled = n_tiled > 0;
+    const bool enc16 = bf16 && f->c3_encoder && f->gat_x3 && f->gat8 && f->gat8_h4 && f->gat_tiled_h4 && f->g8stream != nullptr;
+    const bool fused_tail = n_tiled < B && f->gat8_tail && f->gat_split_tail && f->gat_x3 && gat8_tail_supported(c, f, enc16);
+    float* tail_jkv = nullptr;
     {   // x_out [B,3J] IS pose3d [B,J,3]: the tail writes the caller's buffer and produces the MDR joint K/V
         StageTimer tm(c, "gat", stream);
-        const bool enc16 = bf16 && f->c3_encoder && f->gat_x3 && f->gat8 && f->gat8_h4 && f->gat_tiled_h4 && f->g8stream != nullptr;
         if (n_tiled > 0) rc = launch_gat_tiled(c, f, pose2d, n_tiled, f->feat, stream, B, enc16);
         if (rc == GATOR_OK && n_tiled < B) {
             const size_t o = (size_t)n_tiled * c->J;
-            rc = launch_gat(c, f, pose2d + o * 2, B - n_tiled, pose3d + o * 3, f->feat + o * kC, stream, true, B, n_tiled, enc16);
+            // k_gat8 with the lifter + joint tokens of its samples as its epilogue (round 6); the sample-tiled part keeps the two launches
+            if (fused_tail) tail_jkv = f->jkv + (size_t)n_tiled * 12 * kTile;
+            rc = launch_gat(c, f, pose2d + o * 2, B - n_tiled, pose3d + o * 3, f->feat + o * kC, stream, true, B, n_tiled, enc16, tail_jkv);
         }
     }
     if (rc) return rc;
-    if (f->gat_split_tail || tiled) {   // lifter + MDR joint tokens as two batched launches (gat_tail.hip)
+    const int n_tail = fused_tail ? n_tiled : ((f->gat_split_tail || tiled) ? B : 0);
+    if (n_tail > 0) {   // lifter + MDR joint tokens as two batched launches (gat_tail.hip)
         StageTimer tm(c, "gat_tail", stream);
-        rc = launch_gat_tail(c, f, pose2d, f->feat, B, pose3d, stream, true);
+        rc = launch_gat_tail(c, f, pose2d, f->feat, n_tail, pose3d, stream, true, !fused_tail);
         if (rc) return rc;
     }
     c->set_tap(TAP_FEAT, f->feat, (int64_t)B * c->J * kC);

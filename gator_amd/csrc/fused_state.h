@@ -66,6 +66,7 @@ struct FusedState : FusedWs {
     int gat_tiled_wshift = 0;
     float* g8stream = nullptr;          // the same tiles as four per-wave streams in consumption order (gat_roles.hip)
     bool gat8 = true;                   // one-sample-per-workgroup encoder: the two-role kernel k_gat8 (GATOR_GAT8=0: k_gat)
+    bool gat8_tail = true;              // k_gat8 runs the lifter and the MDR joint tokens as its epilogue (round 6; GATOR_GAT8_TAIL=0: the two launches of gat_tail.hip)
     bool gat8_h4 = true;                // ... with its token-wise products on four partial products (x3_common.h; GATOR_GAT8_H4=0: the exact six)
     float* g8stream_b = nullptr;        // ... and its byte-lo image (H3B tiles, 5 KiB: gat_roles.hip), what k_gat8<true, LR, false, true> streams
     bool gat8_lobyte = false;           // set when every weight's lo plane survives the byte round trip (always, for finite weights; GATOR_GAT8_LOBYTE=0: off)
@@ -74,6 +75,8 @@ struct FusedState : FusedWs {
     int mdr_persist = -1;               // the four MDR stages as ONE persistent launch (k_mdr_persist): -1 by batch size (launch_mdr), GATOR_MDR_PERSIST=0 never, =1 always
     int mdr_persist_chunk = 0;          // GATOR_MDR_PERSIST_CHUNK: most samples per persistent launch (0: 384)
     int mdr_persist_grid = 0;           // GATOR_MDR_PERSIST_GRID: workgroups of the persistent launch (0: two per CU)
+    float* jf128_h3 = nullptr;          // get_joint_feature columns 5..132 as H3 tiles [2][4] of 2^jf128_wshift * w (k_gat8's fused tail)
+    int jf128_wshift = 0;
     int mdr_wshift = 0;                 // GATOR_MDR_X3=2: wxbuf holds three fp16 planes of 2^mdr_wshift * w
     int mdr_x3 = 2;                     // GATOR_MDR_X3: 0 fp32-input MFMA; 1 exact bf16 x 3 split everywhere; 2 (default) that + the 431x431 attention on two fp16 planes
     bool c3_mdr = true;                 // gator_forward_bf16 (BASELINE config 3): the MDR layers on one fp16 activation plane (GATOR_C3_MDR=0: fp32 form)
@@ -134,18 +137,20 @@ int launch_upsample(const FusedState* f, const gator_ctx* c, int B, float* verts
 int gat_prepare_device();
 int gat_ensure_blk_tap(gator_ctx* c, FusedState* f, int B);
 int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue = false,
-               int B_total = 0, int tap_row0 = 0, bool half16 = false);      // half16: the one-plane form of the two-role kernel (config 3); other forms ignore it
+               int B_total = 0, int tap_row0 = 0, bool half16 = false, float* tail_jkv = nullptr);      // half16: the one-plane form of the two-role kernel (config 3); other forms ignore it
 // gat_roles.hip
 int gat8_prepare_device();
 int gat8_build_stream(FusedState* f, void* stream);
-int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total = 0, int tap_row0 = 0, bool half16 = false);
+int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total = 0, int tap_row0 = 0, bool half16 = false,
+                float* tail_x_out = nullptr, float* tail_jkv = nullptr, int ctr_B = 0);
+bool gat8_tail_supported(const gator_ctx* c, const FusedState* f, bool half16);
 // gat_tiled.hip
 int gat_tiled_prepare_device();
 int gat_tiled_samples_per_wg(int J);
 int launch_gat_tiled(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total = 0, bool half16 = false);
 // gat_tail.hip
 size_t gat_tail_part_floats(int B, int J);
-int launch_gat_tail(gator_ctx* c, FusedState* f, const float* pose2d, const float* feat, int B, float* x_out, void* stream, bool joint);
+int launch_gat_tail(gator_ctx* c, FusedState* f, const float* pose2d, const float* feat, int B, float* x_out, void* stream, bool joint, bool zero_ctr = true);
 // upsample_bf16.hip
 size_t upsample_bf16_weight_elems();
 size_t upsample_bf16_vcp_elems(int B);

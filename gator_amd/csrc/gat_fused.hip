@@ -680,7 +680,7 @@ int gat_ensure_blk_tap(gator_ctx* c, FusedState* f, int B) {
 }
 
 int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x_out, float* feat, void* stream, bool joint_epilogue,
-               int B_total, int tap_row0, bool half16) {
+               int B_total, int tap_row0, bool half16, float* tail_jkv) {
     GatArgs a;
     const Weights& w = c->w;
     a.B = B; a.J = c->J; a.pose2d = pose2d;
@@ -738,7 +738,8 @@ int launch_gat(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* x
 #ifdef GATOR_DIAG
         if (d_st) GATOR_HIP_CHECK(hipFree(d_st));                                         // (it prints its own stamps)
 #endif
-        return launch_gat8(c, f, pose2d, B, feat, stream, B_total, tap_row0, half16);
+        // tail_jkv: k_gat8 runs the lifter + joint tokens of ITS samples as its epilogue (and zeroes the MDR counters of the whole forward)
+        return launch_gat8(c, f, pose2d, B, feat, stream, B_total, tap_row0, half16, tail_jkv ? x_out : nullptr, tail_jkv, tail_jkv ? (B_total > 0 ? B_total : B) : 0);
     }
     if (split_tail) {
         if (f->gat_x3) k_gat<true, false><<<B, 256, kGatLdsX3, (hipStream_t)stream>>>(a);

@@ -69,6 +69,23 @@ enum { V_N1W = 0, V_N1B = 128, V_QKVB = 256, V_PROJB = 640, V_GCNB = 768, V_LIN0
        V_N2B = 1280, V_FC1B = 1408, V_FC2B = 1920 };
 
 struct Gat8Blk { const float *back32, *mc, *mdT, *aoffT, *f1b, *vecs; };
+// Epilogue of k_gat8<..., TAIL = true> (round 6): what gat_tail.hip's two launches do for the batch, done by the workgroup that owns
+// the sample and has its feat on chip.
+struct Gat8Tail {
+    const float *lifter_w, *lifter_b;       // lifter.weight [3J][128J] as the reference stores it, bias [3J]  (GAT.py:151-152)
+    float* x_out;                           // [B][3J] = pose3d [B][J][3] (mm)
+    float* jkv;                             // nullptr: lifter only (stand-alone GAT entry point)
+    unsigned* mdr_ctr;                      // non-null: zero k_mdr_persist's tickets / completion counts of the forward (as k_gat_joint does)
+    int ctr_B;                              //           ... of a forward of ctr_B samples (mdr_ctr_words)
+    const float *jf5, *jf_h3, *jf_b, *posj_T;      // get_joint_feature: columns 0..4 as [5][64], columns 5..132 as H3 tiles [2][4], bias; pos_j tiles
+    const float *j_n1w[3], *j_n1b[3], *j_wk_h3[3], *j_wv_h3[3];      // per LBF layer: norm1, wk / wv as H3 tiles [2][2] (the MDR layers' own weight image)
+    const float *jf_p, *j_wk_p[3], *j_wv_p[3];     // the same weights as packed fp32 tiles (GAT8_TAIL_F32: fp32-input MFMA forms of the two linears)
+    float jf_inv, kv_inv;                          // 1 / (16 x 2^weight shift) of the two H3 weight sets (x3_common.h: four-product linears)
+#ifdef GATOR_DIAG
+    unsigned long long* tstamps;                   // [8 waves][8] s_memtime stamps of workgroup B/2's epilogue (GATOR_GAT_STAMPS)
+#endif
+    int warm_n;                                    // L2 warm-up of the epilogue's weights: workgroups per XCD that share it (0: off)
+};
 
 struct Gat8Args {
     int B, J;
@@ -82,6 +99,7 @@ struct Gat8Args {
     int tapB;
     float* blk_tap;
     float lin_inv;                   // H4 form: 1 / (16 x 2^weight shift), the factor every raw product tile carries
+    Gat8Tail tl;                     // k_gat8<..., TAIL = true>: the lifter and the MDR joint tokens as the kernel's epilogue
     int pf_n, pf_loads;              // L2 warm-up of the next block's weights: workgroups per XCD that share it, 8 KiB touches per helper wave (0: off)
 #ifdef GATOR_DIAG
     unsigned long long* stamps;      // [2 roles][kDepth][23 steps][work, wait]
@@ -500,8 +518,8 @@ __device__ __forceinline__ void tile_mma_refill(H3B& w, const X2& b, f32x16& acc
 #undef GAT8_MM
 }
 // floats from one tile of a wave's stream to the next
-template <class WT> struct WTile { static constexpr int floats = kTileX3; };
-template <> struct WTile<H3B> { static constexpr int floats = kTileH3B; };
+template <class WT> struct StreamTile { static constexpr int floats = kTileX3; };
+template <> struct StreamTile<H3B> { static constexpr int floats = kTileH3B; };
 // one k-step of the two-plane product (x3_common.h: x2_mma does both): lo*hi | hi*lo | hi*hi
 __device__ __forceinline__ f32x16 x2_mma_step(const X2& A, const X2& B, int s, f32x16 acc) {
     acc = GATOR_MFMA_F16(A.p[1][s], B.p[0][s], acc);
@@ -546,7 +564,7 @@ __device__ __forceinline__ void unit4(WT (&W)[kNT], const float* __restrict__& w
         OT bn = b;
         if (kb < 3) ld_opnd<SWZ>(bn, ops[kb + 1], lane);
         tile_mma_refill<CL>(W[(S0 + kb) % kNT], b, acc, acs, wp, lane);
-        wp += WTile<WT>::floats;
+        wp += StreamTile<WT>::floats;
         b = bn;
     }
     if constexpr (!std::is_same<WT, X3>::value) acc = acc + acs;
@@ -559,7 +577,7 @@ __device__ __forceinline__ void unit1(WT (&W)[kNT], const float* __restrict__& w
     OT b;
     ld_tile(b, o0, lane);
     tile_mma_refill<true>(W[S0 % kNT], b, acc, acs, wp, lane);
-    wp += WTile<WT>::floats;
+    wp += StreamTile<WT>::floats;
     if constexpr (!std::is_same<WT, X3>::value) acc = acc + acs;
     store_block(raw, lane, acc);
 }
@@ -570,17 +588,277 @@ __device__ __forceinline__ void skip_pad(WT (&W)[kNT], const float* __restrict__
 #pragma unroll
     for (int i = 0; i < kPadTiles; ++i) {
         ld_tile(W[(S0 + i) % kNT], wp, lane);
-        wp += WTile<WT>::floats;
+        wp += StreamTile<WT>::floats;
+    }
+}
+
+
+// ---- epilogue (TAIL): lifter Linear(128J -> 3J) (GAT.py:151-152), MDR joint tokens and the three layers' cross-attention K / V
+// operand tiles (MDR.py:130-134,37-38,65) -- formerly k_gat_lifter + k_gat_joint (gat_tail.hip: 5.7 + 16.4 us and two launch
+// boundaries at B = 256, with ~2 MFLOP per sample between them; those launches stay for the sample-tiled encoder).  This workgroup owns
+// the sample and ends with its feat on chip:
+//   lifter       a 3J x 128J matrix-vector product: 444 KB (J = 17) of fp32 weights per sample that nobody on the CU can share, i.e.
+//                a stream like the rest of this kernel.  All eight waves walk rows o = wave + 8 r as coalesced 1 KiB loads (lane l owns
+//                k = 256 i + 4 l), exact fp32 FMAs against feat held in registers (read once from the T-layout tiles in X), one DPP
+//                reduction per row.  (The product waves idle from barrier 20 of the last block on, but rows fetched ahead there would live beside the five
+//                weight-stream tiles the block loop carries: 140 - 430 B per lane of scratch.  They stage the small operands instead.)  Fixed order: results do not depend on the batch.
+//   joint tokens jf = Linear(133 -> 64)(cat(pose2d, pose3d / 1000, feat)) + pos_j: the 128 feat columns do not need pose3d, so product waves
+//                0 / 1 (whose share of the rows is the smaller one) contract them behind their last rows; the five other columns are FMAs
+//                once pose3d is known.  Then LayerNorm per layer and the 12 (layer, K | V, channel block) jobs, two on each of the other
+//                six waves, their weight tiles requested behind the last lifter rows (same operand tiles out as k_gat_joint: two fp16
+//                planes of 16 x value).  These token-wise linears run as every other one of the
+//                default arithmetic does -- weights exact on three fp16 planes, activations on two, four partial products -- instead of
+//                k_gat_joint's fp32-input MFMAs: measured with the MFMAs cut out (GAT8_TAIL_CUT), the 32-MFMA fp32 chains of the K / V jobs
+//                alone were 6.5 us of the epilogue's 15.
+// LDS: the operand tiles A | Bq are dead after barrier 20 of the last block.
+constexpr int kTP = kA;                                 // the joint tokens without their pose3d columns (2 channel blocks, token on the lane)
+constexpr int kTPosj = kTP + 2 * kTile;                 // pos_j tiles (2)
+constexpr int kTVJ = kTPosj + 2 * kTile;                // per-channel vectors
+constexpr int kTXO = kTVJ + 768;                        // pose3d of the sample (3J <= 64 floats)
+enum { TVJ_JFB = 0, TVJ_JF5 = 64, TVJ_N1W = 384, TVJ_N1B = 576, TVJ_TOTAL = 768 };      // jf bias | jf columns 0..4 [5][64] | norm1 w / b [3 layers][64]
+static_assert(kTXO + 64 <= kR, "the epilogue's LDS lives in the dead operand tiles");
+
+#ifndef GAT8_TAIL_F32
+#define GAT8_TAIL_F32 0              // 1: joint-token linear on the fp32-input MFMA (exact products), 2: the K / V jobs too  (A/B of the epilogue's arithmetic)
+#endif
+#ifndef GAT8_TAIL_CUT
+#define GAT8_TAIL_CUT 0              // timing experiments only (tools/build_variant.py ... -DGAT8_TAIL_CUT=n): 1 no lifter loads, 2 no joint-token MFMAs, 4 no K / V MFMAs, 8 lifter only, 16 no L2 warm-up of the lifter weight
+#endif
+__device__ __forceinline__ float dpp_add(float s, int ctrl_tag) {
+    const int u = __builtin_bit_cast(int, s);
+    int m;
+    if (ctrl_tag == 0) m = __builtin_amdgcn_update_dpp(u, u, 0xB1, 0xf, 0xf, false);            // quad_perm [1,0,3,2]
+    else if (ctrl_tag == 1) m = __builtin_amdgcn_update_dpp(u, u, 0x4E, 0xf, 0xf, false);       // quad_perm [2,3,0,1]
+    else if (ctrl_tag == 2) m = __builtin_amdgcn_update_dpp(u, u, 0x141, 0xf, 0xf, false);      // row_half_mirror
+    else m = __builtin_amdgcn_update_dpp(u, u, 0x140, 0xf, 0xf, false);                         // row_mirror
+    return s + __builtin_bit_cast(float, m);
+}
+// sum over the 64 lanes, the same value (and the same association) in every lane
+__device__ __forceinline__ float wave_sum64(float s) {
+    s = dpp_add(s, 0); s = dpp_add(s, 1); s = dpp_add(s, 2); s = dpp_add(s, 3);      // every lane: the total of its row of 16
+    const int u = __builtin_bit_cast(int, s);
+    const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0)), t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16)),
+                t2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32)), t3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48));
+    return (t0 + t1) + (t2 + t3);
+}
+// one row of the lifter weight: NI - 1 full 1 KiB chunks and a half chunk (K = 128 J = 256 (NI - 1) + 128 for J = 17, 19)
+template <int NI>
+struct LiftRow { f32x4 w[NI]; };
+template <int NI>
+__device__ __forceinline__ void lift_load(LiftRow<NI>& r, const float* __restrict__ wrow, int lane, bool live) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) r.w[i] = (!(GAT8_TAIL_CUT & 1) && live && (i < NI - 1 || lane < 32)) ? *reinterpret_cast<const f32x4*>(wrow + 256 * i + 4 * lane) : z;
+}
+template <int NI>
+__device__ __forceinline__ float lift_dot(const LiftRow<NI>& r, const f32x4 (&f)[NI]) {
+    f32x2 acc = {0.f, 0.f};                               // two chains of packed FMAs (components 0, 2 | 1, 3), fixed order
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        acc = pk_fma(f32x2{r.w[i][0], r.w[i][1]}, f32x2{f[i][0], f[i][1]}, acc);
+        acc = pk_fma(f32x2{r.w[i][2], r.w[i][3]}, f32x2{f[i][2], f[i][3]}, acc);
+    }
+    return wave_sum64(acc[0] + acc[1]);
+}
+constexpr int kLiftPre = 2;          // rows per batch; two batches in registers (one being multiplied, one in flight)
+
+#ifdef GATOR_DIAG
+#define GAT8_TSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (tl.tstamps && b == 32 && lane == 0) tl.tstamps[v8 * 8 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GAT8_TSTAMP(k)
+#endif
+// HELPER: the calling wave is helper w (holds channel block w of feat in `y`); else product wave w.
+template <int LR, bool HELPER>
+__device__ __forceinline__ void gat8_tail(const Gat8Tail& tl, const float* pose2d, float* lds, int b, int J, int w, int lane) {
+    constexpr int NI = LR == 10 ? 9 : 10;
+    const int h = lane >> 5, tok = lane & 31, tkj = tok < J ? tok : 0;
+    const int v8 = HELPER ? w : 4 + w;                        // row phase of this wave (phases 0 .. 2 own one row more: the helpers', who have nothing else here)
+    const int K = kC * J, R = 3 * J;
+    const float* X = lds + kXo;                               // feat as four T-layout tiles, zero for the tokens that do not exist (stored before barrier 22)
+    float* P = lds + kTP;
+    const float* VJ = lds + kTVJ;
+    float* XO = lds + kTXO;
+    const bool joint = tl.jkv != nullptr && !(GAT8_TAIL_CUT & 8);
+    // who does what besides its lifter rows: product waves 0 / 1 the feat columns of the joint-token linear (channel block w, all of K = 128);
+    // the other six waves two K / V jobs each
+    const bool jf_wave = !HELPER && w < 2 && joint;
+    // K / V jobs (layer li, k | v, channel block nb) = 2 pair + nb, pair = 2 li + kv: helper w both blocks of pair w, product wave w block
+    // w & 1 of pair 4 + (w >> 1) -- three jobs on every SIMD, and a wave's jobs share their operand (one layer's LayerNorm)
+    const int pair = HELPER ? w : 4 + (w >> 1), li = pair >> 1, kv = pair & 1;
+    const int job0 = HELPER ? 2 * w : 8 + w, njob = HELPER ? 2 : 1;
+    GAT8_TSTAMP(0);
+    const float bias_r = (lane < 8 && v8 + 8 * lane < R) ? tl.lifter_b[v8 + 8 * lane] : 0.f;      // lane r: the bias of row v8 + 8 r
+    const float* wbase = tl.lifter_w + (size_t)v8 * K;
+    // rows r = 0 .. 7 of this wave in batches of kLiftPre, the next batch in flight while the current one is multiplied
+    constexpr int NB = 8 / kLiftPre;
+    LiftRow<NI> cur[kLiftPre], nxt[kLiftPre];
+#pragma unroll
+    for (int q = 0; q < kLiftPre; ++q) lift_load(cur[q], wbase + (size_t)(8 * q) * K, lane, v8 + 8 * q < R);
+    GAT8_TSTAMP(1);
+    f32x4 f[NI];                                              // feat[k], k = 256 i + 4 lane: token 2 i + (lane >> 5), channels 4 (lane & 31) ..
+    {
+        const int c = 4 * (lane & 31);
+        const float* fx = X + (c >> 5) * kTile + (((c & 31) >> 3) * 64 + 32 * ((c >> 2) & 1)) * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = 2 * i + (lane >> 5);
+            f[i] = *reinterpret_cast<const f32x4*>(fx + (j < J ? j : 0) * 4);
+        }
+    }
+    auto job_tile = [&](int job, int i) {
+        const int li = job >> 2, kv = (job >> 1) & 1, nb = job & 1;
+        return h3_load((kv ? tl.j_wv_h3[li] : tl.j_wk_h3[li]) + (size_t)(nb * 2 + i) * kTileX3, lane);
+    };
+    // the weights of what follows the lifter are requested behind the last batch of rows, so that they ride in the same stream
+    H3 wt[4];                                                 // jf wave: its channel block's four k tiles; K / V wave: [job][k block]
+    float p2x = 0.f, p2y = 0.f;
+    float res = 0.f;
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {
+        if (bt + 1 < NB) {
+#pragma unroll
+            for (int q = 0; q < kLiftPre; ++q) {
+                const int r = (bt + 1) * kLiftPre + q;
+                lift_load(nxt[q], wbase + (size_t)(8 * r) * K, lane, v8 + 8 * r < R);
+            }
+        }
+        auto tail_tiles = [&](int i0) {       // two of the four weight tiles of what follows (requested while the last rows are multiplied)
+            if (jf_wave) {
+#pragma unroll
+                for (int kb = i0; kb < i0 + 2; ++kb) wt[kb] = h3_load(tl.jf_h3 + (size_t)(w * 4 + kb) * kTileX3, lane);
+            } else if (i0 < 2 * njob) {
+#pragma unroll
+                for (int i = i0; i < i0 + 2; ++i) wt[i] = job_tile(job0 + (i >> 1), i & 1);
+            }
+        };
+        if (bt + 1 == NB && joint) {
+            tail_tiles(0);
+            p2x = pose2d[((size_t)b * J + tkj) * 2];
+            p2y = pose2d[((size_t)b * J + tkj) * 2 + 1];
+        }
+#pragma unroll
+        for (int q = 0; q < kLiftPre; ++q) {
+            const int r = bt * kLiftPre + q;
+            const float tot = lift_dot(cur[q], f);
+            res = lane == r ? tot : res;
+            if (bt + 1 == NB && q == 0 && joint) { __builtin_amdgcn_sched_barrier(0); tail_tiles(2); }      // (this row's registers are free now)
+        }
+        if (bt + 1 < NB) {
+#pragma unroll
+            for (int q = 0; q < kLiftPre; ++q) cur[q] = nxt[q];
+        }
+    }
+    GAT8_TSTAMP(2);
+    // x_out[o] = bias[o] + sum_k W[o][k] feat[k]
+    if (lane < 8 && v8 + 8 * lane < R) {
+        const float xo = res + bias_r;
+        tl.x_out[(size_t)b * R + v8 + 8 * lane] = xo;
+        XO[v8 + 8 * lane] = xo;
+    }
+    if (!joint) return;
+    if (jf_wave) {
+        // jf without its pose3d columns: bias + pos_j + feat columns (GATOR.py:19, MDR.py:130-134), channel block w, token on the lane
+        f32x16 acc = zero16(), acs = zero16();
+        const f32x16 init = chanvec_lds(VJ, TVJ_JFB + 32 * w, h) + load_block(lds + kTPosj + w * kTile, lane);
+        if constexpr ((GAT8_TAIL_F32 & 1) != 0) {
+            mma2_T(load_wtile(tl.jf_p, w * 4 + 0, lane), load_block(X, lane), acc, load_wtile(tl.jf_p, w * 4 + 1, lane), load_block(X + kTile, lane), acs);
+            mma2_T(load_wtile(tl.jf_p, w * 4 + 2, lane), load_block(X + 2 * kTile, lane), acc, load_wtile(tl.jf_p, w * 4 + 3, lane), load_block(X + 3 * kTile, lane), acs);
+            store_block(P + w * kTile, lane, (acc + acs) + init);
+        } else {
+            if (!(GAT8_TAIL_CUT & 2)) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const X2 fx2 = x2_split(load_block(X + kb * kTile, lane) * 16.0f);
+                    acs = h3_mma_wa_small(wt[kb], fx2, acs);
+                    acc = h3_mma_wa_main(wt[kb], fx2, acc);
+                }
+            }
+            store_block(P + w * kTile, lane, fma16(acc + acs, tl.jf_inv, init));
+        }
+        wt[0] = job_tile(job0, 0);                             // (its own K / V job's tiles, in flight across the barrier)
+        wt[1] = job_tile(job0, 1);
+    }
+    GAT8_TSTAMP(3);
+    __syncthreads();
+    GAT8_TSTAMP(4);
+    // jf = that + columns 0..4 (pose2d, pose3d / 1000)
+    f32x16 jf[2];
+    {
+        const float pin[5] = {p2x, p2y, XO[tkj * 3] / 1000.f, XO[tkj * 3 + 1] / 1000.f, XO[tkj * 3 + 2] / 1000.f};
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            f32x16 acc = load_block(P + nb * kTile, lane);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc += chanvec_lds(VJ, TVJ_JF5 + i * 64 + 32 * nb, h) * pin[i];
+            jf[nb] = acc;
+        }
+    }
+    auto rs = [&](const f32x16& p, const f32x16& q) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += p[r] + q[r];
+        return s + xhalf(s);
+    };
+    const float mean = rs(jf[0], jf[1]) * (1.0f / 64.0f);
+    const f32x16 d0 = jf[0] - mean, d1 = jf[1] - mean;
+    const float rstd = 1.0f / sqrtf(rs(d0 * d0, d1 * d1) * (1.0f / 64.0f) + 1e-5f);
+    GAT8_TSTAMP(5);
+    // per LBF layer: k = wk(LN1(jf)), v = wv(LN1(jf)) as MFMA operand tiles (two fp16 planes of 16 x value: mdr_fused.hip, cross_attention_head_x2)
+    const f32x16 fz0 = d0 * rstd * chanvec_lds(VJ, TVJ_N1W + 64 * li, h) + chanvec_lds(VJ, TVJ_N1B + 64 * li, h);
+    const f32x16 fz1 = d1 * rstd * chanvec_lds(VJ, TVJ_N1W + 64 * li + 32, h) + chanvec_lds(VJ, TVJ_N1B + 64 * li + 32, h);
+    const X2 z0 = x2_split(fz0 * 16.0f), z1 = x2_split(fz1 * 16.0f);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (q >= njob) break;
+        const int nb = (job0 + q) & 1;
+        float* out = tl.jkv + (((size_t)b * 3 + li) * 4 + kv * 2 + nb) * kTile;
+        const H3 &k0 = wt[2 * q], &k1 = wt[2 * q + 1];
+        f32x16 r0 = zero16(), r1 = zero16();                   // r1: the cross products of both k blocks, r0: the hi x hi ones (x3_common.h on the order)
+        if constexpr ((GAT8_TAIL_F32 & 2) != 0) {
+            const float* wp32 = kv ? tl.j_wv_p[li] : tl.j_wk_p[li];
+            const WTile t0 = load_wtile(wp32, nb * 2, lane), t1 = load_wtile(wp32, nb * 2 + 1, lane);
+            if (kv == 0) {
+                mma2_T(t0, fz0, r0, t1, fz1, r1);
+                r0 += r1;
+                if (tok >= J) r0 = zero16();
+            } else {
+                mma2_C(t0, fz0, r0, t1, fz1, r1);
+                r0 += r1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) r0[r] = (kap(r) + 4 * h < J) ? r0[r] : 0.f;
+            }
+            x2_store(out, lane, x2_split(r0 * 16.0f));
+            continue;
+        }
+        if (kv == 0) {
+            if (!(GAT8_TAIL_CUT & 4)) {
+                r1 = h3_mma_wa_small(k1, z1, h3_mma_wa_small(k0, z0, r1));
+                r0 = h3_mma_wa_main(k1, z1, h3_mma_wa_main(k0, z0, r0));
+            }
+            r0 += r1;
+            if (tok >= J) r0 = zero16();                       // joints >= J: zero rows (masked in the softmax anyway)
+        } else {
+            if (!(GAT8_TAIL_CUT & 4)) {
+                r1 = h3_mma_aw_small(z1, k1, h3_mma_aw_small(z0, k0, r1));
+                r0 = h3_mma_aw_main(z1, k1, h3_mma_aw_main(z0, k0, r0));
+            }
+            r0 += r1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) r0[r] = (kap(r) + 4 * h < J) ? r0[r] : 0.f;
+        }
+        x2_store(out, lane, x2_split(r0 * (16.0f * tl.kv_inv)));
+        GAT8_TSTAMP(6 + q);
     }
 }
 
 // H4: the token-wise products on four partial products (weights H3, operands X2; raw tiles carry 1 / a.lin_inv) instead of six
-template <bool H4, int LR, bool H2 = false, bool LB = false>
+template <bool H4, int LR, bool H2 = false, bool LB = false, bool TAIL = false>
 __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
+    static_assert(H4 || !TAIL, "the fused tail writes two-plane K / V tiles: four-product forms only");
     static_assert(H4 || !H2, "the one-plane form is a variant of the four-product form");
     static_assert((H4 && !H2) || !LB, "the byte-lo stream is a form of the four-product stream");
     typedef typename std::conditional<LB, H3B, typename std::conditional<H2, H3P2, typename std::conditional<H4, H3, X3>::type>::type>::type WT;
-    constexpr int kWF = WTile<WT>::floats;                 // floats per tile of the weight stream
+    constexpr int kWF = StreamTile<WT>::floats;                 // floats per tile of the weight stream
     typedef typename std::conditional<H4, X2, X3>::type OT;
     const float inv = H4 ? a.lin_inv : 1.0f;
     // operand tile of a true-scale register tile; pick-up of a raw product tile with what is added to it
@@ -606,7 +884,10 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
                                                          // SIMD, helpers on the other two: 180 us instead of 162, measured in round 4)
     float* R0w = lds + kR + w * kTile;
     float* R1w = lds + kR + (4 + w) * kTile;
-
+    if constexpr (TAIL) {      // the persistent MDR launch's counter blocks (tickets, error flag, completion counts), dealt over the workgroups:
+        if (a.tl.mdr_ctr)      // the previous forward's launches are complete (stream order), this forward's start after this kernel
+            for (size_t i = (size_t)b * 512 + t; i < mdr_ctr_words(a.tl.ctr_B); i += (size_t)a.B * 512) a.tl.mdr_ctr[i] = 0u;
+    }
 
     // ---------------- embedding: GraphLinear(2->64) . GroupNorm(4,64) . GELU . GraphLinear(64->128) + pos (GAT.py:135-144)
     {
@@ -730,10 +1011,26 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
             unit4<(OFF_FC2 + 12) % kNT, false, H4>(W, wp, pre, Y1, Y2, Y3, R1w, lane);
             skip_pad<(OFF_FC2 + 16) % kNT>(W, wp, lane);                          // the block's dummy tiles: refill their slots, no product
             GAT8_BAR(20);
+            if constexpr (TAIL) {
+                if (bi + 1 == kDepth) {      // idle from here on: stage the epilogue's vectors and pos_j tiles (the operand tiles are dead), fetch the first lifter rows
+                    if (a.tl.jkv) {
+                        const Gat8Tail& tl = a.tl;
+                        if (t < TVJ_TOTAL / 4) {
+                            const int off = 4 * t;
+                            const float* src = off < TVJ_JF5 ? tl.jf_b + off : off < TVJ_N1W ? tl.jf5 + (off - TVJ_JF5)
+                                               : off < TVJ_N1B ? tl.j_n1w[(off - TVJ_N1W) >> 6] + (off & 63) : tl.j_n1b[(off - TVJ_N1B) >> 6] + (off & 63);
+                            reinterpret_cast<f32x4*>(lds + kTVJ)[t] = *reinterpret_cast<const f32x4*>(src);
+                        }
+                        for (int e = t; e < 2 * kTile / 4; e += 256)
+                            reinterpret_cast<f32x4*>(lds + kTPosj)[e] = reinterpret_cast<const f32x4*>(tl.posj_T)[e];
+                    }
+                }
+            }
             GAT8_BAR(21);                                                   // helpers: residual
             GAT8_BAR(22);                                                   // helpers: Y = LN1(x) of the next block | final norm
         }
         GAT8_STAMPS_OUT(0, kDepth * 23 * 2);
+        if constexpr (TAIL) gat8_tail<LR, false>(a.tl, a.pose2d, lds, b, J, w, lane);
         return;
     }
 
@@ -804,6 +1101,25 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
         X2 qx;                                                 // H4: q on two planes already here (the helper has slack in this step)
         if constexpr (H4) qx = x2_split(q * op16);            // (op16: zero for the token lanes that do not exist)
         if (warm) warm_weights(0, (a.pf_loads + 1) / 2);
+        if constexpr (TAIL) {
+            // The epilogue's weights are HBM-cold like the streams (the lifter's 444 KB at J = 17, the joint-token linear's and the three
+            // layers' wk / wv H3 tiles): every workgroup of the XCD would miss on them together.  One block ahead -- the last block has no
+            // next block to warm -- this helper pulls its share of each region into the XCD's L2, one dword per 128-byte line.
+            if (!(GAT8_TAIL_CUT & 16) && bi + 1 == kDepth && a.tl.warm_n > 0) {
+                const int idx = ((b >> 3) % a.tl.warm_n) * 4 + w, parts = a.tl.warm_n * 4;
+                auto touch = [&](const float* base, int bytes) {
+                    const int share = ((bytes / parts + 127) / 128) * 128;
+                    for (int off = lane * 128; off < share; off += 8192)
+                        glds4(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + min(idx * share + off, bytes - 128)), dummy);
+                };
+                touch(a.tl.lifter_w, 3 * J * kC * J * 4);
+                if (a.tl.jkv) {
+                    touch(a.tl.jf_h3, 8 * kTileX3 * 4);
+#pragma unroll 1
+                    for (int li = 0; li < 3; ++li) touch(a.tl.j_wk_h3[li], 8 * kTileX3 * 4);      // wk | wv: eight contiguous tiles of the layer's grid
+                }
+            }
+        }
         GAT8_BAR(2);
         // ---- step 3: k; scores and softmax of heads 2w, 2w+1 (modules.py:121-133): S^T[key][query], query on the lane
         f32x16 sa = zero16(), sb = zero16();
@@ -1089,11 +1405,16 @@ __global__ __launch_bounds__(512, 2) void k_gat8(const Gat8Args a) {
                         *reinterpret_cast<f32x4*>(a.feat + ((size_t)b * J + tok) * kC + 32 * w + 8 * g + 4 * h) = v4;
                     }
                 }
+                if constexpr (TAIL) {        // feat stays on chip for the epilogue: channel block w as a T-layout tile (X is free since step 9);
+                    if (tok >= J) y = zero16();      // zero for the token lanes that do not exist (they are operand columns of the joint-token linear)
+                    store_block(X + w * kTile, lane, y);
+                }
             }
         }
         GAT8_BAR(22);
     }
     GAT8_STAMPS_OUT(kDepth * 23 * 2, 2 * kDepth * 23 * 2 + kDepth * 8);
+    if constexpr (TAIL) gat8_tail<LR, true>(a.tl, a.pose2d, lds, b, J, w, lane);
 }
 
 // one workgroup per destination tile: dst tile i <- src tile idx[i]  (TILE floats: 6 KiB X3 tiles or 4 KiB fp32 tiles)
@@ -1142,6 +1463,10 @@ int gat8_prepare_device() {
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 12, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 10, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 12, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 10, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
+    GATOR_HIP_CHECK(hipFuncSetAttribute((const void*)k_gat8<true, 12, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGat8Lds));
     return GATOR_OK;
 }
 
@@ -1210,7 +1535,16 @@ int gat8_build_stream(FusedState* f, void* stream) {
 }
 
 // feat only (the lifter and the MDR joint tokens are the batched launches of gat_tail.hip)
-int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total, int tap_row0, bool half16) {
+// tail_x_out != nullptr: the lifter (-> tail_x_out [B][3J]) and, with tail_jkv, the MDR joint tokens / K / V tiles run as the kernel's epilogue
+// (gat8_tail_supported); ctr_B > 0: the kernel also zeroes the persistent MDR launch's counters of a forward of ctr_B samples
+bool gat8_tail_supported(const gator_ctx* c, const FusedState* f, bool half16) {
+    if (!half16 && !f->gat8_lobyte) return false;        // (the three-plane stream's kernel has no registers left for the epilogue: GATOR_GAT8_LOBYTE=0 keeps the two launches)
+    return f->gat8 && f->gat8_h4 && f->g8stream != nullptr && f->mdr_x3 == 2 && f->wxbuf != nullptr && f->jf128_h3 != nullptr && (c->J == 17 || c->J == 19);
+}
+
+int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* feat, void* stream, int B_total, int tap_row0, bool half16,
+                float* tail_x_out, float* tail_jkv, int ctr_B) {
+    if (tail_x_out && !gat8_tail_supported(c, f, half16)) return fail(GATOR_EUNSUPPORTED, "k_gat8: the fused tail needs the four-product forms and 17 or 19 joints");
     if (half16 && !f->gat8_h4) return fail(GATOR_EUNSUPPORTED, "the 16-bit encoder needs the four-product weight stream (GATOR_GAT8_H4=1, the default)");
     Gat8Args a;
     const Weights& w = c->w;
@@ -1224,6 +1558,20 @@ int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* 
         a.blk[i] = Gat8Blk{p.back, p.mc, p.mdT, p.aoffT, p.f1b, f->g_vecs + (size_t)i * 2048};
     }
     a.feat = feat;
+    a.tl = Gat8Tail{};
+    const bool tail = tail_x_out != nullptr;
+    if (tail) {
+        Gat8Tail& tl = a.tl;
+        tl.lifter_w = w.lifter_w; tl.lifter_b = w.lifter_b; tl.x_out = tail_x_out; tl.jkv = tail_jkv;
+        if (ctr_B > 0 && f->mdr_persist != 0) { tl.mdr_ctr = f->mdr_ctr; tl.ctr_B = ctr_B; f->mdr_ctr_clean = true; }
+        tl.jf_p = f->jfeat128_p;
+        for (int i = 0; i < 3; ++i) { tl.j_wk_p[i] = f->lay[i].wk; tl.j_wv_p[i] = f->lay[i].wv; }
+        tl.jf5 = f->jfeat5; tl.jf_h3 = f->jf128_h3; tl.jf_b = w.jfeat_b; tl.posj_T = f->posj_T;
+        auto h3_of = [&](const float* t) { return f->wxbuf + (size_t)(t - f->lay[0].wq) / kTile * kTileX3; };      // the MDR layers' H3 image mirrors wbuf tile for tile
+        for (int i = 0; i < 3; ++i) { tl.j_n1w[i] = w.lay[i].n1w; tl.j_n1b[i] = w.lay[i].n1b; tl.j_wk_h3[i] = h3_of(f->lay[i].wk); tl.j_wv_h3[i] = h3_of(f->lay[i].wv); }
+        tl.jf_inv = std::ldexp(1.0f, -(4 + f->jf128_wshift));
+        tl.kv_inv = std::ldexp(1.0f, -(4 + f->mdr_wshift));
+    }
     a.blk_tap = nullptr;
     a.tapB = B;
     if (c->block_taps) {
@@ -1239,6 +1587,7 @@ int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* 
     if (lob) a.wstream = f->g8stream_b;
     a.pf_loads = l2warm ? (kBlkTiles * (lob ? kTileH3B : kTileX3) * 4 / a.pf_n + 8191) / 8192 : 0;       // 8 KiB (64 lines) per instruction
     if (a.pf_loads > 6) a.pf_loads = 0;      // fewer than ~8 workgroups per XCD (B < 64): a share is so large that touching it costs more than it hides
+    a.tl.warm_n = (tail && l2warm && a.pf_n >= 8) ? a.pf_n : 0;      // (fewer than 8 workgroups per XCD: a share is too large to be worth touching)
 #ifdef GATOR_DIAG
     a.stamps = nullptr;
     a.dbg = getenv("GATOR_GAT8_DBG") ? atoi(getenv("GATOR_GAT8_DBG")) : 0;
@@ -1249,9 +1598,21 @@ int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* 
         GATOR_HIP_CHECK(hipMemset(a.stamps, 0, kSt * sizeof(unsigned long long)));
     }
 #endif
+#ifdef GATOR_DIAG
+    a.tl.tstamps = nullptr;
+    if (want_stamps && tail) {
+        GATOR_HIP_CHECK(hipMalloc(&a.tl.tstamps, 64 * sizeof(unsigned long long)));
+        GATOR_HIP_CHECK(hipMemset(a.tl.tstamps, 0, 64 * sizeof(unsigned long long)));
+    }
+#endif
     a.lin_inv = std::ldexp(1.0f, -(4 + f->gat8_wshift));
     // token rows that exist sit in registers r < LR of a row-over-token tile: token t <-> r = (t & 3) + 4 (t >> 3), so J <= 18 / 20 -> 10 / 12
-    if (!f->gat8_h4) k_gat8<false, 16><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    if (tail && half16 && c->J == 17) k_gat8<true, 10, true, false, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else if (tail && half16) k_gat8<true, 12, true, false, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else if (tail && lob && c->J == 17) k_gat8<true, 10, false, true, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else if (tail && lob) k_gat8<true, 12, false, true, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
+    else if (tail) return fail(GATOR_EUNSUPPORTED, "k_gat8: no fused tail on the three-plane weight stream");
+    else if (!f->gat8_h4) k_gat8<false, 16><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else if (half16 && c->J <= 18) k_gat8<true, 10, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else if (half16 && c->J <= 20) k_gat8<true, 12, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
     else if (lob && c->J <= 18) k_gat8<true, 10, false, true><<<B, 512, kGat8Lds, (hipStream_t)stream>>>(a);
@@ -1261,6 +1622,17 @@ int launch_gat8(gator_ctx* c, FusedState* f, const float* pose2d, int B, float* 
     else return fail(GATOR_EUNSUPPORTED, "k_gat8: more than 20 joints (gator_create admits 17 and 19)");
     GATOR_HIP_CHECK(hipGetLastError());
 #ifdef GATOR_DIAG
+    if (a.tl.tstamps) {
+        unsigned long long ts[64];
+        GATOR_HIP_CHECK(hipMemcpy(ts, a.tl.tstamps, sizeof(ts), hipMemcpyDeviceToHost));
+        GATOR_HIP_CHECK(hipFree(a.tl.tstamps));
+        fprintf(stderr, "[k_gat8 tail stamps, one workgroup, B=%d] s_memtime cycles since wave 0 entered: entry | loads issued + joint-token MFMAs | lifter done | at barrier | past barrier | jf + LN done | job 1 | job 2\n", B);
+        for (int v = 0; v < 8; ++v) {
+            fprintf(stderr, "  wave %d:", v);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %6lld", ts[v * 8 + k] ? (long long)(ts[v * 8 + k] - ts[0]) : -1LL);
+            fprintf(stderr, "\n");
+        }
+    }
     if (a.stamps) {     // diagnostic build: synchronous read-back; blocks 1..5 averaged (block 0 carries the cold start)
         std::vector<unsigned long long> hs(kSt);
         GATOR_HIP_CHECK(hipMemcpy(hs.data(), a.stamps, kSt * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_gat_joint(const JointTailArgs a) {
 
 size_t gat_tail_part_floats(int B, int J) { return (size_t)((B + 31) / 32) * J * 2 * kTile; }
 
-int launch_gat_tail(gator_ctx* c, FusedState* f, const float* pose2d, const float* feat, int B, float* x_out, void* stream, bool joint) {
+int launch_gat_tail(gator_ctx* c, FusedState* f, const float* pose2d, const float* feat, int B, float* x_out, void* stream, bool joint, bool zero_ctr) {
     const Weights& w = c->w;
     const int J = c->J, MT = (B + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
@@ -186,7 +186,7 @@ int launch_gat_tail(gator_ctx* c, FusedState* f, const float* pose2d, const floa
     a.mdr_ctr = nullptr;
     a.x2 = f->mdr_x3 == 2;
     if (joint) {
-        if (f->mdr_persist != 0) { a.mdr_ctr = f->mdr_ctr; f->mdr_ctr_clean = true; }
+        if (f->mdr_persist != 0 && zero_ctr) { a.mdr_ctr = f->mdr_ctr; f->mdr_ctr_clean = true; }      // (!zero_ctr: k_gat8's fused tail zeroes them for the whole forward)
         a.jkv = f->jkv; a.jf5 = f->jfeat5; a.jf_p = f->jfeat128_p; a.jf_b = w.jfeat_b; a.posj_T = f->posj_T;
         for (int i = 0; i < 3; ++i) { a.j_n1w[i] = w.lay[i].n1w; a.j_n1b[i] = w.lay[i].n1b; a.j_wk_p[i] = f->lay[i].wk; a.j_wv_p[i] = f->lay[i].wv; }
     }

@@ -92,3 +92,37 @@ def test_gat8_agrees_with_k_gat_to_fp32_noise(monkeypatch, name):
     assert dv <= 1.5e-3 and dp <= 1e-3
     assert df <= 2e-5 * max(1.0, float(feat4.abs().max()))
     assert not torch.equal(feat8, feat4)                         # (the switch selected a different kernel)
+
+
+@pytest.mark.parametrize('name', ['h36m17_bn', 'coco19_alpha'])
+def test_fused_tail_agrees_with_the_two_tail_launches(monkeypatch, name):
+    """Round 6: k_gat8<..., TAIL> runs the lifter (GAT.py:151-152) and the MDR joint tokens / K / V tiles (MDR.py:130-134,37-38,65) as its
+    epilogue; GATOR_GAT8_TAIL=0 keeps k_gat_lifter + k_gat_joint (gat_tail.hip), which the sample-tiled encoder still uses.  The two
+    agree to fp32 rounding (the lifter sums 128 J exact fp32 products in another order; the joint-token linear's four k blocks are
+    partial sums instead of one chain); both sit inside the parity bar; the fused form is bitwise batch / position independent."""
+    from oracle import gator_oracle as go
+    monkeypatch.setenv('GATOR_GAT_TILED', '0')
+    monkeypatch.delenv('GATOR_GAT8_TAIL', raising=False)
+    z, m1 = build_model(name, 'fused')
+    zz, c, sd = oracle_setup(name)
+    B = 70
+    x = torch.from_numpy(synthetic.synthetic_pose2d(B, c.J, seed=321))
+    v1, p1 = m1(x.cuda())
+    monkeypatch.setenv('GATOR_GAT8_TAIL', '0')
+    z, m0 = build_model(name, 'fused')
+    v0, p0 = m0(x.cuda())
+    torch.cuda.synchronize()
+    m1.device_status(); m0.device_status()
+    assert not torch.equal(p1, p0)                          # the switch really selects the other form (different last bits)
+    ref, rp = go.gator_forward(sd, c, x[:24], torch.float64)
+    for tag, v, p in (('fused tail', v1, p1), ('two launches', v0, p0)):
+        e = float(np.abs(v[:24].cpu().numpy().astype(np.float64) - ref.numpy()).max() * 1e3)
+        ep = float(np.abs(p[:24].cpu().numpy().astype(np.float64) - rp.numpy()).max())
+        print('\n[%s %s] verts %.2e mm, pose3d %.2e mm vs fp64' % (name, tag, e, ep))
+        assert e <= 1e-3 and ep <= 1e-3
+    assert float((p1 - p0).abs().max()) <= 2e-4 and float((v1 - v0).abs().max()) * 1e3 <= 1e-3
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
+    vp, pp = m1(x[perm].cuda())
+    assert torch.equal(vp, v1[perm.cuda()]) and torch.equal(pp, p1[perm.cuda()])
+    vs, ps = m1(x[10:13].cuda())
+    assert torch.equal(vs, v1[10:13]) and torch.equal(ps, p1[10:13])

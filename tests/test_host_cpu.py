@@ -102,3 +102,10 @@ def test_gat8_roles_keep_the_same_barrier_sequence():
         assert got == want, (role, got)
     # and neither role leaves its branch early: one `return` (the product waves', after their last barrier)
     assert product.count('return;') == 1 and helper.count('return;') == 0
+    # round 6: the fused tail (gat8_tail, its own barrier inside) is entered exactly once by each role, after the numbered sequence
+    for role, text in (('product', product), ('helper', helper)):
+        assert len(re.findall(r'gat8_tail<', text)) == 1, role
+        assert text.rindex('gat8_tail<') > text.rindex('GAT8_BAR(22)'), role
+    tail = src[src.index('void gat8_tail('):src.index('// H4: the token-wise products on four partial products')]
+    assert tail.count('__syncthreads()') == 1 and 'GAT8_BAR' not in tail
+    assert tail.index('if (!joint) return;') < tail.index('__syncthreads()')      # the lifter-only exit is workgroup-uniform and ahead of the barrier
