@@ -120,6 +120,7 @@ def parse():
     ap.add_argument('--subbatch-variant', action='store_true', help='also time the sub-batch-streams=2 mode (extra key)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variants', action='store_true', help='skip the A/B variants measured beside the headline (N = 1 only)')
+    ap.add_argument('--no-config3', action='store_true', help='skip the `config3` sub-record (BASELINE configs[2] beside the default headline, N = 1 only)')
     a = ap.parse_args()
     preset = BASELINE_CONFIGS.get(a.config, dict(batch=256, joints=17, precision='f32', mode='gather'))
     for k in ('batch', 'joints', 'precision', 'mode'):
@@ -624,6 +625,34 @@ def main():
             f32v = variants.get('fp32 build at this shape (gator_forward_f32)')
             if f32v and 'value' in f32v:      # config 3's own bar (round-4 review): >= 1.6 x the fp32 build on the same box
                 line['vs_fp32_build_same_box'] = round(value / f32v['value'], 3)
+        if world == 1 and a.config == 0 and not a.no_config3 and a.impl == 'fused' and a.mode == 'gather' and (B, J, a.precision) == (256, 17, 'f32'):
+            # BASELINE configs[2] (B = 2048 COCO 19-joint, 16-bit operand mode) beside the default headline, so that the driver's own run carries it
+            # (round-5 review): same process, same box, the variants' protocol (median of 5 blocks of --steps steps), the fp32 build at the same
+            # shape next to it, parity of 8 samples of the timed batch against the fp64 oracle.  `python bench.py --config 3` is the full line.
+            try:
+                c3 = BASELINE_CONFIGS[3]
+                B3, J3 = c3['batch'], c3['joints']
+                m3, base3, alpha3 = build_model(J3, a.impl, dev)
+                x3 = torch.from_numpy(synthetic.synthetic_pose2d(B3, J3, seed=1003)).to(dev)
+                rec = {'workload': c3['name'], 'dtype': 'f16', 'protocol': 'median of 5 blocks of %d steps after %d warm-up steps' % (a.steps, a.warmup)}
+                for prec, key in (('bf16', None), ('f32', 'fp32_build_same_shape')):
+                    m3.precision = prec
+                    for _ in range(a.warmup):
+                        o3 = m3(x3)
+                    dv = sorted(block(lambda: m3(x3), a.steps)[0] for _ in range(5))[2]
+                    r = {'value': round(B3 * a.steps / dv, 1), 'unit': 'meshes/sec', 'ms_per_step': round(dv / a.steps * 1e3, 4)}
+                    if key is None:
+                        rec.update(r)
+                        if not a.no_cpu_baseline:
+                            m3.precision = 'bf16'
+                            rec['parity'] = parity_check(m3, base3, alpha3, J3, x3, m3(x3)[0], n=8, bar_mm=1.0)
+                    else:
+                        rec[key] = r
+                rec['vs_fp32_build_same_box'] = round(rec['value'] / rec['fp32_build_same_shape']['value'], 3)
+                line['config3'] = rec
+                del m3, x3
+            except Exception as e:       # the sub-record must never cost the headline
+                line['config3'] = {'error': str(e)[:300]}
         if world == 1 and B >= 128 and a.subbatch_variant:
             # same workload with the library's sub-batch pipelining (two half-batches on two streams; bit-identical results).
             # Reported beside the headline, not as it: concurrent streams make per-kernel durations (and so `roofline`) ambiguous.

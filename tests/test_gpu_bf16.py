@@ -132,7 +132,16 @@ def test_config3_attention_long_way_under_large_logits(gain):
     if gain <= 3.0:
         assert e.max() < 1.0 and np.sqrt((e ** 2).mean()) < 0.2
     else:
-        assert e.max() < 20.0
+        # Against the fp32 mode on the SAME weights (round-5 review: a stated ratio instead of "< 20 mm"): one plane carries 11 significant
+        # bits of a score where the fp32 mode's two planes carry 22, so the 16-bit mode may sit up to 2^11 above it -- and no further.
+        m.precision = 'f32'
+        v32, _ = m(x.cuda())
+        m.precision = 'bf16'
+        e32 = np.abs(v32.cpu().numpy().astype(np.float64) - r64.numpy()) * 1e3
+        r_max, r_rms = e.max() / e32.max(), np.sqrt((e ** 2).mean()) / np.sqrt((e32 ** 2).mean())
+        print('[config 3, logit gain %.0f^2] fp32 mode on the same weights: max %.2e mm rms %.2e mm -> 16-bit / fp32 = %.0f (max), %.0f (rms); bound 2^11 = 2048'
+              % (gain, e32.max(), np.sqrt((e32 ** 2).mean()), r_max, r_rms))
+        assert r_max <= 2048.0 and r_rms <= 2048.0
     v2, _ = m(x.cuda())
     vs, _ = m(x[5:9].cuda())
     assert torch.equal(v, v2) and torch.equal(vs, v[5:9])
