@@ -67,6 +67,7 @@ SIGNATURES = {
     'gator_comm_create': (_I, [_P, _I, _I, ctypes.POINTER(_P)]),
     'gator_comm_destroy': (_I, [_P]),
     'gator_allgather_verts': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    'gator_emulate_gather_traffic': (_I, [_P, _P, _L, _I, _I, _P]),
     'gator_floyd_warshall': (_I, [_P, _I, _P, _P]),
     'gator_gen_edge_input': (_I, [_P, _P, _I, _I, _P]),
     'gator_verts_joints_relation': (_I, [_P, _I, _P, _I, _P]),

@@ -368,3 +368,25 @@ extern "C" int gator_rigid_align_f32(const float* a, const float* b, int32_t bat
     GATOR_HIP_CHECK(hipGetLastError());
     return GATOR_OK;
 }
+
+// ---- measurement helper: the device-side traffic of this rank's share of an all-gather (include/gator_hip.h) ------------------------------
+namespace gator {
+typedef float tr_f4 __attribute__((ext_vector_type(4)));
+// persistent-style: every workgroup walks the source in 4 KiB steps, strided by the grid, once per copy; 16 B per lane, non-temporal stores
+// (the data is not read again on this device, like a receive buffer)
+__global__ __launch_bounds__(256) void k_gather_traffic(const tr_f4* __restrict__ src, tr_f4* __restrict__ dst, long long n16, int copies) {
+    for (int c = 0; c < copies; ++c) {
+        tr_f4* d = dst + (size_t)c * n16;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256)
+            __builtin_nontemporal_store(src[i], d + i);
+    }
+}
+}  // namespace gator
+
+extern "C" int gator_emulate_gather_traffic(const void* src, void* dst, int64_t bytes, int32_t copies, int32_t n_workgroups, void* stream) {
+    using namespace gator;
+    if (!src || !dst || bytes < 16 || (bytes & 15) || copies <= 0 || n_workgroups <= 0) return fail(GATOR_EINVAL, "gator_emulate_gather_traffic: bad arguments (bytes: a positive multiple of 16)");
+    k_gather_traffic<<<n_workgroups, 256, 0, (hipStream_t)stream>>>((const tr_f4*)src, (tr_f4*)dst, (long long)(bytes / 16), copies);
+    GATOR_HIP_CHECK(hipGetLastError());
+    return GATOR_OK;
+}

@@ -105,11 +105,15 @@ __device__ __forceinline__ void ex_write(float* EX, int t, int h, const f32x16& 
         *reinterpret_cast<f32x4*>(EX + t * kEXS + 8 * g + 4 * h) = q;
     }
 }
-// out[r] = sum_j' coef[j'] * EX[base + j'][my 16 columns]   (the lane's own channels of the J tokens of its sample)
+// out[r] = sum_j' coef[j'] * EX[base + j'][my 16 columns]   (the lane's own channels of the J tokens of its sample).  The coefficients are
+// read from their LDS table row as they are used: held in a register array (J floats, two such arrays live across the whole X_Feat loop) they
+// were what pushed the kernel over its 512 registers (round 6: 160 / 188 B of scratch per lane -> 0; same values, same order, same bits)
 template <int J>
-__device__ __forceinline__ f32x16 aggregate(const float* EX, int base, int h, const float (&coef)[J]) {
+__device__ __forceinline__ f32x16 aggregate(const float* EX, int base, int h, const float* coef) {
     f32x16 acc = zero16();
-#pragma unroll
+    // a (mostly) ROLLED loop: fully unrolled, hipcc hoists all 4 J row reads (68 - 76 b128 loads = 270 - 300 registers in flight) to the top of the sum -- that,
+    // not the kernel's state, was its scratch (round 6, found by cutting the kernel apart: without this sum 0 B, with it 160 / 188 B per lane)
+#pragma unroll 4
     for (int jp = 0; jp < J; ++jp) {
         const float* row = EX + (base + jp) * kEXS + 4 * h;
 #pragma unroll
@@ -414,8 +418,7 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
                 {
                     float qh[16], sc[J], o[16];
                     to_head(q, qh);
-                    float brow[J];
-                    table_row<J>(TBIAS + (2 * nb + h) * J * kTabS, j, brow);
+                    const float* brow = TBIAS + ((2 * nb + h) * J + j) * kTabS;       // row j of the head's hop / path bias table (LDS)
                     float mx = -1e30f;
 #pragma unroll
                     for (int jp = 0; jp < J; ++jp) {
@@ -461,9 +464,7 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
                 __syncthreads();                                             // publishes the M . h1 image
                 // ---- MGCN (modules.py:243-255): diag(A) (M . h0) + offdiag(A) (M . h1) on this lane's 16 channels ----
                 {
-                    float aoff[J];
-                    table_row<J>(TAOFF + bi * J * kTabS, j, aoff);
-                    const f32x16 g = h0 * mblk * adiag + aggregate<J>(EXK, base, h, aoff);
+                    const f32x16 g = h0 * mblk * adiag + aggregate<J>(EXK, base, h, TAOFF + (bi * J + j) * kTabS);
                     if (nb == 0) pacc[0] += g;
                     if (nb == 1) pacc[1] += g;
                     if (nb == 2) pacc[2] += g;
@@ -473,9 +474,7 @@ __global__ __launch_bounds__(256, 1) void k_gat_tiled(const TiledArgs a) {
         }
         // ================= phase 2: X_Feat (modules.py:158-177) + residual =================
         {
-            float c1[J], c2[J];
-            table_row<J>(TM1, j, c1);
-            table_row<J>(TM2, j, c2);
+            const float *c1 = TM1 + j * kTabS, *c2 = TM2 + j * kTabS;      // this token's rows of the hop masks (LDS)
             OT ss[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) ss[i] = sp(pacc[i], inv);

@@ -12,11 +12,7 @@ import sys
 HOT = ('k_gat<true', 'k_gat8', 'k_gat_lifter', 'k_gat_joint', 'k_gat_tiled<', 'k_mdr_layer<0, 2>', 'k_mdr_layer<1, 2>', 'k_mdr_layer<2, 2>', 'k_mdr_persist<2>',
        'k_mdr_layer<0, 3>', 'k_mdr_layer<1, 3>', 'k_mdr_layer<2, 3>', 'k_mdr_persist<3>',
        'k_mdr_head<', 'k_upsample_x3', 'k_upsample_x2', 'k_upsample_bf16', 'k_regress', 'k_jreg_reduce', 'k_joint_errors', 'k_rigid_align', 'k_preprocess')
-SCRATCH_BUDGET = {
-    'k_gat_tiled<17, false, false>': 292, 'k_gat_tiled<19, false, false>': 300,     # 74 spilled VGPRs, stored once before the block loop and re-read once per block
-    'k_gat_tiled<17, true, false>': 164, 'k_gat_tiled<19, true, false>': 192,       # the four-product form (default): operands on two planes free 32 registers
-    'k_gat_tiled<17, true, true>': 92, 'k_gat_tiled<19, true, true>': 84,           # the one-plane form of config 3: 32 more
-}
+SCRATCH_BUDGET = {}      # (round 6: k_gat_tiled's entries are gone -- its scratch was a hoisted sum, gat_tiled.hip: aggregate)
 _FIELD = re.compile(r'remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)')
 _NAME = re.compile(r'remark:\s+Function Name: (\S+)')
 

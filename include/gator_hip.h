@@ -236,6 +236,11 @@ int gator_comm_destroy(gator_comm* comm);
 int gator_allgather_verts(gator_comm* comm, const float* verts_local, const float* pose3d_local /* or NULL */, int32_t batch_local,
                           int32_t num_joint, float* verts_all, float* pose3d_all /* or NULL */, void* stream);
 
+/* Measurement helper (tools/contention_model.py): the memory traffic a rank's share of an all-gather causes on ITS device --
+ * read `bytes` at src, write them `copies` times to dst (dst holds copies x bytes) -- from `n_workgroups` workgroups of 256 threads on `stream`,
+ * i.e. a stand-in for RCCL's send / receive kernels at a given channel count, to be run beside the forward on a one-GPU box.  No reference counterpart. */
+int gator_emulate_gather_traffic(const void* src, void* dst, int64_t bytes, int32_t copies, int32_t n_workgroups, void* stream);
+
 /* Evaluation errors of a batch in ONE launch (data/PW3D/dataset.py:273-286 compute_both_err, :337-375 PA alignment):
  *   pred_joints [B,n_joint,3] (scaled by pred_scale, e.g. 1000 for metres -> mm, lib/core/base.py:219), target_joints [B,n_joint,3];
  *   eval_joints: n_eval joint indices (device) or NULL for all; root: the joint both sets are aligned to.
