@@ -5,7 +5,7 @@ Writes profiles/<tag>_* (kernel stats CSV, one CSV per PMC pass, the summary JSO
 import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 src = os.path.join('gpurun_out', 'prof_' + tag)
 KEEP = ('k_gat', 'k_mdr_layer', 'k_mdr_persist', 'k_mdr_head', 'k_upsample', 'k_mdr_joint', 'k_pack_vc', 'k_jreg')
 
