@@ -1412,6 +1412,30 @@ __global__ __launch_bounds__(128) void k_mdr_joint(const JointArgs a) {
     }
 }
 
+// sum of a double over the 64 lanes on DPP row operations (quad swaps, half-row and row mirrors: every lane ends with its row's total) and four
+// v_readlane per half -- 12 cross-lane moves in registers instead of the 12 ds_bpermute round trips of a __shfl_xor butterfly; fixed association
+__device__ __forceinline__ double dpp_mov_f64(double v, int which) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+    if (which == 0) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false); }             // quad_perm [1,0,3,2]
+    else if (which == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); }        // quad_perm [2,3,0,1]
+    else if (which == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, false); }      // row_half_mirror
+    else { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xf, 0xf, false); }                      // row_mirror
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum64_f64(double s) {
+    s += dpp_mov_f64(s, 0); s += dpp_mov_f64(s, 1); s += dpp_mov_f64(s, 2); s += dpp_mov_f64(s, 3);
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, s);
+    const int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+    double t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned l2 = (unsigned)__builtin_amdgcn_readlane(lo, 16 * r), h2 = (unsigned)__builtin_amdgcn_readlane(hi, 16 * r);
+        t[r] = __builtin_bit_cast(double, ((unsigned long long)h2 << 32) | l2);
+    }
+    return (t[0] + t[1]) + (t[2] + t[3]);
+}
+
 // MDR head (MDR.py:156-166) from the per-token head features hf[b][v][32]:
 //   ch 0..19 = mat_A, 24..26 = bias_linear out, 27 = scale_linear out, 28..30 = mat_C   (our own packing order)
 // Writes vert431 both in the reference layout (tap / stage API) and as the packed A operand of the vertex GEMM.
@@ -1431,10 +1455,13 @@ struct HeadArgs {
 // weights, its token's 32 head features -- is issued before the first phase, and the phases run on registers and LDS only
 // (16 / 13 us).  That costs 196 VGPRs, one workgroup per CU: batches of more than two workgroups per CU take the rolled form
 // (same arithmetic in the same order, 2 workgroups per CU), which is the faster one there.
+#ifndef MDR_HEAD_CUT
+#define MDR_HEAD_CUT 0      // timing experiments only (tools/build_variant.py ... -DMDR_HEAD_CUT=n): 1 no conv FMAs, 2 no wave reductions, 4 no softmax-mix, 8 no conv-weight loads
+#endif
 template <int NT, bool HOIST>
 __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a) {
     static_assert(NT >= kV, "one token per thread");
-    __shared__ float bn[kV][3];
+    __shared__ float bn[kV][5];      // [0 | x y z | 0]: the conv's zero padding of the xyz axis as stored zeros (unconditional reads in the loop)
     __shared__ float bc[20][3];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* hf = a.hf + (size_t)b * kV * 32;
@@ -1456,6 +1483,7 @@ __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a
     // Conv1d(431->20,k3,p1) weight of row m = wave + 8 q at e = lane + 64 it
     auto conv_w = [&](int q, int it) {
         const int e = lane + 64 * it, m = wave + NW * q;
+        if (MDR_HEAD_CUT & 8) return 0.5f;
         return e < kV * 3 ? a.bconv_w[(m < 20 ? m : 0) * (kV * 3) + e] : 0.f;
     };
     float wreg[3][HOIST ? NIT : 1];
@@ -1476,7 +1504,8 @@ __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a
             const float rs = 1.0f / sqrtf(a.bn_var[v] + 1e-5f);
             for (int c = 0; c < 3; ++c) x[c] = (x[c] - a.bn_mean[v]) * rs * a.bn_w[v] + a.bn_b[v];
         }
-        for (int c = 0; c < 3; ++c) bn[v][c] = gelu_f(x[c]);
+        bn[v][0] = 0.f; bn[v][4] = 0.f;
+        for (int c = 0; c < 3; ++c) bn[v][1 + c] = gelu_f(x[c]);
     }
     __syncthreads();
     {   // Conv1d(431->20,k3,p1) over the xyz axis.  Wave w owns output rows m = w, w+8, w+16 and walks the whole (c,k) axis:
@@ -1484,30 +1513,32 @@ __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a
         float acc[3][3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) acc[q][0] = acc[q][1] = acc[q][2] = 0.f;
+        // Round 6 (the conv loop was 6.5 of the launch's 17 us, the nine double-precision butterflies through LDS 2.6: MDR_HEAD_CUT): the walk
+        // e = lane + 64 it advances (channel c, tap k) by (21, +1) instead of dividing; the padding is stored zeros, not conditions; the
+        // products are fused multiply-adds; the wave sums run on DPP row operations (still in double: bc feeds every coarse vertex).
+        int cch = lane / 3, ktap = lane - 3 * cch;
 #pragma unroll(HOIST ? NIT : 1)
         for (int it = 0; it < NIT; ++it) {
             const int e = lane + 64 * it;
-            if (e < kV * 3) {
-                const int c = e / 3, k = e - 3 * c;
-                // tap k of channel c meets input position ll = l + k - 1 (zero padding outside 0..2)
-                const float in0 = (k >= 1) ? bn[c][k - 1] : 0.f;        // l=0: ll = k-1
-                const float in1 = bn[c][k];                             // l=1: ll = k
-                const float in2 = (k <= 1) ? bn[c][k + 1] : 0.f;        // l=2: ll = k+1
+            if (!(MDR_HEAD_CUT & 1) && e < kV * 3) {
+                // tap k of channel c meets input position l + k - 1 (zero padding outside 0..2 = the stored zeros)
+                const float in0 = bn[cch][ktap], in1 = bn[cch][ktap + 1], in2 = bn[cch][ktap + 2];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const float w = HOIST ? wreg[q][HOIST ? it : 0] : conv_w(q, it);
-                    acc[q][0] += w * in0;
-                    acc[q][1] += w * in1;
-                    acc[q][2] += w * in2;
+                    acc[q][0] = fmaf(w, in0, acc[q][0]);
+                    acc[q][1] = fmaf(w, in1, acc[q][1]);
+                    acc[q][2] = fmaf(w, in2, acc[q][2]);
                 }
             }
+            cch += ktap == 2 ? 22 : 21;          // e + 64 = 3 (c + 21) + (k + 1)
+            ktap = ktap == 2 ? 0 : ktap + 1;
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
-                double s = (double)acc[q][l];
-                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                const double s = (MDR_HEAD_CUT & 2) ? (double)acc[q][l] : wave_sum64_f64((double)acc[q][l]);
                 const int m = wave + NW * q;
                 if (lane == 0 && m < 20) bc[m][l] = (float)(s + (double)a.bconv_b[m]);
             }
@@ -1533,7 +1564,7 @@ __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a
         float mx = -1e30f, p[20], l = 0.f;
         for (int m = 0; m < 20; ++m) mx = fmaxf(mx, av[m]);
         for (int m = 0; m < 20; ++m) {
-            p[m] = __builtin_amdgcn_exp2f((av[m] - mx) * kLog2e);
+            p[m] = (MDR_HEAD_CUT & 4) ? av[m] : __builtin_amdgcn_exp2f((av[m] - mx) * kLog2e);
             l += p[m];
         }
         const float il = 1.0f / l;
