@@ -89,3 +89,20 @@ def test_general_preprocess_chain_kernel_matches_reference_golden():
     plain, v2 = pp.preprocess_chain(j)
     red = pp.normalise_pose2d(j)
     assert np.abs(plain[ok].cpu().numpy() - red[ok].cpu().numpy()).max() < 5e-5
+
+
+def test_emulated_gather_traffic_copies_the_shard():
+    """gator_emulate_gather_traffic (include/gator_hip.h; tools/contention_model.py): `copies` images of the source behind each other, whatever the
+    workgroup count; bad arguments are refused."""
+    import ctypes
+    from gator_amd import _lib
+    lib = _lib.load()
+    src = torch.randn(3 * 4096 + 4, device='cuda')
+    dst = torch.zeros(5 * src.numel(), device='cuda')
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n_wg in (1, 16, 300):
+        dst.zero_()
+        _lib.check(lib.gator_emulate_gather_traffic(src.data_ptr(), dst.data_ptr(), src.numel() * 4, 5, n_wg, st), 'gator_emulate_gather_traffic')
+        torch.cuda.synchronize()
+        assert torch.equal(dst.view(5, -1), src.expand(5, -1))
+    assert lib.gator_emulate_gather_traffic(src.data_ptr(), dst.data_ptr(), 10, 1, 1, st) == -1      # GATOR_EINVAL: not a multiple of 16
