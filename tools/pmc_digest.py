@@ -11,7 +11,7 @@ KEEP = ('k_gat', 'k_mdr_layer', 'k_mdr_persist', 'k_mdr_head', 'k_upsample', 'k_
 
 
 def short(name):
-    m = re.match(r'_ZN5gator\d+_GLOBAL__N_1\d+(k_[a-z0-9_]+?)E', name)      # a signature rocprofv3 could not demangle (_Float16 arguments)
+    m = re.match(r'_ZN5gator\d+_GLOBAL__N_1\d+(k_[a-z0-9_]+?)[EI]', name)      # (I: a template argument list follows the name)      # a signature rocprofv3 could not demangle (_Float16 arguments)
     if m:
         return m.group(1)
     n = name.replace('(anonymous namespace)::', '').replace('void ', '').replace('gator::', '')
