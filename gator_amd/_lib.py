@@ -42,6 +42,7 @@ SIGNATURES = {
     'gator_destroy': (_I, [_P]),
     'gator_device_status': (_I, [_P, _I]),
     'gator_status_reason': (_I, [_P]),
+    'gator_c3_state': (_I, [_P, _P]),
     'gator_abi_version': (_I, []),
     'gator_forward_f32': (_I, [_P, _P, _I, _P, _P, _P]),
     'gator_forward_bf16': (_I, [_P, _P, _I, _P, _P, _P]),

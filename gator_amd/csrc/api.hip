@@ -312,6 +312,10 @@ static int report_device_status(gator_ctx* c, unsigned st, const char* fn, bool 
 static unsigned take_status_word(gator_ctx* c) { return c->status_host ? __atomic_exchange_n(c->status_host, 0u, __ATOMIC_RELAXED) : 0u; }
 
 extern "C" int gator_status_reason(gator_ctx* c) { return c ? c->status_reason : 0; }
+extern "C" int gator_c3_state(gator_ctx* c, float* logit_bound) {
+    if (!c) return fail(GATOR_EINVAL, "gator_c3_state: null ctx");
+    return fused_c3_state(c, logit_bound);
+}
 
 extern "C" int gator_device_status(gator_ctx* c, int32_t sync) {
     if (!c) return fail(GATOR_EINVAL, "gator_device_status: null ctx");

@@ -79,6 +79,8 @@ struct FusedState : FusedWs {
     int jf128_wshift = 0;
     int mdr_wshift = 0;                 // GATOR_MDR_X3=2: wxbuf holds three fp16 planes of 2^mdr_wshift * w
     int mdr_x3 = 2;                     // GATOR_MDR_X3: 0 fp32-input MFMA; 1 exact bf16 x 3 split everywhere; 2 (default) that + the 431x431 attention on two fp16 planes
+    float c3_logit_bound = 0.f;         // bound on |q . k| / sqrt(d_k) of the MDR self-attention in the exp2 domain, from the weights (fused_create)
+    bool c3_guarded = false;            // ... exceeded 2^10: c3_mdr switched off for this ctx (GATOR_C3_GUARD=0: never)
     bool c3_mdr = true;                 // gator_forward_bf16 (BASELINE config 3): the MDR layers on one fp16 activation plane (GATOR_C3_MDR=0: fp32 form)
     bool c3_encoder = true;             // ... the encoder's token-wise products on one fp16 activation plane as well (GATOR_C3_ENCODER=0: the fp32 configuration's)
     bool c3_up_w1 = true;               // ... the vertex regressor's weights on ONE fp16 plane, coarse vertices on two (GATOR_C3_UPSAMPLE_W1=0: weights on two)

@@ -123,6 +123,7 @@ int fused_upsample_bf16(gator_ctx* c, const float* vert431, int B, float* verts,
 int fused_set_joint_regressor(gator_ctx* c, const int32_t* row, const int32_t* col, const float* val, int nnz, int nj);
 int fused_forward_joints(gator_ctx* c, const float* pose2d, int B, float* joints, float* pose3d, float* verts, void* stream);
 int fused_set_encoder(gator_ctx* c, int mode);
+int fused_c3_state(const gator_ctx* c, float* bound);
 void fused_disable_persist(gator_ctx* c);
 int fused_set_graph_replay(gator_ctx* c, int on);          // returns the number of graph launches so far (>= 0)
 // samples of a batch of B that the sample-tiled encoder takes under the policy in force (unpinned: under the ctx's own AUTO policy)

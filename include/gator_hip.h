@@ -135,6 +135,12 @@ int gator_forward_f32(gator_ctx* ctx, const float* pose2d, int32_t batch, float*
  * GATOR_C3_UPSAMPLE_BF16=1 (round 4's form of the regressor: both operands one bf16 plane, 8 mm max / 1 mm rms).
  * gator_upsample_bf16: the stage entry point of that bf16 vertex regressor. */
 int gator_forward_bf16(gator_ctx* ctx, const float* pose2d, int32_t batch, float* verts, float* pose3d, void* stream);
+/* Guard of that mode (round 6).  One fp16 plane moves an attention score by up to 2^-11 |q| |k|; gator_create bounds |q . k| / sqrt(d_k) of the three
+ * 431 x 431 self-attentions from the weights alone (sigma_max(Wq_h^T Wk_h) x the custom LayerNorm's bound on |x|^2, exp2 domain).  Above 2^10 the MDR
+ * layers and the encoder of gator_forward_bf16 keep gator_forward_f32's two planes for this ctx (the vertex regressor stays in the mode); GATOR_C3_GUARD=0
+ * switches the guard off.  Returns 1 if the MDR layers run on one plane under gator_forward_bf16, 0 if not (guard, GATOR_C3_MDR=0 or a ctx without the
+ * default operand forms), negative on error; *logit_bound (may be NULL) receives the bound. */
+int gator_c3_state(gator_ctx* ctx, float* logit_bound);
 int gator_upsample_bf16(gator_ctx* ctx, const float* vert431, int32_t batch, float* verts, void* stream);
 
 /* Stage entry points (parity tests; same semantics as the reference sub-modules):

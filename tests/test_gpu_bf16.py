@@ -99,7 +99,7 @@ def test_config3_2048_samples_every_coordinate():
 
 
 @pytest.mark.parametrize('gain', [3.0, 8.0])
-def test_config3_attention_long_way_under_large_logits(gain):
+def test_config3_attention_long_way_under_large_logits(gain, monkeypatch):
     """The one-plane attention proves the fp16 range of its probabilities by their row sums and redoes a tile the long way (maximum,
     rescale, new reference) where that fails; with the shipped synthetic weights only the first tile of a head does.  Here the q / k
     projections of all three layers are scaled so that the logits grow 9 x / 64 x: tiles jump by more than 2^9 all the time.  The
@@ -115,12 +115,14 @@ def test_config3_attention_long_way_under_large_logits(gain):
                 sd[k] = sd[k] * gain
                 sd_o[k] = sd_o[k] * gain
     m.load_state_dict(sd)
+    monkeypatch.setenv('GATOR_C3_GUARD', '0')      # this test is about the long-way path of the one-plane loop: the guard (next test) would take gain 8 out of the mode
     m = m.cuda()
     m.precision = 'bf16'
     x = torch.from_numpy(synthetic.synthetic_pose2d(24, 17, seed=9))
     v, p = m(x.cuda())
     torch.cuda.synchronize()
     m.device_status()
+    assert m.c3_state()[0]
     assert torch.isfinite(v).all()
     r64, _ = go.gator_forward(sd_o, c, x, torch.float64)
     e = np.abs(v.cpu().numpy().astype(np.float64) - r64.numpy()) * 1e3
@@ -145,6 +147,38 @@ def test_config3_attention_long_way_under_large_logits(gain):
     v2, _ = m(x.cuda())
     vs, _ = m(x[5:9].cuda())
     assert torch.equal(v, v2) and torch.equal(vs, v[5:9])
+
+
+@pytest.mark.parametrize('gain,one_plane', [(1.0, True), (3.0, True), (8.0, False)])
+def test_config3_guard_keeps_two_planes_under_sharp_attention(gain, one_plane):
+    """Round 6: gator_create bounds the self-attention logits from the weights (sigma_max(Wq_h^T Wk_h) x the custom LayerNorm's bound on
+    |x|^2); above 2^10 in the exp2 domain the MDR layers of gator_forward_bf16 keep two planes for that ctx.  The shipped synthetic weights (bound ~50)
+    and the logits-x-9 weights (~470, measured 0.63 mm) stay in the mode; logits x 64 (~3 300, measured 7.6 mm in the mode) fall out of it and meet
+    the mode's bar again -- a checkpoint with sharp attention degrades in speed, not silently in millimetres."""
+    from oracle import gator_oracle as go
+    z, m = build_model('h36m17_bn', 'fused', device=None)
+    zz, c, sd_o = oracle_setup('h36m17_bn')
+    sd = m.state_dict()
+    for sfx in ('', '_1', '_2'):
+        for n in (0, 1):
+            for leaf in ('weight', 'bias'):
+                k = 'pose2mesh.selfatt%s.linears.%d.%s' % (sfx, n, leaf)
+                sd[k] = sd[k] * gain
+                sd_o[k] = sd_o[k] * gain
+    m.load_state_dict(sd)
+    m = m.cuda()
+    m.precision = 'bf16'
+    x = torch.from_numpy(synthetic.synthetic_pose2d(24, 17, seed=9))
+    v, p = m(x.cuda())
+    torch.cuda.synchronize()
+    m.device_status()
+    state, bound = m.c3_state()
+    r64, _ = go.gator_forward(sd_o, c, x, torch.float64)
+    e = np.abs(v.cpu().numpy().astype(np.float64) - r64.numpy()) * 1e3
+    print('\n[config 3 guard, logit gain %.0f^2] bound %.0f -> MDR layers on %s; vs fp64: max %.3f mm rms %.4f mm' % (gain, bound, 'one plane' if state else 'two planes', e.max(), np.sqrt((e ** 2).mean())))
+    assert state == one_plane
+    assert (bound <= 1024.0) == one_plane
+    assert e.max() < 1.0 and np.sqrt((e ** 2).mean()) < 0.2
 
 
 def test_config3_persistent_launch_equals_four_launches_bitwise(monkeypatch):
