@@ -117,6 +117,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('libgator_hip.so not built (%s); run `python -m gator_amd.build` -- there is no CPU fallback'
                                % LIB_PATH)
+        # torch first: it ships its own libamdhip64, and the HIP runtime that is loaded FIRST is the one every later library binds to.  Loaded
+        # before torch, this library would pull in the system's copy and the process would hold two runtimes -- tensors in one, gator_create
+        # ("no HIP device available") in the other (seen with __graft_entry__.build() followed by smoke() in one process).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
