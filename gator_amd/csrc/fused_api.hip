@@ -46,7 +46,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
                  o_q = take(9 * tiles / 2), o_k = take(9 * tiles / 2), o_v = take(9 * tiles / 2) /* THREE tile sets each (k_mdr_persist writes every set once per forward); q/k/v sized for X3 tiles (1.5x) */, o_jkv = take((size_t)cap * 12 * kTile),
                  o_hf = take((size_t)cap * kV * 32), o_lbf = take((size_t)cap * kV * kE), o_feat = take((size_t)cap * J * kC),
                  o_xout = take((size_t)cap * J * 3), o_pc = take((size_t)cap * J * 133),
-                 o_vcp3 = take(std::max(upsample_x3_vcp_elems(cap), upsample_x2_vcp_elems(cap)) / 2), o_lpart = take(gat_tail_part_floats(cap, J)), o_ctr = take(mdr_ctr_words(cap));
+                 o_vcp3 = take(std::max(upsample_x3_vcp_elems(cap), upsample_x2_vcp_elems(cap)) / 2), o_lpart = take(gat_tail_part_floats(cap, J)), o_ctr = take(mdr_ctr_words(cap)), o_hpart = take((size_t)cap * kVT * 128);
     GATOR_HIP_CHECK(hipMalloc(&f->ws, n * sizeof(float)));
     GATOR_HIP_CHECK(hipMemset(f->ws, 0, n * sizeof(float)));
     GATOR_HIP_CHECK(hipDeviceSynchronize());      // the memset runs on the null stream; a non-blocking stream would not wait for it
@@ -56,6 +56,7 @@ int fused_ensure_ws(gator_ctx* c, int B) {
     f->v = f->ws + o_v; f->jkv = f->ws + o_jkv; f->hf = f->ws + o_hf; f->lbf = f->ws + o_lbf; f->feat = f->ws + o_feat;
     f->xout = f->ws + o_xout; f->pc = f->ws + o_pc; f->vcp3 = f->ws + o_vcp3; f->lpart = f->ws + o_lpart;
     f->mdr_ctr = reinterpret_cast<unsigned*>(f->ws + o_ctr);
+    f->hpart = f->ws + o_hpart;      // (64-float aligned offsets: 8-byte alignment of the doubles holds)
     return GATOR_OK;
 }
 

@@ -38,6 +38,7 @@ struct FusedWs {
     float *hf = nullptr;                // [B][431][32] head features
     float *lbf = nullptr;               // [B][431][64] tap: verts tokens after LBF3 (reference layout)
     float *feat = nullptr, *xout = nullptr, *pc = nullptr;
+    float* hpart = nullptr;             // [cap][14][64] DOUBLES: the head conv's per-tile partial sums (mdr_fused.hip: head_conv_partial)
     float *lpart = nullptr;             // [MT][J][2][kTile] lifter partial tiles (gat_tail.hip)
     bool mdr_ctr_clean = false;         // the joint-token kernel queued before launch_mdr has zeroed mdr_ctr for it
     unsigned* mdr_ctr = nullptr;        // k_mdr_persist: the counter blocks of a forward's launches, mdr_ctr_words(cap) words (mdr_fused.hip: MdrChunkPlan)

@@ -63,6 +63,10 @@ struct MdrArgs {
     float *hf, *lbf;
     LayerW prev, cur;        // prev: layer whose attention/out-proj runs first; cur: layer whose tokenwise part runs
     float lin_s, lin_inv;    // GATOR_MDR_X3=2: every token-wise linear returns lin_s x its value (x3_common.h: 4-product linears); lin_inv = 1 / lin_s
+    // the head's Conv1d(431 -> 20, k3, p1) (MDR.py:121,163) as per-tile partial sums made by the tile that has the tokens' bias features in registers (round 6)
+    double* hpart;           // [B][14][64] (60 used: row m, position l at m * 3 + l); nullptr: not computed (the A/B form with k_mdr_head)
+    const float *bconv_w, *hbn_w, *hbn_b, *hbn_mean, *hbn_var;
+    int halpha;
 #ifdef GATOR_DIAG
     unsigned long long* stamps;   // diagnostic build only (libgator_hip_diag.so, GATOR_MDR_STAMPS=1)
 #endif
@@ -819,6 +823,98 @@ __device__ __forceinline__ void gelu_tile_table(f32x16& v, float k, const float*
 // per-channel vectors of a stage (biases, norm weights) staged once per workgroup in LDS
 enum { VO_SA3B = 0, VO_N1W = 64, VO_N1B = 128, VO_PROJB = 192, VO_N2W = 256, VO_N2B = 320, VO_FC2B = 384, VO_A2 = 448, VO_B2 = 512,
        VO_SA0B = 576, VO_SA1B = 640, VO_HEADB = 704, VO_FC1B = 768, VO_TOKW3 = 1024, VO_TOTAL = 1216 };
+// ---- the head's Conv1d(431 -> 20, kernel 3, padding 1 over the xyz axis; MDR.py:121,163) as per-tile partial sums ------------------------------
+// Until round 6 k_mdr_head did the whole conv per sample: a 15 us launch of its own whose conv loop and cross-lane sums were most of its chain.  The tile
+// that computes a token's head features has the conv's input -- the token's three bias features -- in registers, so it leaves the tile's 60 partial sums
+// (20 rows x 3 positions over its 32 tokens) behind; the finish (head_finish: sum of the 14 partials in tile order, softmax-mix per token) is light.
+// Everything in double: each product exact, fixed association -- the result does not depend on who computes it.
+// The finish stays a launch of its own (11 us against k_mdr_head's 15): inside the persistent launch -- as a fifth ticket stage, or run by the workgroup that
+// publishes a sample's last tile -- it measured +8 .. +51 us, because the last ~18 samples of an XCD finish together at the launch's end and their heads then
+// stand behind the last tile instead of beside each other (DESIGN 4c'', profiles/r06_fused_head_stage.txt, docs/history/r06_inlaunch_head.patch).
+__device__ __forceinline__ double dpp_mov_f64t(double v, int which) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+    if (which == 0) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false); }             // quad_perm [1,0,3,2]
+    else if (which == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); }        // quad_perm [2,3,0,1]
+    else if (which == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, false); }      // row_half_mirror
+    else { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xf, 0xf, false); }                      // row_mirror
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// Sum of 32 values per lane over the 32 lanes of its half (lanes 0..31 | 32..63) as a reduce-scatter: at step s a lane hands the half of its list that its partner
+// keeps (row mirror, half-row mirror, quad reverse, quad swap, v_permlane16_swap) and adds what it receives to the half it keeps -- 16 + 8 + 4 + 2 + 1 exchanges
+// instead of 32 x 5, and lane p ends with the total of entry slot32(p).  A fixed tree: the result does not depend on who runs it.
+// the partner's value at step s.  The partner must hold the SAME entries as the lane, i.e. differ from it only in bits that have not been decided yet: the row
+// mirror (15 - i: flips bits 0..3, decided: bit 3), the half-row mirror (7 - i: bits 0..2, decided: bit 2), the quad reverse (3 - i: bits 0, 1, decided: bit 1), the
+// quad swap (bit 0), v_permlane16_swap (bit 4)
+__device__ __forceinline__ double lane_xchg_f64(double v, int step) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+    if (step == 0) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xf, 0xf, false); }           // row_mirror
+    else if (step == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, false); }      // row_half_mirror
+    else if (step == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x1B, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x1B, 0xf, 0xf, false); }        // quad_perm [3,2,1,0]
+    else if (step == 3) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false); }        // quad_perm [1,0,3,2]
+    else {
+        const auto rl = __builtin_amdgcn_permlane16_swap((unsigned)lo, (unsigned)lo, false, false), rh = __builtin_amdgcn_permlane16_swap((unsigned)hi, (unsigned)hi, false, false);
+        const bool up = (threadIdx.x & 16) != 0;      // [0]: the value of the lane with bit 4 clear, [1]: with bit 4 set
+        lo = (int)(up ? rl[0] : rl[1]); hi = (int)(up ? rh[0] : rh[1]);
+    }
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// the lane keeps the upper half of its list iff the step's deciding bit of its own index is set; its partner (the other value of that bit) keeps the other half
+template <int N, int STEP, int BIT>
+__device__ __forceinline__ void rs_step(double (&v)[32], int lane) {
+    const bool up = ((lane >> BIT) & 1) != 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double send = up ? v[i] : v[N + i], keep = up ? v[N + i] : v[i];
+        v[i] = keep + lane_xchg_f64(send, STEP);
+    }
+}
+// -> the lane's total and (slot) which of the 32 entries it is the total of
+__device__ __forceinline__ double half_reduce_scatter32(double (&v)[32], int lane, int& slot) {
+    rs_step<16, 0, 3>(v, lane);
+    rs_step<8, 1, 2>(v, lane);
+    rs_step<4, 2, 1>(v, lane);
+    rs_step<2, 3, 0>(v, lane);
+    rs_step<1, 4, 4>(v, lane);
+    slot = 16 * ((lane >> 3) & 1) + 8 * ((lane >> 2) & 1) + 4 * ((lane >> 1) & 1) + 2 * (lane & 1) + ((lane >> 4) & 1);
+    return v[0];
+}
+// lane (token, h) of a T-layout tile: `x` = the token's bias features after bias_norm + GELU (MDR.py:159-160; zeros for a token that does not exist).  Half h makes
+// rows m = 10 h .. 10 h + 9: position l of row m collects tap k of the input at l + k - 1.  `dst`: the tile's 64 doubles, entry (m, l) at m * 3 + l.
+__device__ __forceinline__ void head_conv_partial(const float* __restrict__ bconv_w, int token, const float (&x)[3], int lane, double* __restrict__ dst) {
+    const int h = lane >> 5;
+    const float* wp = bconv_w + (size_t)(10 * h) * (kV * 3) + 3 * (token < kV ? token : 0);
+    double v[32];
+#pragma unroll
+    for (int mm = 0; mm < 10; ++mm) {      // per token in fp32 (three products each: the shipped head's lanes ran 21-term fp32 chains), across tokens and tiles in double
+        const float w0 = wp[mm * (kV * 3)], w1 = wp[mm * (kV * 3) + 1], w2 = wp[mm * (kV * 3) + 2];
+        v[mm * 3 + 0] = (double)fmaf(w2, x[1], w1 * x[0]);
+        v[mm * 3 + 1] = (double)fmaf(w2, x[2], fmaf(w1, x[1], w0 * x[0]));
+        v[mm * 3 + 2] = (double)fmaf(w1, x[2], w0 * x[1]);
+    }
+    v[30] = 0.0; v[31] = 0.0;
+    int slot;
+    const double tot = half_reduce_scatter32(v, lane, slot);
+    if (slot < 30) dst[30 * h + slot] = tot;
+}
+// bias_norm (BatchNorm1d(431) over the vertex axis in eval mode, or LayerNorm(3) in the alpha variant) + GELU of a token's three bias features (MDR.py:159-160)
+__device__ __forceinline__ void head_bias_act(bool alpha, const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, int v, float (&x)[3]) {
+    if (alpha) {      // LayerNorm(3)
+        const float m = (x[0] + x[1] + x[2]) / 3.0f;
+        const float qq = ((x[0] - m) * (x[0] - m) + (x[1] - m) * (x[1] - m) + (x[2] - m) * (x[2] - m)) / 3.0f;
+        const float rs = 1.0f / sqrtf(qq + 1e-5f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = (x[c] - m) * rs * bn_w[c] + bn_b[c];
+    } else {          // BatchNorm1d(431) eval: channel = vertex
+        const float rs = 1.0f / sqrtf(bn_var[v] + 1e-5f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = (x[c] - bn_mean[v]) * rs * bn_w[v] + bn_b[v];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x[c] = gelu_f(x[c]);
+}
+
 constexpr int kParkF4 = 8 * 256;       // f32x4 slots of the residual-stream parking area (split-precision forms only)
 
 // cooperative (256 threads); the caller puts a barrier behind it
@@ -848,7 +944,7 @@ __device__ __forceinline__ void mdr_stage_vectors(const MdrArgs& a, float* VT) {
 
 // one wave, one 32-token tile `id` = sample * 14 + tile of the sample
 template <int MODE, int XA>
-__device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const float* VT, f32x4* park, const float* GT = nullptr) {
+__device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const float* VT, f32x4* park, const float* GT = nullptr, const MdrArgs* a_mem = nullptr) {      // a_mem: the same arguments IN MEMORY (kernel-argument segment)
     constexpr bool X = XA != 0;
     constexpr int TQ = XA == 1 ? kTileX3 : (XA == 3 ? kTileX1 : kTile);
     auto park_vf = [&](const f32x16 (&v)[2]) {
@@ -998,6 +1094,21 @@ __device__ __forceinline__ void mdr_tile(const MdrArgs& a, const int id, const f
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v4[j] = acc[4 * g + j];
                 *reinterpret_cast<f32x4*>(a.hf + ((size_t)b * kV + token) * 32 + 8 * g + 4 * h) = v4;
+            }
+        }
+        {   // the head conv's partial sums over this tile's tokens (their bias features are channels 24..26 = registers 12..14 of the lower half's lanes)
+            const MdrArgs* ah = a_mem;        // (taking the address of a by-value kernel argument would copy all of it to scratch)
+            asm volatile("" : "+s"(ah));      // its fields are fetched here, behind the tile body: nothing of them lives across it
+            if (ah != nullptr && ah->hpart) {
+                float x[3] = {acc[12], acc[13], acc[14]};
+                if (h == 0 && token < kV) head_bias_act(ah->halpha != 0, ah->hbn_w, ah->hbn_b, ah->hbn_mean, ah->hbn_var, token, x);
+                else { x[0] = x[1] = x[2] = 0.f; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {      // the upper half works on the same tokens: rows 10..19
+                    const float other = xhalf(x[c]);
+                    x[c] = h ? other : x[c];
+                }
+                head_conv_partial(ah->bconv_w, token, x, lane, ah->hpart + ((size_t)b * kVT + t) * 64);
             }
         }
         return;
@@ -1203,7 +1314,8 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
     if constexpr (XA == 3 && MODE < 2 && kX1GeluTable) gelu_table_fill(GT);
     mdr_stage_vectors<MODE, XA>(a, VT);
     __syncthreads();
-    mdr_tile<MODE, XA>(a, xcd_remap(blockIdx.x, nwg) * 4 + (threadIdx.x >> 6), VT, park, GT);
+    mdr_tile<MODE, XA>(a, xcd_remap(blockIdx.x, nwg) * 4 + (threadIdx.x >> 6), VT, park, GT,
+                       (const MdrArgs*)(const __attribute__((address_space(4))) MdrArgs*)__builtin_amdgcn_kernarg_segment_ptr());      // `a` is the first kernel argument
 }
 
 // ---- all four stages in ONE persistent launch -------------------------------------------------------------------------------
@@ -1234,10 +1346,6 @@ __global__ __launch_bounds__(256, 2) void k_mdr_layer(const MdrArgs a, int nwg) 
 // {stage arguments, ctr}: the tile body needs every scalar register there is, and each further scalar that must survive it
 // (measured with a base pointer, an offset and a stride more) is spilled into VGPR lanes and reloaded in its loops: +30 - 40 us.
 constexpr int kCtrError = 8, kCtrDone = 32;
-struct MdrPersistArgs {
-    MdrArgs st[4];            // their B and every per-sample pointer are this launch's CHUNK of the batch
-    unsigned* ctr;            // this launch's counter block
-};
 // chunk plan of a forward of B samples in nch launches: the first B % nch chunks have one sample more.  -> (chunk, first sample, size)
 // of sample b, and the word offset of a chunk's counter block
 struct MdrChunkPlan {
@@ -1251,6 +1359,109 @@ struct MdrChunkPlan {
         const int big = ch < rem ? ch : rem;
         return (size_t)ch * kCtrDone + 4 * ((size_t)big * (base + 1) + (size_t)(ch - big) * base);
     }
+};
+
+struct HeadArgs {
+    const float *hf, *bn_w, *bn_b, *bn_mean, *bn_var, *bconv_w, *bconv_b;
+    float *vc, *vcp;
+    __bf16* vcp3;           // non-null: write the hi/mid/lo bf16 planes of the split-precision vertex GEMM instead of vcp
+    size_t vcp3_plane;
+    _Float16* vcp2;         // non-null: write the scaled hi/lo fp16 planes of the two-plane vertex GEMM (upsample_x2.hip) instead
+    const unsigned* persist_ctr;   // non-null: the counter blocks of the forward's persistent launches.  The sample's launch must not have tripped its
+    MdrChunkPlan plan;             // hang guard and must have counted all 14 last-stage tiles of the sample; else its vertices are NaN (loud, not silent)
+    unsigned* status;              // the ctx's sticky device status word (host-mapped; internal.h: DeviceStatus), read by the next API call
+    int alpha;
+};
+
+// where a coarse vertex coordinate goes: the reference layout (tap / stage API) and the packed A operand of whichever vertex GEMM the ctx runs
+__device__ __forceinline__ void head_store(const HeadArgs& a, int b, int v, int c, float val) {
+    const int mt = b >> 5, sl = b & 31;
+    a.vc[((size_t)b * kV + v) * 3 + c] = val;
+    if (a.vcp2) {       // two fp16 planes of 2^4 * val, in k_upsample_x2's operand order [mt/4][v/16][mt%4][l'][plane][lane][v%8]
+        const float sv = val * 16.0f;
+        const _Float16 hi = (_Float16)sv;
+        const _Float16 lo = (_Float16)(sv - (float)hi);
+        const size_t pair = ((((size_t)(mt >> 2) * 28 + (v >> 4)) * 4 + (mt & 3)) * 3 + c) * 2;
+        const size_t e = (size_t)(((v >> 3) & 1) * 32 + sl) * 8 + (v & 7);
+        a.vcp2[pair * 512 + e] = hi; a.vcp2[(pair + 1) * 512 + e] = lo;
+    } else if (a.vcp3) {       // exact three-way bf16 split, in k_upsample_x3's operand order [plane][mt][l'][v/16][lane][v%8]
+        const __bf16 hi = (__bf16)val;
+        const float r1 = val - (float)hi;
+        const __bf16 mid = (__bf16)r1;
+        const __bf16 lo = (__bf16)(r1 - (float)mid);
+        const size_t e = ((((size_t)mt * 3 + c) * 28 + (v >> 4)) * 64 + ((v >> 3) & 1) * 32 + sl) * 8 + (v & 7);
+        a.vcp3[e] = hi; a.vcp3[a.vcp3_plane + e] = mid; a.vcp3[2 * a.vcp3_plane + e] = lo;
+    } else {
+        const int cb = v >> 5, g = (v & 31) >> 3, hh = (v & 7) >> 2, j = v & 3;
+        a.vcp[(((((size_t)mt * 3 + c) * kCB + cb) * 4 + g) * 64 + hh * 32 + sl) * 4 + j] = val;
+    }
+}
+
+// ---- the head behind the tiles' conv partials (round 6): bias_conv1d's result = bias + the 14 partials in tile order; then per token the softmax-mix
+// of MDR.py:161-166.  One sample; `bc`: 60 floats of LDS; called by every thread of a workgroup of NT threads (k_mdr_head_finish).
+// Light by construction: no conv, no cross-lane sums.
+template <int NT>
+__device__ __forceinline__ void head_finish(const HeadArgs& a, const double* __restrict__ hpart_b, int b, bool poisoned, float (*bc)[3]) {
+    const int t = threadIdx.x, lane = t & 63;
+    const float* hf = a.hf + (size_t)b * kV * 32;
+    constexpr int NR = (kV + NT - 1) / NT;
+    // every global read up front: this thread's tokens' head features, and (threads 0..59) the partials of output (row, position) t
+    f32x4 row[NR][5], tail[NR], cc[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int v = t + NT * i;
+        const float* r = hf + (v < kV ? v : 0) * 32;
+#pragma unroll
+        for (int g = 0; g < 5; ++g) row[i][g] = *reinterpret_cast<const f32x4*>(r + 4 * g);
+        tail[i] = *reinterpret_cast<const f32x4*>(r + 24);
+        cc[i] = *reinterpret_cast<const f32x4*>(r + 28);
+    }
+    if (t < 60) {
+        double pv[kVT];
+#pragma unroll
+        for (int k = 0; k < kVT; ++k) pv[k] = hpart_b[k * 64 + t];
+        double s = pv[0];
+#pragma unroll
+        for (int k = 1; k < kVT; ++k) s += pv[k];
+        bc[t / 3][t % 3] = (float)(s + (double)a.bconv_b[t / 3]);
+    }
+    __syncthreads();
+    const float limit = a.vcp2 ? 4094.0f : 3.0e38f;      // (two-plane vertex regressor: 16 x value in an fp16 plane)
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int v = t + NT * i;
+        if (v < kV) {
+            float av[20];
+#pragma unroll
+            for (int g = 0; g < 5; ++g) { av[4 * g] = row[i][g][0]; av[4 * g + 1] = row[i][g][1]; av[4 * g + 2] = row[i][g][2]; av[4 * g + 3] = row[i][g][3]; }
+            float mx = -1e30f, p[20], l = 0.f;
+            for (int m = 0; m < 20; ++m) mx = fmaxf(mx, av[m]);
+            for (int m = 0; m < 20; ++m) {
+                p[m] = __builtin_amdgcn_exp2f((av[m] - mx) * kLog2e);
+                l += p[m];
+            }
+            const float il = 1.0f / l;
+            // alpha = 1.1 ** scale_linear(x)  (MDR.py:162): powf via double exp keeps it exact to fp32 rounding; once per token
+            const float sc = a.alpha ? (float)exp((double)tail[i][3] * 0.09531017980432493) : 1.0f;
+            for (int c = 0; c < 3; ++c) {
+                float o = 0.f;
+                for (int m = 0; m < 20; ++m) o += (p[m] * il) * bc[m][c];
+                float val = sc * o + cc[i][c];
+                if (poisoned) val = __builtin_nanf("");
+                bad = bad || !(fabsf(val) < limit);
+                head_store(a, b, v, c, val);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (a.status && __any(bad) && lane == 0)      // sticky, host-visible: the next API call on the ctx (or gator_device_status) reports it
+        __hip_atomic_store(a.status, poisoned ? (unsigned)DEV_PERSIST_INCOMPLETE : (unsigned)DEV_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct MdrPersistArgs {
+    MdrArgs st[4];            // their B and every per-sample pointer are this launch's CHUNK of the batch
+    unsigned* ctr;            // this launch's counter block
 };
 // (Round 5, measured and dropped: the one-plane form XA = 3 built for 168 registers and launched with THREE workgroups per CU -- a SIMD
 // issues the vector instructions of three waves faster than of two, tools/microbench/valu_rate.hip -- spills 164 B per lane even with
@@ -1319,7 +1530,7 @@ __global__ __launch_bounds__(256, 2) void k_mdr_persist(const MdrPersistArgs p) 
             // alone +30 us.)  The compiler barrier keeps the tile's loads behind the poll.
             asm volatile("" ::: "memory");
         }
-        mdr_tile<MODE, XA>(a, id, VT, park, GT);
+        mdr_tile<MODE, XA>(a, id, VT, park, GT, &a);
         // Release to the same L2: the L1 is write-through, so once the stores are acknowledged (vmcnt 0) every CU of the XCD
         // sees them; then the count goes up (an atomic executed in that L2).  The last stage counts too (for k_mdr_head, see above).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1439,17 +1650,6 @@ __device__ __forceinline__ double wave_sum64_f64(double s) {
 // MDR head (MDR.py:156-166) from the per-token head features hf[b][v][32]:
 //   ch 0..19 = mat_A, 24..26 = bias_linear out, 27 = scale_linear out, 28..30 = mat_C   (our own packing order)
 // Writes vert431 both in the reference layout (tap / stage API) and as the packed A operand of the vertex GEMM.
-struct HeadArgs {
-    const float *hf, *bn_w, *bn_b, *bn_mean, *bn_var, *bconv_w, *bconv_b;
-    float *vc, *vcp;
-    __bf16* vcp3;           // non-null: write the hi/mid/lo bf16 planes of the split-precision vertex GEMM instead of vcp
-    size_t vcp3_plane;
-    _Float16* vcp2;         // non-null: write the scaled hi/lo fp16 planes of the two-plane vertex GEMM (upsample_x2.hip) instead
-    const unsigned* persist_ctr;   // non-null: the counter blocks of the forward's persistent launches.  The sample's launch must not have tripped its
-    MdrChunkPlan plan;             // hang guard and must have counted all 14 last-stage tiles of the sample; else its vertices are NaN (loud, not silent)
-    unsigned* status;              // the ctx's sticky device status word (host-mapped; internal.h: DeviceStatus), read by the next API call
-    int alpha;
-};
 // One workgroup per sample, three short phases with a barrier between them.  The kernel is a LATENCY chain, not a throughput one
 // (18.7 us at B = 64, 24 us at B = 256, round-3 sweep): with HOIST every global read it will ever need -- this lane's 63 conv
 // weights, its token's 32 head features -- is issued before the first phase, and the phases run on registers and LDS only
@@ -1601,6 +1801,19 @@ __global__ __launch_bounds__(NT, HOIST ? 2 : 4) void k_mdr_head(const HeadArgs a
         __hip_atomic_store(a.status, poisoned ? (unsigned)DEV_PERSIST_INCOMPLETE : (unsigned)DEV_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+__global__ __launch_bounds__(256) void k_mdr_head_finish(const HeadArgs a, const double* __restrict__ hpart) {
+    __shared__ float bc[20][3];
+    const int b = blockIdx.x;
+    bool poisoned = false;
+    if (a.persist_ctr) {      // the sample's launch must not have tripped its hang guard and must have counted all 14 last-stage tiles
+        int ch, b0, n;
+        a.plan.locate(b, ch, b0, n);
+        const unsigned* blk = a.persist_ctr + a.plan.block(ch);
+        poisoned = blk[kCtrError] != 0u || blk[kCtrDone + (size_t)3 * n + (b - b0)] != (unsigned)kVT;
+    }
+    head_finish<256>(a, hpart + (size_t)b * kVT * 64, b, poisoned, bc);
+}
+
 LayerW make_layer(const FusedState* f, const gator_ctx* c, int li) {
     const MdrLayerP& p = f->lay[li];
     const MdrLayerW& r = c->w.lay[li];
@@ -1641,6 +1854,9 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     MdrArgs a{};
     a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.xout = pc ? nullptr : x_out; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
     a.head_w = f->mdr_x3 ? f->wxbuf + (size_t)(f->head_w - f->lay[0].wq) / kTile * kTileX3 : f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = c->block_taps ? f->lbf : nullptr;      // the "mdr_lbf2" tap costs 110 KB of stores per sample: recorded with the block taps only
+    static const bool head_partials = [] { const char* e = getenv("GATOR_MDR_HEAD_PARTIALS"); return !(e && atoi(e) == 0); }();      // default on; =0: the whole head in k_mdr_head (A/B)
+    a.hpart = head_partials ? reinterpret_cast<double*>(f->hpart) : nullptr;
+    a.bconv_w = w.bconv_w; a.hbn_w = w.bn_w; a.hbn_b = w.bn_b; a.hbn_mean = w.bn_mean; a.hbn_var = w.bn_var; a.halpha = c->alpha;
     a.lin_s = f->mdr_x3 == 2 ? std::ldexp(kActScale, f->mdr_wshift) : 1.0f;      // 4-product linears: 16 x activations, 2^wshift x weights
     a.lin_inv = 1.0f / a.lin_s;
     const int nwg = (B * kVT + 3) / 4;
@@ -1755,6 +1971,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
                 if (s.pc) s.pc += (size_t)b0 * c->J * 133;
                 if (s.xout) s.xout += (size_t)b0 * c->J * 3;
                 s.hf += (size_t)b0 * kV * 32;
+                if (s.hpart) s.hpart += (size_t)b0 * kVT * 64;
                 if (s.lbf) s.lbf += (size_t)b0 * kV * kE;
             }
             pc_.ctr = f->mdr_ctr + plan.block(ch);
@@ -1818,7 +2035,8 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     ha.alpha = c->alpha;
     {
         StageTimer tm(c, "mdr_head", stream);
-        if (B <= 2 * f->n_cu) k_mdr_head<512, true><<<B, 512, 0, st>>>(ha);
+        if (a.hpart) k_mdr_head_finish<<<B, 256, 0, st>>>(ha, a.hpart);      // the conv came out of the tiles as partial sums: what is left is light
+        else if (B <= 2 * f->n_cu) k_mdr_head<512, true><<<B, 512, 0, st>>>(ha);
         else k_mdr_head<512, false><<<B, 512, 0, st>>>(ha);
     }
     GATOR_HIP_CHECK(hipGetLastError());

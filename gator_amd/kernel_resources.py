@@ -11,7 +11,7 @@ import sys
 # k_mdr_layer<*, 0>, k_mdr_persist<0>) and the all-bf16x3 form (k_mdr_layer<*, 1>, k_mdr_persist<1>) are A/B variants, not checked.
 HOT = ('k_gat<true', 'k_gat8', 'k_gat_lifter', 'k_gat_joint', 'k_gat_tiled<', 'k_mdr_layer<0, 2>', 'k_mdr_layer<1, 2>', 'k_mdr_layer<2, 2>', 'k_mdr_persist<2>',
        'k_mdr_layer<0, 3>', 'k_mdr_layer<1, 3>', 'k_mdr_layer<2, 3>', 'k_mdr_persist<3>',
-       'k_mdr_head<', 'k_upsample_x3', 'k_upsample_x2', 'k_upsample_bf16', 'k_regress', 'k_jreg_reduce', 'k_joint_errors', 'k_rigid_align', 'k_preprocess')
+       'k_mdr_head<', 'k_mdr_head_finish', 'k_upsample_x3', 'k_upsample_x2', 'k_upsample_bf16', 'k_regress', 'k_jreg_reduce', 'k_joint_errors', 'k_rigid_align', 'k_preprocess')
 SCRATCH_BUDGET = {}      # (round 6: k_gat_tiled's entries are gone -- its scratch was a hoisted sum, gat_tiled.hip: aggregate)
 _FIELD = re.compile(r'remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)')
 _NAME = re.compile(r'remark:\s+Function Name: (\S+)')
