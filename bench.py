@@ -352,10 +352,12 @@ def cpu_baseline(model, base, alpha, J):
     bb = max(per_b, key=per_b.get)
     legit = None      # is the port a fair stand-in?  measured in the dev container against the imported reference (tools/cpu_port_vs_reference.py)
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r05_cpu_port_vs_reference.json')) as fh:
+        import glob
+        rec = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r[0-9][0-9]_cpu_port_vs_reference.json')))[-1]      # the newest round's record
+        with open(rec) as fh:
             d = json.load(fh)
         legit = {'oracle_over_reference_by_batch': {k: v['oracle_over_reference'] for k, v in d['per_batch'].items()}, 'threads': d['threads'],
-                 'where': 'dev container (8 shared vCPUs, timing noise +-25 %), separate processes, profiles/r05_cpu_port_vs_reference.txt'}
+                 'where': 'dev container (8 shared vCPUs), separate processes, profiles/%s' % os.path.basename(rec).replace('.json', '.txt')}
     except Exception:
         pass
     return {'value': round(per_b[bb], 1), 'unit': 'meshes/sec', 'cores': int(nt), 'kind': 'port', 'port_vs_reference': legit,

@@ -131,6 +131,9 @@ def gat_forward(sd, c, pose2d, dtype=torch.float32, taps=None, p='pose_lifter.')
     return x_out, feat
 
 
+_ATTN_KEPT = {}
+
+
 def _custom_ln(x, a2, b2, eps=1e-6):
     """lib/models/vanilla_transformer_encoder.py:31-34 -- unbiased std, eps added to std."""
     mean = x.mean(-1, keepdim=True)
@@ -177,6 +180,7 @@ def mdr_forward(sd, c, pc, dtype=torch.float32, taps=None, p='pose2mesh.', train
                       for n in range(3)]
         sc = torch.matmul(qq, kk.transpose(-2, -1)) / math.sqrt(d)
         pa = F.softmax(sc, dim=-1)
+        _ATTN_KEPT[li] = pa                    # vanilla_transformer_encoder.py:91 keeps self.attn: three maps stay allocated between forwards
         xo = torch.matmul(pa, vv).transpose(1, 2).contiguous().view(B, -1, E)
         vf = vf + F.linear(xo, g(sa + '3.weight'), g(sa + '3.bias'))
         if taps is not None:

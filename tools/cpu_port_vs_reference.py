@@ -9,7 +9,7 @@ process the two disturb each other (the reference module keeps its three 380 MB 
 whichever runs second at B = 256 is up to 2 x slower -- measured both ways round).  One more process checks that the two agree
 (<= 1e-3 mm) on the timed inputs.
 
-    python tools/cpu_port_vs_reference.py [--reps 10] [--threads N] > profiles/r05_cpu_port_vs_reference.txt
+    python tools/cpu_port_vs_reference.py [--reps 10] [--threads N] --json profiles/r06_cpu_port_vs_reference.json > profiles/r06_cpu_port_vs_reference.txt
 
 The reference never travels to the GPU box; this figure (oracle / reference meshes per second) is what bench.py quotes beside its
 CPU baseline as `port_vs_reference`.
