@@ -322,6 +322,7 @@ def cpu_baseline(model, base, alpha, J):
     from oracle import gator_oracle as go
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     c = go.Consts(J, synthetic.model_j_regressor(J), base, alpha)
+    go.KEEP_ATTENTION_MAPS = True       # as the reference's modules do between forwards (oracle/gator_oracle.py); released below
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -349,6 +350,8 @@ def cpu_baseline(model, base, alpha, J):
                 go.gator_forward(sd, c, x, torch.float32)
                 ts.append(time.perf_counter() - t0)
             per_b[B] = B / float(np.median(ts))
+    go.KEEP_ATTENTION_MAPS = False
+    go._ATTN_KEPT.clear()
     bb = max(per_b, key=per_b.get)
     legit = None      # is the port a fair stand-in?  measured in the dev container against the imported reference (tools/cpu_port_vs_reference.py)
     try:

@@ -132,6 +132,9 @@ def gat_forward(sd, c, pose2d, dtype=torch.float32, taps=None, p='pose_lifter.')
 
 
 _ATTN_KEPT = {}
+KEEP_ATTENTION_MAPS = False     # timing runs only (bench.py cpu_baseline, tools/cpu_port_vs_reference.py): the reference's MultiHeadedAttention keeps self.attn
+                                # (vanilla_transformer_encoder.py:91), so its three maps stay allocated between forwards and the next forward's temporaries land on
+                                # warm pages; a port that frees them pays first-touch page faults the reference does not (0.73 against 0.93 of its speed)
 
 
 def _custom_ln(x, a2, b2, eps=1e-6):
@@ -180,7 +183,8 @@ def mdr_forward(sd, c, pc, dtype=torch.float32, taps=None, p='pose2mesh.', train
                       for n in range(3)]
         sc = torch.matmul(qq, kk.transpose(-2, -1)) / math.sqrt(d)
         pa = F.softmax(sc, dim=-1)
-        _ATTN_KEPT[li] = pa                    # vanilla_transformer_encoder.py:91 keeps self.attn: three maps stay allocated between forwards
+        if KEEP_ATTENTION_MAPS:
+            _ATTN_KEPT[li] = pa
         xo = torch.matmul(pa, vv).transpose(1, 2).contiguous().view(B, -1, E)
         vf = vf + F.linear(xo, g(sa + '3.weight'), g(sa + '3.bias'))
         if taps is not None:

@@ -64,6 +64,7 @@ def build_reference(J, alpha, seed):
 
 def worker(side, J, reps, nt):
     torch.set_num_threads(nt)
+    go.KEEP_ATTENTION_MAPS = True        # the reference's modules keep theirs (vanilla_transformer_encoder.py:91)
     alpha = J == 19
     model, scratch, c, osd = build_reference(J, alpha, seed=0 if J == 17 else 100)
     res = {}
