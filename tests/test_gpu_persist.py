@@ -108,3 +108,22 @@ def test_unserved_queue_is_loud_and_the_ctx_falls_back(monkeypatch):
     torch.cuda.synchronize()
     m.device_status()
     assert torch.equal(v2, want_v) and torch.equal(p2, want_p)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('name,J,B', [('h36m17_bn', 17, 37), ('coco19_alpha', 19, 256)])
+def test_head_from_partial_sums_agrees_with_the_whole_head(monkeypatch, name, J, B):
+    """Round 6: the head's Conv1d leaves the stage-3 tiles as partial sums (double, fixed association) and k_mdr_head_finish adds the 14 of a sample;
+    GATOR_MDR_HEAD_PARTIALS=0 is the whole head in k_mdr_head (double sums over the sample in another order).  Same products, both exact in double:
+    the two forms may differ in the last place of the fp32 results only."""
+    x = torch.from_numpy(synthetic.synthetic_pose2d(B, J, seed=5)).cuda()
+    monkeypatch.setenv('GATOR_MDR_HEAD_PARTIALS', '0')
+    z, m0 = build_model(name, 'fused')
+    v0, p0 = m0(x)
+    monkeypatch.delenv('GATOR_MDR_HEAD_PARTIALS')
+    z, m1 = build_model(name, 'fused')
+    v1, p1 = m1(x)
+    torch.cuda.synchronize()
+    assert torch.equal(p0, p1)
+    assert torch.isfinite(v1).all()
+    assert float((v0 - v1).abs().max()) <= 2e-6            # metres: vertices are O(1) m, one fp32 ulp is 1.2e-7; the bar of the path is 1e-6 m = 1e-3 mm
