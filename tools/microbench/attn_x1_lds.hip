@@ -158,6 +158,59 @@ __global__ __launch_bounds__(NW * 64, 1) void k_lds(const float* __restrict__ Q,
     if (cyc && lane == 0) atomicAdd(cyc, __builtin_readcyclecounter() - t0);
 }
 
+
+// ---- inside the ticket design: the four waves of a workgroup run four consecutive query tiles of ONE sample (as the library's tickets mostly do) and share every
+// K / V tile through a two-slot LDS ring: each tile leaves the L2 once per workgroup (one 16 B load per thread) instead of once per wave; one workgroup barrier per
+// key tile keeps the four waves in step.
+template <int KT_LAST>
+__device__ __forceinline__ void ring_tile(const X1& kb, const X1& vb, const X1& qx, f32x16& O, f32x16& Ci, float& m, float& l, int h) {
+    ATTN_TILE_X1(KT_LAST, kb, vb)
+}
+__global__ __launch_bounds__(256, 2) void k_ring(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vv, float* __restrict__ Oo,
+                                                 int samples, int reps, unsigned long long* cyc) {
+    __shared__ __attribute__((aligned(16))) float ring[2][2][kTileX1];      // [slot][K | V]: 8 KiB
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const int ngroups = samples * 4;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int b = grp >> 2, tile = (grp & 3) * 4 + wave;
+        const bool valid = tile < kVT;
+        for (int r = 0; r < reps; ++r)
+#pragma unroll 1
+            for (int hd = 0; hd < 2; ++hd) {
+                const f32x4* src = reinterpret_cast<const f32x4*>((t < 128 ? K : Vv) + ((size_t)b * kVT * 2 + hd) * kTileX1) + (t & 127);     // + kt * (2 * kTileX1 / 4)
+                f32x4* dst0 = reinterpret_cast<f32x4*>(&ring[0][t >> 7][0]) + (t & 127);
+                f32x4* dst1 = reinterpret_cast<f32x4*>(&ring[1][t >> 7][0]) + (t & 127);
+                const X1 qx = x1_load(Q + ((size_t)(b * kVT + (valid ? tile : 0)) * 2 + hd) * kTileX1, lane);
+                f32x16 O = zero16();
+                float m = -1e30f, l = 0.f;
+                f32x16 Ci = f32x16(1e30f);
+                __syncthreads();                         // the ring is free
+                *dst0 = src[0];
+                __syncthreads();
+#pragma unroll 1
+                for (int kt = 0; kt < kVT - 1; ++kt) {
+                    const f32x4 nxt = src[(size_t)(kt + 1) * (2 * kTileX1 / 4)];           // the next tile's 16 B of this thread: in flight over this tile's work
+                    const float* slot = &ring[kt & 1][0][0];
+                    const X1 kb = tile_load<true>(slot, lane), vb = tile_load<true>(slot + kTileX1, lane);
+                    if (valid) ring_tile<0>(kb, vb, qx, O, Ci, m, l, h);
+                    *((kt & 1) ? dst0 : dst1) = nxt;
+                    __syncthreads();
+                }
+                {
+                    const float* slot = &ring[(kVT - 1) & 1][0][0];
+                    const X1 kb = tile_load<true>(slot, lane), vb = tile_load<true>(slot + kTileX1, lane);
+                    if (valid) ring_tile<kVT - 1>(kb, vb, qx, O, Ci, m, l, h);
+                }
+                if (valid) {
+                    l += xhalf(l);
+                    x1_store(Oo + ((size_t)(b * kVT + tile) * 2 + hd) * kTileX1, lane, x1_cvt(O * (1.0f / l)));
+                }
+            }
+    }
+    if (cyc && lane == 0) atomicAdd(cyc, __builtin_readcyclecounter() - t0);
+}
+
 static uint16_t f2h(float f) {
     _Float16 h = (_Float16)f;
     uint16_t u;
@@ -215,6 +268,7 @@ int main(int argc, char** argv) {
     run("lds  8 waves, K / V resident", [&] { hipLaunchKernelGGL(k_lds<8>, dim3(ncu), dim3(512), lds_bytes, 0, Q, K, V, O2, samples, reps, 0, cyc); }, ncu * 8);
     run("lds  7 waves, staged per attention", [&] { hipLaunchKernelGGL(k_lds<7>, dim3(ncu), dim3(448), lds_bytes, 0, Q, K, V, O2, samples, reps, 1, cyc); }, ncu * 7);
     run("lds  7 waves, K / V resident", [&] { hipLaunchKernelGGL(k_lds<7>, dim3(ncu), dim3(448), lds_bytes, 0, Q, K, V, O2, samples, reps, 0, cyc); }, ncu * 7);
+    run("ring 4 waves share K / V tiles in LDS", [&] { hipLaunchKernelGGL(k_ring, dim3(2 * ncu), dim3(256), 0, 0, Q, K, V, O2, samples, reps, cyc); }, 2 * ncu * 4);
     // the two forms compute the same thing
     std::vector<uint16_t> a(2 * n), b2(2 * n);
     CHECK(hipMemcpy(a.data(), O1, n * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(b2.data(), O2, n * 4, hipMemcpyDeviceToHost));
