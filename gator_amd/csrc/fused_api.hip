@@ -299,6 +299,7 @@ int fused_create(gator_ctx* c, void* stream) {
     f->mdr_persist_grid = mpg ? atoi(mpg) : 0;
     const char* mpc = getenv("GATOR_MDR_PERSIST_CHUNK");
     f->mdr_persist_chunk = mpc ? atoi(mpc) : 0;
+    if (const char* e = getenv("GATOR_MDR_HEAD_PARTIALS")) f->mdr_head_partials = atoi(e) != 0;
     const size_t n_up = f->x3 ? 0 : (size_t)3 * kOB * kCB * kTile, n_layer = (size_t)64 * kTile;
     const size_t total = n_up + 3 * n_layer + 24 * kTile + 64 + (size_t)kVT * 2 * kTile + 3 * 64 + 1024;
     GATOR_HIP_CHECK(hipMalloc(&f->wbuf, total * sizeof(float)));

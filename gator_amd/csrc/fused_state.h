@@ -75,6 +75,7 @@ struct FusedState : FusedWs {
     float* wxbuf = nullptr;             // X3 tiles of the MDR layer + head weights, tile-for-tile image of wbuf from lay[0].wq on
     int mdr_persist = -1;               // the four MDR stages as ONE persistent launch (k_mdr_persist): -1 by batch size (launch_mdr), GATOR_MDR_PERSIST=0 never, =1 always
     int mdr_persist_chunk = 0;          // GATOR_MDR_PERSIST_CHUNK: most samples per persistent launch (0: 384)
+    bool mdr_head_partials = true;      // GATOR_MDR_HEAD_PARTIALS=0 (read at create): the whole head in k_mdr_head instead of the tiles' conv partial sums + k_mdr_head_finish (A/B)
     int mdr_persist_grid = 0;           // GATOR_MDR_PERSIST_GRID: workgroups of the persistent launch (0: two per CU)
     float* jf128_h3 = nullptr;          // get_joint_feature columns 5..132 as H3 tiles [2][4] of 2^jf128_wshift * w (k_gat8's fused tail)
     int jf128_wshift = 0;

@@ -1854,8 +1854,7 @@ int launch_mdr(gator_ctx* c, FusedState* f, const float* pc, int B, void* stream
     MdrArgs a{};
     a.B = B; a.J = c->J; a.jkv = f->jkv; a.pc = pc; a.xout = pc ? nullptr : x_out; a.vj = w.vj; a.tok_base = f->tok_base; a.tok_w3 = f->tok_w3;
     a.head_w = f->mdr_x3 ? f->wxbuf + (size_t)(f->head_w - f->lay[0].wq) / kTile * kTileX3 : f->head_w; a.head_b = f->head_b; a.hf = f->hf; a.lbf = c->block_taps ? f->lbf : nullptr;      // the "mdr_lbf2" tap costs 110 KB of stores per sample: recorded with the block taps only
-    static const bool head_partials = [] { const char* e = getenv("GATOR_MDR_HEAD_PARTIALS"); return !(e && atoi(e) == 0); }();      // default on; =0: the whole head in k_mdr_head (A/B)
-    a.hpart = head_partials ? reinterpret_cast<double*>(f->hpart) : nullptr;
+    a.hpart = f->mdr_head_partials ? reinterpret_cast<double*>(f->hpart) : nullptr;      // default on; GATOR_MDR_HEAD_PARTIALS=0 at create: the whole head in k_mdr_head (A/B)
     a.bconv_w = w.bconv_w; a.hbn_w = w.bn_w; a.hbn_b = w.bn_b; a.hbn_mean = w.bn_mean; a.hbn_var = w.bn_var; a.halpha = c->alpha;
     a.lin_s = f->mdr_x3 == 2 ? std::ldexp(kActScale, f->mdr_wshift) : 1.0f;      // 4-product linears: 16 x activations, 2^wshift x weights
     a.lin_inv = 1.0f / a.lin_s;

@@ -126,4 +126,5 @@ def test_head_from_partial_sums_agrees_with_the_whole_head(monkeypatch, name, J,
     torch.cuda.synchronize()
     assert torch.equal(p0, p1)
     assert torch.isfinite(v1).all()
-    assert float((v0 - v1).abs().max()) <= 2e-6            # metres: vertices are O(1) m, one fp32 ulp is 1.2e-7; the bar of the path is 1e-6 m = 1e-3 mm
+    assert float((v0 - v1).abs().max()) <= 5e-7            # metres: vertices are O(1) m, one fp32 ulp is 1.2e-7 (measured: 2.4e-7, 64 % of the values bit-equal); the bar of the path is 1e-6 m
+    assert not torch.equal(v0, v1)                          # the switch is read at gator_create: if it were ignored the comparison above would be vacuous (drop this line should the forms ever agree bit for bit)
