@@ -560,6 +560,8 @@ def main():
             # MDR layers (bitwise the same results as the persistent launch).
             variants = {}
             vlist = (('headline, re-measured with the variants\' protocol (5 blocks, later in the run: clocks drift)', {}),
+                               ('round-5 form of the path: two tail launches, whole head in k_mdr_head (GATOR_GAT8_TAIL=0 GATOR_MDR_HEAD_PARTIALS=0)',
+                                {'GATOR_GAT8_TAIL': '0', 'GATOR_MDR_HEAD_PARTIALS': '0'}),
                                ('exact_split (GATOR_MDR_X3=1 GATOR_UPSAMPLE_X3=1 GATOR_GAT8_H4=0 GATOR_GAT_TILED_H4=0)',
                                 {'GATOR_MDR_X3': '1', 'GATOR_UPSAMPLE_X3': '1', 'GATOR_GAT8_H4': '0', 'GATOR_GAT_TILED_H4': '0'}),
                                ('six-product encoder (GATOR_GAT8_H4=0)', {'GATOR_GAT8_H4': '0'}),
