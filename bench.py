@@ -596,7 +596,7 @@ def main():
                         else:
                             os.environ[k] = v
             # the headline forward captured once into a hipGraph (torch.cuda.CUDAGraph around model(x)) and replayed: what a caller with a
-            # fixed batch shape gets by removing the host side of the six launches (results are bitwise the eager ones: tests/test_gpu_fullsize.py)
+            # fixed batch shape gets by removing the host side of the four launches (results are bitwise the eager ones: tests/test_gpu_fullsize.py)
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
